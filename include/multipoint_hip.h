@@ -1,0 +1,130 @@
+/*
+ * libmultipoint_hip.so -- C ABI of the MI355X (gfx950) implementation of the MultiPoint
+ * inference hot path (ethz-asl/multipoint).
+ *
+ * The reference has no FFI: its boundary is Python (class MultiPoint + three free functions).
+ * Each entry point below names the reference interface it replaces (paths relative to the
+ * reference repository root); multipoint_amd/ binds them with ctypes (see INTEGRATION.md for the
+ * stub a reference maintainer would add).
+ *
+ * Conventions
+ *   - every function returns MP_OK (0) or a negative MP_E* code; mp_last_error() gives the text.
+ *   - all tensor arguments are DEVICE pointers owned by the caller unless marked "host".
+ *     The library never frees or reallocates caller memory; outputs are fully overwritten.
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream).  Kernels are enqueued on
+ *     it; functions do not synchronise unless stated.
+ *   - one handle per (process, device); a handle is not thread-safe.  The handle owns the packed
+ *     device weights and one grow-only workspace.
+ *   - images / probability maps are fp32 [B][H][W] (== NCHW with C = 1), H and W multiples of 8.
+ *   - coarse descriptor maps are channels-last fp32 [B][H/8][W/8][D].
+ *   - keypoint lists are int32 [B][K][2] as (y, x) in row-major order (torch.nonzero order),
+ *     counts int32 [B].
+ */
+#ifndef MULTIPOINT_HIP_H
+#define MULTIPOINT_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MP_OK 0
+#define MP_EINVAL (-1)      /* bad argument / unsupported configuration */
+#define MP_EHIP (-2)        /* HIP runtime error */
+#define MP_ESTATE (-3)      /* call order (e.g. forward before load_weights) */
+#define MP_ENOMEM (-4)
+
+typedef struct mp_handle mp_handle;
+
+/* model: keys of MultiPoint.default_config (multipoint/models/MultiPoint.py:9-23) that change
+ * the computation */
+typedef struct mp_model_config {
+    int multispectral;          /* two encoders routed by is_optical (MultiPoint.py:55-59,107-122) */
+    int descriptor_head;
+    int descriptor_size;        /* 64 (shipped params.yaml) | 128 | 256 */
+    int normalize_descriptors;
+    int final_batchnorm;
+    int reflection_pad;         /* 1: ReflectionPad2d(1), 0: ZeroPad2d(1)  (MultiPoint.py:33-36) */
+    int bn_first;               /* MultiPoint.py:137-141 */
+    int double_convolution;     /* must be 1 */
+    int channel_version;        /* must be 0: channels [1,64,64,128,128], heads 256 */
+} mp_model_config;
+
+/* one entry of the reference state_dict (torch.save(net.state_dict()), train.py:161-173), host fp32 */
+typedef struct mp_tensor {
+    const char* name;           /* e.g. "encoder.5.weight", "detector_head_convolutions.5.running_var" */
+    const float* data;          /* host pointer, contiguous, reference layout (conv: OIHW) */
+    long long numel;
+} mp_tensor;
+
+/* lifetime ----------------------------------------------------------------------------------- */
+int mp_create(mp_handle** out, int device);
+void mp_destroy(mp_handle* h);
+const char* mp_last_error(const mp_handle* h);      /* h may be NULL: error of the last mp_create */
+const char* mp_version(void);
+
+/* replaces MultiPoint.__init__ + load_state_dict (MultiPoint.py:25-91,
+ * predict_align_image_pair.py:57-62): validates the key set strictly, repacks conv weights into
+ * MFMA fragment order, precomputes eval-mode BatchNorm scale/shift, uploads. */
+int mp_load_weights(mp_handle* h, const mp_model_config* cfg, const mp_tensor* tensors, int n_tensors);
+
+/* replaces MultiPoint.forward / forward_impl in eval mode (MultiPoint.py:99-135).
+ *   images      [B][H][W] fp32 in [0,1]
+ *   is_optical  host uint8[B] or NULL (only read when cfg.multispectral)
+ *   prob        [B][H][W] or NULL          (softmax -> drop dustbin -> PixelShuffle(8))
+ *   logits      [B][65][H/8][W/8] or NULL  (force_return_logits path, MultiPoint.py:153-154)
+ *   desc        [B][H/8][W/8][D] or NULL   (channels-last; L2-normalised if cfg says so) */
+int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optical, int B, int H,
+               int W, float* prob, float* logits, float* desc, void* stream);
+
+/* replaces utils.box_nms (multipoint/utils/utils.py:78-122) incl. the `prob * valid_mask`
+ * multiply of its callers (predict_align_image_pair.py:128,133).
+ *   valid_mask  uint8 [B][H][W] or NULL
+ *   prob_nms    [B][H][W] dense output (zeros except kept pixels, which keep their score)
+ *   max_rounds  0: run until converged (synchronises `stream`); >0: enqueue exactly that many
+ *               fixed-point rounds asynchronously, check with mp_nms_unresolved() after a sync.
+ * Tie-break (stated rule): priority = (score descending, row-major index ascending). */
+int mp_box_nms(mp_handle* h, const float* prob, const unsigned char* valid_mask, int B, int H, int W,
+               float size, float min_prob, float iou, int keep_top_k, float* prob_nms,
+               int max_rounds, void* stream);
+
+/* fused box_nms + torch.nonzero(prob_nms > min_prob) (predict_align_image_pair.py:170-171,
+ * evaluation.py:262-263): same NMS, but the survivors are returned as lists.
+ *   kp_yx [B][K][2], kp_score [B][K] (may be NULL), kp_count [B]; kp_count may exceed K when
+ *   keep_top_k == 0 and more than K pixels survive (only the first K are stored). */
+int mp_detect_keypoints(mp_handle* h, const float* prob, const unsigned char* valid_mask, int B, int H,
+                        int W, float size, float min_prob, float iou, int keep_top_k, int K,
+                        int* kp_yx, float* kp_score, int* kp_count, int max_rounds, void* stream);
+
+/* number of still-undecided NMS candidates of the last mp_box_nms / mp_detect_keypoints call
+ * (0 = exact result).  Synchronises `stream`. */
+int mp_nms_unresolved(mp_handle* h, int* unresolved, void* stream);
+
+/* replaces torch.nonzero(map > thr) on an arbitrary dense map. */
+int mp_extract_keypoints(mp_handle* h, const float* map, int B, int H, int W, float thr, int K,
+                         int* kp_yx, float* kp_score, int* kp_count, void* stream);
+
+/* replaces utils.interpolate_descriptors (multipoint/utils/utils.py:159-167).
+ *   desc [B][Hc][Wc][D] channels-last, out [B][K][D]; rows k >= kp_count[b] are left untouched. */
+int mp_sample_descriptors(mp_handle* h, const float* desc, int B, int Hc, int Wc, int D, int H, int W,
+                          const int* kp_yx, const int* kp_count, int K, float* out, void* stream);
+
+/* replaces utils.get_matches(..., 'nnmatcher' | 'bfmatcher' crossCheck=True)
+ * (multipoint/utils/matching.py:4-33, NNMatcher.match :41-72) for P independent pairs.
+ *   descA/descB: first pair's descriptors [K][D]; pair p at + p * pair_stride floats
+ *   countA/countB: int32, pair p at [p * count_stride]
+ *   threshold < 0 disables the distance test (plain mutual NN == crossCheck)
+ *   match_idx [P][K]: train index of query i or -1; match_dist [P][K]; match_count [P] */
+int mp_match_mutual_nn(mp_handle* h, const float* descA, const int* countA, const float* descB,
+                       const int* countB, long long pair_stride, int count_stride, int P, int K,
+                       int D, float threshold, int* match_idx, float* match_dist, int* match_count,
+                       void* stream);
+
+/* per-launch timing of mp_forward with hipEvents on the caller's stream (bench.py roofline leg).
+ * mp_profile_read synchronises; names[i] points to static strings. */
+int mp_profile_enable(mp_handle* h, int enable);
+int mp_profile_read(mp_handle* h, const char** names, float* ms, double* flop, int capacity, int* n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MULTIPOINT_HIP_H */

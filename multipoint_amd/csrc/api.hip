@@ -1,0 +1,678 @@
+// C ABI of libmultipoint_hip.so (declared in include/multipoint_hip.h): handle, weight repacking,
+// workspace, and the launch sequences of the hot path.
+#include "../../include/multipoint_hip.h"
+#include "mp_common.h"
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+struct ConvLayer {            // one MFMA conv launch
+    const char* name = "";
+    float *wpack = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
+    int cin = 0, cout = 0, taps = 9, nslices = 0;
+    bool pool = false, relu = true;
+};
+
+struct FirstLayer {
+    float *w = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
+};
+
+struct Encoder {
+    FirstLayer first;
+    ConvLayer conv[7];
+};
+
+struct ProfEntry {
+    const char* name;
+    hipEvent_t a, b;
+    double flop;
+};
+
+}  // namespace
+
+struct mp_handle {
+    int device = 0;
+    std::string err;
+    bool loaded = false;
+    mp_model_config cfg{};
+    std::vector<void*> weight_allocs;
+    Encoder enc[2];                 // [0] = encoder / encoder_thermal, [1] = encoder_optical
+    ConvLayer heads3, det1, desc1;
+    DevBuf ws;                      // forward workspace
+    DevBuf ws2;                     // NMS work map + kept lists
+    DevBuf ws3;                     // matching arg-min arrays
+    DevBuf nms_state;               // 64 round counters + tile flags
+    int last_nms_rounds = 0;
+    int* pinned = nullptr;          // small pinned host scratch (img lists, counters)
+    bool prof = false;
+    std::vector<ProfEntry> prof_entries;
+    size_t prof_used = 0;
+};
+
+namespace {
+
+int fail(mp_handle* h, int code, const std::string& msg)
+{
+    if (h) h->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define MP_HIP(expr)                                                                          \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess)                                                                 \
+            return fail(h, MP_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));       \
+    } while (0)
+
+int ensure(mp_handle* h, DevBuf& b, size_t bytes)
+{
+    if (b.bytes >= bytes) return MP_OK;
+    if (b.p) { MP_HIP(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(h, MP_ENOMEM, "hipMalloc(" + std::to_string(bytes) + " B): " + hipGetErrorString(e));
+    }
+    b.bytes = bytes;
+    return MP_OK;
+}
+
+int upload(mp_handle* h, const std::vector<float>& v, float** out)
+{
+    void* d = nullptr;
+    MP_HIP(hipMalloc(&d, v.size() * sizeof(float)));
+    h->weight_allocs.push_back(d);
+    MP_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    *out = static_cast<float*>(d);
+    return MP_OK;
+}
+
+void free_weights(mp_handle* h)
+{
+    for (void* p : h->weight_allocs) (void)hipFree(p);
+    h->weight_allocs.clear();
+    h->loaded = false;
+}
+
+struct TensorMap {
+    std::map<std::string, const mp_tensor*> m;
+    std::map<std::string, bool> used;
+    const float* get(const std::string& k, long long numel, std::string& err)
+    {
+        auto it = m.find(k);
+        if (it == m.end()) { err = "missing key in state_dict: " + k; return nullptr; }
+        if (it->second->numel != numel) {
+            err = "size mismatch for " + k + ": got " + std::to_string(it->second->numel) +
+                  " elements, expected " + std::to_string(numel);
+            return nullptr;
+        }
+        used[k] = true;
+        return it->second->data;
+    }
+};
+
+// eval-mode BatchNorm2d(eps=1e-5) as y = x*scale + shift, evaluated like ATen's CPU kernel
+// (batch_norm_cpu_collect_linear_and_constant_terms): invstd = 1/sqrt(var+eps); alpha = invstd*gamma;
+// beta' = beta - mean*alpha, all in fp32.
+bool bn_terms(TensorMap& tm, const std::string& prefix, int c, int padded, std::vector<float>& scale,
+              std::vector<float>& shift, std::string& err)
+{
+    const float* g = tm.get(prefix + ".weight", c, err); if (!g) return false;
+    const float* b = tm.get(prefix + ".bias", c, err); if (!b) return false;
+    const float* m = tm.get(prefix + ".running_mean", c, err); if (!m) return false;
+    const float* v = tm.get(prefix + ".running_var", c, err); if (!v) return false;
+    if (tm.m.count(prefix + ".num_batches_tracked")) tm.used[prefix + ".num_batches_tracked"] = true;
+    scale.assign(padded, 1.f); shift.assign(padded, 0.f);
+    for (int i = 0; i < c; ++i) {
+        const float invstd = 1.0f / std::sqrt(v[i] + 1e-5f);
+        const float alpha = invstd * g[i];
+        scale[i] = alpha;
+        shift[i] = b[i] - m[i] * alpha;
+    }
+    return true;
+}
+
+// Packed B-operand layout consumed by conv_mfma_kernel:
+//   [slice][chunk][step = tap*4 + kgroup][nblock(2)][lane(64)][4]
+//   element e of lane l = W[cout = slice*64 + nblock*32 + (l&31)][cin = chunk*32 + kgroup*8 + (l>>5)*4 + e][tap]
+// srcs: list of OIHW tensors concatenated along O (the two 3x3 head convs share one launch).
+void pack_conv_weights(const std::vector<const float*>& srcs, const std::vector<int>& couts, int cin,
+                       int taps, std::vector<float>& out)
+{
+    int cout = 0;
+    for (int c : couts) cout += c;
+    const int nslices = (cout + 63) / 64, nchunks = cin / 32;
+    out.assign((size_t)nslices * nchunks * taps * 4 * 2 * 64 * 4, 0.f);
+    size_t o = 0;
+    for (int s = 0; s < nslices; ++s)
+        for (int c = 0; c < nchunks; ++c)
+            for (int tap = 0; tap < taps; ++tap)
+                for (int g = 0; g < 4; ++g)
+                    for (int nb = 0; nb < 2; ++nb)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < 4; ++e, ++o) {
+                                int co = s * 64 + nb * 32 + (l & 31);
+                                const int ci = c * 32 + g * 8 + (l >> 5) * 4 + e;
+                                if (co >= cout) continue;
+                                size_t t = 0;
+                                while (co >= couts[t]) { co -= couts[t]; ++t; }
+                                out[o] = srcs[t][((size_t)co * cin + ci) * taps + tap];
+                            }
+}
+
+int build_conv(mp_handle* h, TensorMap& tm, ConvLayer& L, const char* name,
+               const std::vector<std::string>& conv_keys, const std::vector<std::string>& bn_keys,
+               const std::vector<int>& couts, int cin, int taps, bool pool, bool relu)
+{
+    std::string err;
+    int cout = 0;
+    for (int c : couts) cout += c;
+    const int padded = ((cout + 63) / 64) * 64;
+    std::vector<const float*> srcs;
+    std::vector<float> bias(padded, 0.f), scale(padded, 1.f), shift(padded, 0.f);
+    int off = 0;
+    for (size_t i = 0; i < conv_keys.size(); ++i) {
+        const float* w = tm.get(conv_keys[i] + ".weight", (long long)couts[i] * cin * taps, err);
+        if (!w) return fail(h, MP_EINVAL, err);
+        const float* b = tm.get(conv_keys[i] + ".bias", couts[i], err);
+        if (!b) return fail(h, MP_EINVAL, err);
+        srcs.push_back(w);
+        for (int c = 0; c < couts[i]; ++c) bias[off + c] = b[c];
+        if (!bn_keys[i].empty()) {
+            std::vector<float> s, t;
+            if (!bn_terms(tm, bn_keys[i], couts[i], couts[i], s, t, err)) return fail(h, MP_EINVAL, err);
+            for (int c = 0; c < couts[i]; ++c) { scale[off + c] = s[c]; shift[off + c] = t[c]; }
+        }
+        off += couts[i];
+    }
+    std::vector<float> packed;
+    pack_conv_weights(srcs, couts, cin, taps, packed);
+    L.name = name; L.cin = cin; L.cout = cout; L.taps = taps; L.nslices = padded / 64;
+    L.pool = pool; L.relu = relu;
+    int rc;
+    if ((rc = upload(h, packed, &L.wpack))) return rc;
+    if ((rc = upload(h, bias, &L.bias))) return rc;
+    if ((rc = upload(h, scale, &L.scale))) return rc;
+    if ((rc = upload(h, shift, &L.shift))) return rc;
+    return MP_OK;
+}
+
+const char* kEncNames[7] = {"enc.conv2", "enc.conv3", "enc.conv4", "enc.conv5", "enc.conv6", "enc.conv7",
+                            "enc.conv8"};
+
+int build_encoder(mp_handle* h, TensorMap& tm, Encoder& E, const std::string& prefix)
+{
+    // generate_encoder (MultiPoint.py:168-185): Sequential indices, 4 modules per conv block
+    // (pad, conv, X, Y) and one MaxPool2d after blocks 2, 4, 6.
+    static const int conv_idx[8] = {1, 5, 10, 14, 19, 23, 28, 32};
+    static const int chan[9] = {1, 64, 64, 64, 64, 128, 128, 128, 128};
+    static const bool pool[8] = {false, true, false, true, false, true, false, false};
+    const int bn_off = h->cfg.bn_first ? 1 : 2;
+    std::string err;
+    {   // first layer (Cin = 1): [tap][cout]
+        const std::string ck = prefix + "." + std::to_string(conv_idx[0]);
+        const std::string bk = prefix + "." + std::to_string(conv_idx[0] + bn_off);
+        const float* w = tm.get(ck + ".weight", 64 * 9, err); if (!w) return fail(h, MP_EINVAL, err);
+        const float* b = tm.get(ck + ".bias", 64, err); if (!b) return fail(h, MP_EINVAL, err);
+        std::vector<float> wt(9 * 64), bias(b, b + 64), s, t;
+        for (int co = 0; co < 64; ++co)
+            for (int k = 0; k < 9; ++k) wt[k * 64 + co] = w[co * 9 + k];
+        if (!bn_terms(tm, bk, 64, 64, s, t, err)) return fail(h, MP_EINVAL, err);
+        int rc;
+        if ((rc = upload(h, wt, &E.first.w))) return rc;
+        if ((rc = upload(h, bias, &E.first.bias))) return rc;
+        if ((rc = upload(h, s, &E.first.scale))) return rc;
+        if ((rc = upload(h, t, &E.first.shift))) return rc;
+    }
+    for (int i = 1; i < 8; ++i) {
+        const std::string ck = prefix + "." + std::to_string(conv_idx[i]);
+        const std::string bk = prefix + "." + std::to_string(conv_idx[i] + bn_off);
+        int rc = build_conv(h, tm, E.conv[i - 1], kEncNames[i - 1], {ck}, {bk}, {chan[i + 1]}, chan[i], 9,
+                            pool[i], true);
+        if (rc) return rc;
+    }
+    return MP_OK;
+}
+
+int pick_mbw(int H, int W)
+{
+    long long best = -1;
+    int arg = 32;
+    for (int mbw : {32, 16, 8}) {
+        const int tw = mbw, th = 256 / mbw;
+        const long long area = (long long)((H + th - 1) / th) * th * ((W + tw - 1) / tw) * tw;
+        if (best < 0 || area < best) { best = area; arg = mbw; }
+    }
+    return arg;
+}
+
+void prof_begin(mp_handle* h, const char* name, double flop, hipStream_t s)
+{
+    if (!h->prof) return;
+    if (h->prof_used == h->prof_entries.size()) {
+        ProfEntry e{};
+        (void)hipEventCreate(&e.a); (void)hipEventCreate(&e.b);
+        h->prof_entries.push_back(e);
+    }
+    ProfEntry& e = h->prof_entries[h->prof_used];
+    e.name = name; e.flop = flop;
+    (void)hipEventRecord(e.a, s);
+}
+
+void prof_end(mp_handle* h, hipStream_t s)
+{
+    if (!h->prof) return;
+    (void)hipEventRecord(h->prof_entries[h->prof_used].b, s);
+    ++h->prof_used;
+}
+
+void run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, int in_coff, float* out,
+              int out_cstride, int out_coff, int B, int H, int W, const int* img_list, hipStream_t s)
+{
+    ConvParams p{};
+    p.in = in; p.out = out; p.wpack = L.wpack; p.bias = L.bias; p.scale = L.scale; p.shift = L.shift;
+    p.img_list = img_list;
+    p.B = B; p.H = H; p.W = W;
+    p.in_cstride = in_cstride; p.in_coff = in_coff; p.cin = L.cin;
+    p.out_cstride = out_cstride; p.out_coff = out_coff; p.cout = L.cout;
+    p.nslices = L.nslices;
+    p.pad_zero = h->cfg.reflection_pad ? 0 : 1;
+    p.bn_first = h->cfg.bn_first;
+    p.relu = L.relu ? 1 : 0;
+    int mbw = 32;
+    if (L.taps == 9) {
+        mbw = pick_mbw(H, W);
+        const int tw = mbw, th = 256 / mbw;
+        p.tiles_x = (W + tw - 1) / tw; p.tiles_y = (H + th - 1) / th;
+    } else {
+        p.total_px = (long long)B * H * W;
+    }
+    prof_begin(h, L.name, 2.0 * L.taps * L.cin * L.cout * (double)B * H * W, s);
+    launch_conv_mfma(p, L.taps, mbw, L.pool, s);
+    prof_end(h, s);
+}
+
+bool footprint(float size, float iou, NmsFootprint& fp)
+{
+    // torchvision nms CPU kernel arithmetic (fp32) for two size x size boxes offset by (dy,dx):
+    //   inter = max(0, size-|dy|) * max(0, size-|dx|); ovr = inter / (area + area - inter) > iou
+    int R = (int)std::ceil(size) - 1;
+    if (R < 0) R = 0;
+    if (R > MP_NMS_MAX_R) return false;
+    fp.R = R;
+    const float half = size * 0.5f;
+    for (int dy = -R; dy <= R; ++dy) {
+        unsigned m = 0;
+        for (int dx = -R; dx <= R; ++dx) {
+            // boxes [y-half, x-half, y+half, x+half] at a generic in-image position
+            const float y1a = 100.f - half, x1a = 100.f - half, y2a = 100.f + half, x2a = 100.f + half;
+            const float y1b = (100.f + dy) - half, x1b = (100.f + dx) - half;
+            const float y2b = (100.f + dy) + half, x2b = (100.f + dx) + half;
+            const float area_a = (y2a - y1a) * (x2a - x1a), area_b = (y2b - y1b) * (x2b - x1b);
+            float w = std::fmin(y2a, y2b) - std::fmax(y1a, y1b); if (w < 0.f) w = 0.f;
+            float hh = std::fmin(x2a, x2b) - std::fmax(x1a, x1b); if (hh < 0.f) hh = 0.f;
+            const float inter = w * hh;
+            const float ovr = inter / (area_a + area_b - inter);
+            if (ovr > iou) m |= 1u << (dx + R);
+        }
+        fp.rowmask[dy + R] = m;
+    }
+    return true;
+}
+
+int nms_common(mp_handle* h, const float* prob, const unsigned char* mask, int B, int H, int W,
+               float size, float min_prob, float iou, int topk, int K, int* kp_yx, float* kp_score,
+               int* kp_count, float* prob_nms, int max_rounds, hipStream_t s)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || (W % 4) != 0)
+        return fail(h, MP_EINVAL, "box_nms: need B,H,W > 0 and W % 4 == 0");
+    NmsFootprint fp{};
+    if (!footprint(size, iou, fp))
+        return fail(h, MP_EINVAL, "box_nms: box size > " + std::to_string(MP_NMS_MAX_R + 1) + " unsupported");
+    const long long n = (long long)B * H * W;
+    const int ntiles = B * ((W + 31) / 32) * ((H + 31) / 32);
+    // workspace: work map | list_idx | list_score
+    const size_t bytes = (size_t)n * 4 * 3;
+    int rc;
+    if ((rc = ensure(h, h->ws2, bytes))) return rc;
+    if ((rc = ensure(h, h->nms_state, (size_t)(64 + 2 * ntiles) * 4))) return rc;
+    float* work = static_cast<float*>(h->ws2.p);
+    int* list_idx = reinterpret_cast<int*>(work + n);
+    float* list_score = work + 2 * n;
+    int* remaining = static_cast<int*>(h->nms_state.p);
+    MP_HIP(hipMemsetAsync(remaining, 0, 64 * 4, s));
+    launch_nms_init(prob, mask, min_prob, work, n, s);
+    int round = 0;
+    const int per = max_rounds > 0 ? max_rounds : 8;
+    for (;;) {
+        for (int r = 0; r < per && round < 64; ++r, ++round) launch_nms_round(work, B, H, W, fp, remaining, round, s);
+        if (max_rounds > 0 || round >= 64) break;
+        MP_HIP(hipMemcpyAsync(h->pinned, remaining + (round - 1), 4, hipMemcpyDeviceToHost, s));
+        MP_HIP(hipStreamSynchronize(s));
+        if (h->pinned[0] == 0) break;
+    }
+    h->last_nms_rounds = round;
+    launch_select_keypoints(work, B, H, W, topk, K, list_idx, list_score, H * W, kp_yx, kp_score, kp_count,
+                            prob_nms, s);
+    MP_HIP(hipGetLastError());
+    if (max_rounds == 0 && round >= 64) {
+        MP_HIP(hipMemcpyAsync(h->pinned, remaining + 63, 4, hipMemcpyDeviceToHost, s));
+        MP_HIP(hipStreamSynchronize(s));
+        if (h->pinned[0] != 0) return fail(h, MP_ESTATE, "box_nms did not converge within 64 rounds");
+    }
+    return MP_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+const char* mp_version(void) { return "multipoint_hip 0.1 (gfx950)"; }
+
+const char* mp_last_error(const mp_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int mp_create(mp_handle** out, int device)
+{
+    mp_handle* h = nullptr;
+    if (!out) return fail(h, MP_EINVAL, "mp_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    MP_HIP(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev)
+        return fail(h, MP_EINVAL, "mp_create: device " + std::to_string(device) + " not available (" +
+                                      std::to_string(ndev) + " HIP devices visible)");
+    MP_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    MP_HIP(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(h, MP_EINVAL, std::string("mp_create: kernels are built for gfx950 only, device is ") +
+                                      prop.gcnArchName);
+    mp_handle* hh = new mp_handle();
+    hh->device = device;
+    if (hipHostMalloc(reinterpret_cast<void**>(&hh->pinned), 4096) != hipSuccess) {
+        delete hh;
+        return fail(h, MP_ENOMEM, "mp_create: hipHostMalloc failed");
+    }
+    *out = hh;
+    return MP_OK;
+}
+
+void mp_destroy(mp_handle* h)
+{
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    free_weights(h);
+    if (h->ws.p) (void)hipFree(h->ws.p);
+    if (h->ws2.p) (void)hipFree(h->ws2.p);
+    if (h->ws3.p) (void)hipFree(h->ws3.p);
+    if (h->nms_state.p) (void)hipFree(h->nms_state.p);
+    if (h->pinned) (void)hipHostFree(h->pinned);
+    for (auto& e : h->prof_entries) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    delete h;
+}
+
+int mp_load_weights(mp_handle* h, const mp_model_config* cfg, const mp_tensor* tensors, int n_tensors)
+{
+    if (!h) return MP_EINVAL;
+    if (!cfg || (!tensors && n_tensors > 0)) return fail(h, MP_EINVAL, "mp_load_weights: NULL argument");
+    if (cfg->channel_version != 0)
+        return fail(h, MP_EINVAL, "unsupported model config: channel_version must be 0 "
+                                  "(channels [1,64,64,128,128]; MultiPoint.py:38-40)");
+    if (!cfg->double_convolution)
+        return fail(h, MP_EINVAL, "unsupported model config: double_convolution must be true");
+    if (cfg->descriptor_head && cfg->descriptor_size != 64 && cfg->descriptor_size != 128 &&
+        cfg->descriptor_size != 256)
+        return fail(h, MP_EINVAL, "unsupported model config: descriptor_size must be 64, 128 or 256");
+    MP_HIP(hipSetDevice(h->device));
+    free_weights(h);
+    h->cfg = *cfg;
+    TensorMap tm;
+    for (int i = 0; i < n_tensors; ++i) {
+        if (!tensors[i].name || (!tensors[i].data && tensors[i].numel > 0))
+            return fail(h, MP_EINVAL, "mp_load_weights: tensor " + std::to_string(i) + " has NULL field");
+        tm.m[tensors[i].name] = &tensors[i];
+    }
+    int rc;
+    if (cfg->multispectral) {
+        if ((rc = build_encoder(h, tm, h->enc[0], "encoder_thermal"))) return rc;
+        if ((rc = build_encoder(h, tm, h->enc[1], "encoder_optical"))) return rc;
+    } else {
+        if ((rc = build_encoder(h, tm, h->enc[0], "encoder"))) return rc;
+    }
+    const std::string det = "detector_head_convolutions", dsc = "descriptor_head_convolutions";
+    const std::string bn3 = cfg->bn_first ? ".2" : ".3";
+    // both 3x3 head convs read the same encoder output: one launch with N = 256 (+256)
+    if (cfg->descriptor_head)
+        rc = build_conv(h, tm, h->heads3, "heads.conv3x3", {det + ".1", dsc + ".1"}, {det + bn3, dsc + bn3},
+                        {256, 256}, 128, 9, false, true);
+    else
+        rc = build_conv(h, tm, h->heads3, "heads.conv3x3", {det + ".1"}, {det + bn3}, {256}, 128, 9, false, true);
+    if (rc) return rc;
+    if ((rc = build_conv(h, tm, h->det1, "det.conv1x1", {det + ".4"},
+                         {cfg->final_batchnorm ? det + ".5" : std::string()}, {65}, 256, 1, false, false)))
+        return rc;
+    if (cfg->descriptor_head &&
+        (rc = build_conv(h, tm, h->desc1, "desc.conv1x1", {dsc + ".4"},
+                         {cfg->final_batchnorm ? dsc + ".5" : std::string()}, {cfg->descriptor_size}, 256, 1,
+                         false, false)))
+        return rc;
+    // strict=True semantics of load_state_dict: no unexpected keys
+    for (auto& kv : tm.m)
+        if (!tm.used.count(kv.first)) {
+            if (kv.first.size() > 20 && kv.first.rfind(".num_batches_tracked") == kv.first.size() - 20) continue;
+            free_weights(h);
+            return fail(h, MP_EINVAL, "unexpected key in state_dict: " + kv.first);
+        }
+    h->loaded = true;
+    return MP_OK;
+}
+
+int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optical, int B, int H, int W,
+               float* prob, float* logits, float* desc, void* stream)
+{
+    if (!h) return MP_EINVAL;
+    if (!h->loaded) return fail(h, MP_ESTATE, "mp_forward: no weights loaded (call mp_load_weights)");
+    if (!images || B <= 0 || H <= 0 || W <= 0) return fail(h, MP_EINVAL, "mp_forward: bad image tensor");
+    if ((H % 8) != 0 || (W % 8) != 0)
+        return fail(h, MP_EINVAL, "mp_forward: H and W must be divisible by 8 (got " + std::to_string(H) +
+                                      "x" + std::to_string(W) + ")");
+    if (desc && !h->cfg.descriptor_head) return fail(h, MP_EINVAL, "mp_forward: model has no descriptor head");
+    if (h->cfg.multispectral && !is_optical)
+        return fail(h, MP_EINVAL, "mp_forward: multispectral model needs is_optical");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MP_HIP(hipSetDevice(h->device));
+    const int Hc = H / 8, Wc = W / 8;
+    const long long npx = (long long)B * Hc * Wc;
+    const int D = h->cfg.descriptor_size;
+    const int headc = h->cfg.descriptor_head ? 512 : 256;
+    // workspace: P (B*H*W*64) | Q (B*H*W*16) | logits (npx*80) | desc raw (npx*D) | img lists
+    const size_t nP = (size_t)B * H * W * 64, nQ = (size_t)B * H * W * 16;
+    const size_t nL = (size_t)npx * 80, nD = (size_t)npx * (h->cfg.descriptor_head ? D : 0);
+    int rc;
+    if ((rc = ensure(h, h->ws, (nP + nQ + nL + nD) * 4 + 2 * 1024 * 4 + 256))) return rc;
+    float* P = static_cast<float*>(h->ws.p);
+    float* Q = P + nP;
+    float* Lg = Q + nQ;
+    float* Dr = Lg + nL;
+    int* lists = reinterpret_cast<int*>(Dr + nD);
+    h->prof_used = 0;
+
+    // encoder(s): multispectral routes each image by is_optical (MultiPoint.py:107-122)
+    int nsets = 1, counts[2] = {B, 0};
+    const int* lptr[2] = {nullptr, nullptr};
+    if (h->cfg.multispectral) {
+        if (B > 512) return fail(h, MP_EINVAL, "mp_forward: multispectral B > 512 unsupported");
+        nsets = 2;
+        std::vector<int> host(1024, 0);      // [0..512) thermal image ids, [512..1024) optical ids
+        counts[0] = counts[1] = 0;
+        for (int b = 0; b < B; ++b) {
+            if (is_optical[b]) host[512 + counts[1]++] = b;
+            else host[counts[0]++] = b;
+        }
+        // pageable source: the runtime stages it before returning, so `host` may die here
+        MP_HIP(hipMemcpyAsync(lists, host.data(), 1024 * 4, hipMemcpyHostToDevice, s));
+        lptr[0] = lists; lptr[1] = lists + 512;
+    }
+    for (int e = 0; e < nsets; ++e) {
+        const int nb = counts[e];
+        if (nb == 0) continue;
+        const Encoder& E = h->enc[e];
+        Conv1Params c1{};
+        c1.in = images; c1.out = P; c1.w = E.first.w; c1.bias = E.first.bias; c1.scale = E.first.scale;
+        c1.shift = E.first.shift; c1.img_list = lptr[e]; c1.B = nb; c1.H = H; c1.W = W;
+        c1.pad_zero = h->cfg.reflection_pad ? 0 : 1; c1.bn_first = h->cfg.bn_first;
+        prof_begin(h, "enc.conv1", 2.0 * 9 * 64 * (double)nb * H * W, s);
+        launch_conv_first(c1, s);
+        prof_end(h, s);
+        int hh = H, ww = W;
+        float* src = P;
+        float* dst = Q;
+        for (int i = 0; i < 7; ++i) {
+            const ConvLayer& L = E.conv[i];
+            run_conv(h, L, src, L.cin, 0, dst, L.cout, 0, nb, hh, ww, lptr[e], s);
+            if (L.pool) { hh /= 2; ww /= 2; }
+            float* t = src; src = dst; dst = t;
+        }
+        // 7 layers: P->Q->P->Q->P->Q->P->Q : encoder output ends in Q
+    }
+    // heads
+    run_conv(h, h->heads3, Q, 128, 0, P, headc, 0, B, Hc, Wc, nullptr, s);
+    run_conv(h, h->det1, P, headc, 0, Lg, 80, 0, B, Hc, Wc, nullptr, s);
+    if (prob || logits) {
+        prof_begin(h, "det.softmax_shuffle", 0.0, s);
+        launch_det_post(Lg, 80, B, Hc, Wc, prob, logits, s);
+        prof_end(h, s);
+    }
+    if (desc) {
+        run_conv(h, h->desc1, P, headc, 256, desc, D, 0, B, Hc, Wc, nullptr, s);
+        prof_begin(h, "desc.l2norm", 0.0, s);
+        if (h->cfg.normalize_descriptors) launch_desc_l2norm(desc, desc, npx, D, 1, s);
+        prof_end(h, s);
+    }
+    MP_HIP(hipGetLastError());
+    return MP_OK;
+}
+
+int mp_box_nms(mp_handle* h, const float* prob, const unsigned char* valid_mask, int B, int H, int W,
+               float size, float min_prob, float iou, int keep_top_k, float* prob_nms, int max_rounds,
+               void* stream)
+{
+    if (!h) return MP_EINVAL;
+    if (!prob || !prob_nms) return fail(h, MP_EINVAL, "mp_box_nms: NULL tensor");
+    MP_HIP(hipSetDevice(h->device));
+    return nms_common(h, prob, valid_mask, B, H, W, size, min_prob, iou, keep_top_k, 0, nullptr, nullptr,
+                      nullptr, prob_nms, max_rounds, static_cast<hipStream_t>(stream));
+}
+
+int mp_detect_keypoints(mp_handle* h, const float* prob, const unsigned char* valid_mask, int B, int H,
+                        int W, float size, float min_prob, float iou, int keep_top_k, int K, int* kp_yx,
+                        float* kp_score, int* kp_count, int max_rounds, void* stream)
+{
+    if (!h) return MP_EINVAL;
+    if (!prob || !kp_yx || !kp_count || K <= 0) return fail(h, MP_EINVAL, "mp_detect_keypoints: bad argument");
+    MP_HIP(hipSetDevice(h->device));
+    return nms_common(h, prob, valid_mask, B, H, W, size, min_prob, iou, keep_top_k, K, kp_yx, kp_score,
+                      kp_count, nullptr, max_rounds, static_cast<hipStream_t>(stream));
+}
+
+int mp_nms_unresolved(mp_handle* h, int* unresolved, void* stream)
+{
+    if (!h || !unresolved) return MP_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    *unresolved = 0;
+    if (h->last_nms_rounds <= 0 || !h->nms_state.p) return MP_OK;
+    const int* remaining = static_cast<const int*>(h->nms_state.p);
+    MP_HIP(hipMemcpyAsync(h->pinned, remaining + (h->last_nms_rounds - 1), 4, hipMemcpyDeviceToHost, s));
+    MP_HIP(hipStreamSynchronize(s));
+    *unresolved = h->pinned[0];
+    return MP_OK;
+}
+
+int mp_extract_keypoints(mp_handle* h, const float* map, int B, int H, int W, float thr, int K, int* kp_yx,
+                         float* kp_score, int* kp_count, void* stream)
+{
+    if (!h) return MP_EINVAL;
+    if (!map || !kp_yx || !kp_count || K <= 0 || B <= 0 || ((long long)H * W) % 4 != 0)
+        return fail(h, MP_EINVAL, "mp_extract_keypoints: bad argument (H*W must be a multiple of 4)");
+    MP_HIP(hipSetDevice(h->device));
+    launch_extract_threshold(map, B, H, W, thr, K, kp_yx, kp_score, kp_count, static_cast<hipStream_t>(stream));
+    MP_HIP(hipGetLastError());
+    return MP_OK;
+}
+
+int mp_sample_descriptors(mp_handle* h, const float* desc, int B, int Hc, int Wc, int D, int H, int W,
+                          const int* kp_yx, const int* kp_count, int K, float* out, void* stream)
+{
+    if (!h) return MP_EINVAL;
+    if (!desc || !kp_yx || !kp_count || !out) return fail(h, MP_EINVAL, "mp_sample_descriptors: NULL tensor");
+    if (D % 64 != 0 || D > 256 || D <= 0)
+        return fail(h, MP_EINVAL, "mp_sample_descriptors: D must be 64, 128, 192 or 256");
+    MP_HIP(hipSetDevice(h->device));
+    launch_sample_desc(desc, B, Hc, Wc, D, H, W, kp_yx, kp_count, K, out, static_cast<hipStream_t>(stream));
+    MP_HIP(hipGetLastError());
+    return MP_OK;
+}
+
+int mp_match_mutual_nn(mp_handle* h, const float* descA, const int* countA, const float* descB,
+                       const int* countB, long long pair_stride, int count_stride, int P, int K, int D,
+                       float threshold, int* match_idx, float* match_dist, int* match_count, void* stream)
+{
+    if (!h) return MP_EINVAL;
+    if (!descA || !descB || !countA || !countB || !match_idx || !match_dist || !match_count)
+        return fail(h, MP_EINVAL, "mp_match_mutual_nn: NULL tensor");
+    if (D != 64 && D != 128 && D != 256) return fail(h, MP_EINVAL, "mp_match_mutual_nn: D must be 64, 128 or 256");
+    if (P <= 0 || K <= 0) return fail(h, MP_EINVAL, "mp_match_mutual_nn: P and K must be positive");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MP_HIP(hipSetDevice(h->device));
+    const size_t need = (size_t)P * K * 8 * 2;      // packed (distance bits, index) arg-min arrays
+    int rc;
+    if ((rc = ensure(h, h->ws3, need))) return rc;
+    unsigned long long* rowbest = static_cast<unsigned long long*>(h->ws3.p);
+    unsigned long long* colbest = rowbest + (size_t)P * K;
+    MP_HIP(hipMemsetAsync(match_count, 0, (size_t)P * 4, s));
+    launch_match_impl(descA, countA, descB, countB, pair_stride, count_stride, P, K, D, threshold, rowbest,
+                      colbest, match_idx, match_dist, match_count, s);
+    MP_HIP(hipGetLastError());
+    return MP_OK;
+}
+
+int mp_profile_enable(mp_handle* h, int enable)
+{
+    if (!h) return MP_EINVAL;
+    h->prof = enable != 0;
+    h->prof_used = 0;
+    return MP_OK;
+}
+
+int mp_profile_read(mp_handle* h, const char** names, float* ms, double* flop, int capacity, int* n)
+{
+    if (!h || !n) return MP_EINVAL;
+    *n = 0;
+    for (size_t i = 0; i < h->prof_used && (int)i < capacity; ++i) {
+        ProfEntry& e = h->prof_entries[i];
+        MP_HIP(hipEventSynchronize(e.b));
+        float t = 0.f;
+        MP_HIP(hipEventElapsedTime(&t, e.a, e.b));
+        if (names) names[i] = e.name;
+        if (ms) ms[i] = t;
+        if (flop) flop[i] = e.flop;
+        ++*n;
+    }
+    return MP_OK;
+}
+
+}  // extern "C"

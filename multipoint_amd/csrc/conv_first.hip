@@ -1,0 +1,103 @@
+// First encoder block: ReflectionPad2d(1) -> Conv2d(1, 64, 3) -> ReLU -> BatchNorm2d(64)
+// (reference multipoint/models/MultiPoint.py:143-148 with N_in = 1, encoder modules 0-3).
+// K = 9 only: arithmetic intensity 4.4 FLOP/B, i.e. bound by the 64-channel NHWC output write
+// (78.6 MB per 480x640 image).  Direct VALU convolution: 16 lanes share one pixel, each lane owns
+// 4 consecutive output channels whose 36 weights + bias/scale/shift live in registers; a wave
+// writes 4 adjacent pixels = 1 KiB contiguous per store instruction.
+#include "mp_common.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 32;              // output tile per workgroup
+constexpr int LW = TW + 2, LH = TH + 2;
+
+__device__ __forceinline__ int reflect_clamp1(int v, int n)
+{
+    v = v < 0 ? -v : v;
+    v = v >= n ? 2 * (n - 1) - v : v;
+    v = v < 0 ? 0 : v;
+    return v >= n ? n - 1 : v;
+}
+
+__global__ __launch_bounds__(256) void conv_first_kernel(const Conv1Params p)
+{
+    __shared__ float tile[LH * LW];
+    const int tid = threadIdx.x;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int bi = t / tiles_y;
+    const int img = p.img_list ? p.img_list[bi] : bi;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const float* in = p.in + (long long)img * p.H * p.W;
+
+    for (int f = tid; f < LH * LW; f += 256) {
+        const int ly = f / LW, lx = f - ly * LW;
+        int gy = y0 + ly - 1, gx = x0 + lx - 1;
+        float v;
+        if (p.pad_zero) {
+            const bool zero = (gy < 0) | (gy >= p.H) | (gx < 0) | (gx >= p.W);
+            gy = min(max(gy, 0), p.H - 1); gx = min(max(gx, 0), p.W - 1);
+            v = zero ? 0.f : in[gy * p.W + gx];
+        } else {
+            v = in[reflect_clamp1(gy, p.H) * p.W + reflect_clamp1(gx, p.W)];
+        }
+        tile[f] = v;
+    }
+
+    // this lane's 4 output channels
+    const int c4 = (tid & 15) * 4;
+    float w[9][4], bia[4], scl[4], sft[4];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p.w + k * 64 + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) w[k][e] = v[e];
+    }
+    {
+        const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + c4);
+        const f32x4 s = *reinterpret_cast<const f32x4*>(p.scale + c4);
+        const f32x4 h = *reinterpret_cast<const f32x4*>(p.shift + c4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bia[e] = b[e]; scl[e] = s[e]; sft[e] = h[e]; }
+    }
+    __syncthreads();
+
+    float* out = p.out + (long long)img * p.H * p.W * 64;
+    const int psub = tid >> 4;                    // 16 pixels per pass
+#pragma unroll 4
+    for (int it = 0; it < (TH * TW) / 16; ++it) {
+        const int pix = it * 16 + psub;
+        const int py = pix / TW, px = pix % TW;
+        float x[9];
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) x[kh * 3 + kw] = tile[(py + kh) * LW + px + kw];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) a = fmaf(x[k], w[k][e], a);
+            a += bia[e];
+            if (p.bn_first) a = fmaxf(a * scl[e] + sft[e], 0.f);
+            else a = fmaxf(a, 0.f) * scl[e] + sft[e];
+            o[e] = a;
+        }
+        const int oy = y0 + py, ox = x0 + px;
+        if (oy < p.H && ox < p.W)
+            *reinterpret_cast<f32x4*>(out + ((long long)oy * p.W + ox) * 64 + c4) = o;
+    }
+}
+
+}  // namespace
+
+void launch_conv_first(const Conv1Params& p, hipStream_t s)
+{
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    const long long nblk = (long long)p.B * tiles_x * tiles_y;
+    if (nblk <= 0) return;
+    hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)nblk), dim3(256), 0, s, p);
+}

@@ -1,0 +1,289 @@
+// 3x3 / 1x1 convolution as an implicit GEMM on the exact-fp32 matrix instruction of gfx950
+// (v_mfma_f32_32x32x2_f32: f32 in, f32 accumulate, bitwise a k-ordered fmaf chain).
+//
+// Replaces, for the MultiPoint encoder and heads (reference multipoint/models/MultiPoint.py:143-148,
+// :62-66, :78-82, :168-185), the ATen sequence ReflectionPad2d(1) -> Conv2d(k=3) -> ReLU ->
+// BatchNorm2d(eval) [-> MaxPool2d(2,2)] with ONE kernel: the padded halo tile is staged in LDS once
+// and re-used by all 9 taps, bias/ReLU/BN-affine/2x2-max run in the epilogue on the accumulators.
+//
+// GEMM view:  M = output pixels, N = output channels, K = taps * Cin.
+//   A[m][k]  = in[pixel m shifted by tap][cin]      (LDS halo tile, read as ds_read_b128)
+//   B[k][n]  = packed weights, streamed from L2 straight into VGPRs in MFMA-fragment order
+//              (1 KiB fully coalesced global_load_dwordx4 per 32-wide N-block per 8 k)
+//   D        = 32x32 fp32 tiles, 16 VGPRs each: col = lane&31 (channel), row = pixel
+// Workgroup = 256 threads = 4 waves, tile = 256 pixels x 64 channels; wave = 2x2 MFMA tiles
+// (64 accumulator VGPRs).  K is walked in chunks of 32 input channels: per chunk the LDS tile is
+// (tile+halo) x 32 ch = ~48 KiB, so three workgroups share a CU and their load/compute phases
+// overlap (the fp32 MFMA takes 64 cycles per issue, everything else hides behind it).
+#include "mp_common.h"
+
+namespace {
+
+constexpr int CK = 32;        // input channels per LDS chunk
+constexpr int PS = CK + 4;    // LDS pixel stride in floats (144 B: 16 consecutive pixels hit
+                              // 16 distinct 16-byte bank slots -> conflict-free ds_read_b128)
+
+template <int TAPS, int MBW>
+struct Geo {
+    static constexpr int MBH = 32 / MBW;
+    static constexpr int TW = MBW;
+    static constexpr int TH = 256 / MBW;
+    static constexpr int HALO = (TAPS == 9) ? 1 : 0;
+    static constexpr int LW = TW + 2 * HALO;
+    static constexpr int LH = TH + 2 * HALO;
+    static constexpr int NPIX = LW * LH;
+    static constexpr int NF4 = NPIX * (CK / 4);          // float4 per chunk tile
+    static constexpr int NITER = (NF4 + 255) / 256;      // staging float4 per thread
+    static constexpr int STEPS = TAPS * (CK / 8);        // k8-steps per chunk
+};
+
+__device__ __forceinline__ int reflect_clamp(int v, int n)
+{
+    v = v < 0 ? -v : v;                     // ReflectionPad2d(1): -1 -> 1
+    v = v >= n ? 2 * (n - 1) - v : v;       //                      n -> n-2
+    v = v < 0 ? 0 : v;
+    return v >= n ? n - 1 : v;              // (only reachable for pixels outside the image tile)
+}
+
+template <int TAPS, int MBW, bool POOL>
+__global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvParams p)
+{
+    using G = Geo<TAPS, MBW>;
+    __shared__ __attribute__((aligned(16))) float lds[G::NPIX * PS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int li = lane & 31;
+
+    // ---- workgroup -> (image, tile, channel slice); XCD-aware bijective remap so that
+    //      consecutive logical ids (neighbouring tiles, same slice set) share one XCD's L2 ----
+    int logical;
+    {
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, pos = bid >> 3;
+        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
+    }
+    const int slice = logical % p.nslices;
+    int tile = logical / p.nslices;
+
+    int img = 0, y0 = 0, x0 = 0;
+    long long px0 = 0;
+    const float* in_base;      // wave-uniform base: image (3x3) or first pixel of the tile (1x1)
+    if constexpr (TAPS == 9) {
+        const int tx = tile % p.tiles_x; tile /= p.tiles_x;
+        const int ty = tile % p.tiles_y;
+        const int bi = tile / p.tiles_y;
+        img = p.img_list ? p.img_list[bi] : bi;
+        y0 = ty * G::TH; x0 = tx * G::TW;
+        in_base = p.in + (long long)img * p.H * p.W * p.in_cstride + p.in_coff;
+    } else {
+        px0 = (long long)tile * 256;
+        in_base = p.in + px0 * p.in_cstride + p.in_coff;
+    }
+
+    // ---- per-thread staging offsets (element offsets from in_base, -1 = store zeros) ----
+    int goff[G::NITER];
+#pragma unroll
+    for (int j = 0; j < G::NITER; ++j) {
+        const int f = tid + j * 256;
+        const int lp = f >> 3, c4 = f & 7;
+        int off = -1;
+        if (f < G::NF4) {
+            if constexpr (TAPS == 9) {
+                const int ly = lp / G::LW, lx = lp - ly * G::LW;
+                int gy = y0 + ly - 1, gx = x0 + lx - 1;
+                bool zero = false;
+                if (p.pad_zero) {
+                    zero = (gy < 0) | (gy >= p.H) | (gx < 0) | (gx >= p.W);
+                    gy = min(max(gy, 0), p.H - 1); gx = min(max(gx, 0), p.W - 1);
+                } else {
+                    gy = reflect_clamp(gy, p.H); gx = reflect_clamp(gx, p.W);
+                }
+                if (!zero) off = (gy * p.W + gx) * p.in_cstride + c4 * 4;
+            } else {
+                if (px0 + lp < p.total_px) off = lp * p.in_cstride + c4 * 4;
+            }
+        }
+        goff[j] = off;
+    }
+
+    // ---- A-fragment LDS base of this lane (M-block 2*wave, tap (0,0), k-group 0) ----
+    const int a_base = (((2 * wave) * G::MBH + li / MBW) * G::LW + (li % MBW)) * PS + half * 4;
+    constexpr int A_MB = G::MBH * G::LW * PS;     // second M-block of the wave
+
+    const int nchunks = p.cin / CK;
+    // B fragments: [slice][chunk][step][nb][lane][4]
+    const f32x4* wp = reinterpret_cast<const f32x4*>(p.wpack) +
+                      ((long long)slice * nchunks) * (G::STEPS * 128) + lane;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    for (int c = 0; c < nchunks; ++c) {
+        // -------- stage the (tile+halo) x 32-channel chunk into LDS --------
+        f32x4 stg[G::NITER];
+#pragma unroll
+        for (int j = 0; j < G::NITER; ++j) {
+            stg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (goff[j] >= 0)
+                stg[j] = *reinterpret_cast<const f32x4*>(in_base + goff[j] + c * CK);
+        }
+        if (c > 0) __syncthreads();            // previous chunk fully consumed
+#pragma unroll
+        for (int j = 0; j < G::NITER; ++j) {
+            const int f = tid + j * 256;
+            if (f < G::NF4)
+                *reinterpret_cast<f32x4*>(&lds[(f >> 3) * PS + (f & 7) * 4]) = stg[j];
+        }
+        __syncthreads();
+
+        // -------- 9 taps x 4 k-groups, 16 MFMAs each, operands prefetched one step ahead ------
+        const f32x4* wc = wp + (long long)c * (G::STEPS * 128);
+        f32x4 a_cur[2], b_cur[2], a_nxt[2], b_nxt[2];
+        a_cur[0] = *reinterpret_cast<const f32x4*>(&lds[a_base]);
+        a_cur[1] = *reinterpret_cast<const f32x4*>(&lds[a_base + A_MB]);
+        b_cur[0] = wc[0];
+        b_cur[1] = wc[64];
+#pragma unroll
+        for (int s = 0; s < G::STEPS; ++s) {
+            if (s + 1 < G::STEPS) {
+                const int sn = s + 1;
+                const int tap = sn >> 2, gg = sn & 3;
+                const int kh = (TAPS == 9) ? tap / 3 : 0, kw = (TAPS == 9) ? tap % 3 : 0;
+                const int aoff = (kh * G::LW + kw) * PS + gg * 8;
+                a_nxt[0] = *reinterpret_cast<const f32x4*>(&lds[a_base + aoff]);
+                a_nxt[1] = *reinterpret_cast<const f32x4*>(&lds[a_base + A_MB + aoff]);
+                b_nxt[0] = wc[sn * 128];
+                b_nxt[1] = wc[sn * 128 + 64];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0][e], b_cur[0][e], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[0][e], b_cur[1][e], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1][e], b_cur[0][e], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[1][e], b_cur[1][e], acc[1][1], 0, 0, 0);
+            }
+            if (s + 1 < G::STEPS) {
+                a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1];
+                b_cur[0] = b_nxt[0]; b_cur[1] = b_nxt[1];
+            }
+        }
+    }
+
+    // ---------------- epilogue: bias -> (ReLU, BN) | (BN, ReLU) -> [2x2 max] -> store --------
+    float bia[2], scl[2], sft[2];
+    int ch[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        ch[nb] = slice * 64 + nb * 32 + li;
+        bia[nb] = p.bias[ch[nb]]; scl[nb] = p.scale[ch[nb]]; sft[nb] = p.shift[ch[nb]];
+    }
+    auto act = [&](float v, int nb) -> float {
+        v += bia[nb];
+        if (p.bn_first) {
+            v = v * scl[nb] + sft[nb];
+            if (p.relu) v = fmaxf(v, 0.f);
+        } else {
+            if (p.relu) v = fmaxf(v, 0.f);
+            v = v * scl[nb] + sft[nb];
+        }
+        return v;
+    };
+
+    if constexpr (TAPS == 1) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const long long gp = px0 + (2 * wave + mb) * 32 + i;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    if (gp < p.total_px && ch[nb] < p.cout)
+                        p.out[gp * p.out_cstride + p.out_coff + ch[nb]] = act(acc[mb][nb][r], nb);
+            }
+    } else if constexpr (!POOL) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int oy = y0 + (2 * wave + mb) * G::MBH + i / MBW;
+                const int ox = x0 + i % MBW;
+                if (oy < p.H && ox < p.W) {
+                    const long long o = (((long long)img * p.H + oy) * p.W + ox) * p.out_cstride + p.out_coff;
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+                        if (ch[nb] < p.cout) p.out[o + ch[nb]] = act(acc[mb][nb][r], nb);
+                }
+            }
+    } else {
+        const int Ho = p.H >> 1, Wo = p.W >> 1;
+        // partner registers of the 2x2 window: +1 column = r+1; +1 row depends on the M-block shape
+        if constexpr (MBW == 32) {
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int oy = (y0 + 2 * wave) >> 1, ox = (x0 + i) >> 1;
+                if (oy < Ho && ox < Wo) {
+                    const long long o = (((long long)img * Ho + oy) * Wo + ox) * p.out_cstride + p.out_coff;
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb) {
+                        const float v = fmaxf(fmaxf(act(acc[0][nb][r], nb), act(acc[0][nb][r + 1], nb)),
+                                              fmaxf(act(acc[1][nb][r], nb), act(acc[1][nb][r + 1], nb)));
+                        if (ch[nb] < p.cout) p.out[o + ch[nb]] = v;
+                    }
+                }
+            }
+        } else {
+            constexpr int RDOWN = (MBW == 16) ? 8 : 4;      // register holding the pixel one row down
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    if ((r & RDOWN) != 0) continue;          // only top rows of each 2-row pair
+                    const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int oy = (y0 + (2 * wave + mb) * G::MBH + i / MBW) >> 1;
+                    const int ox = (x0 + i % MBW) >> 1;
+                    if (oy < Ho && ox < Wo) {
+                        const long long o = (((long long)img * Ho + oy) * Wo + ox) * p.out_cstride + p.out_coff;
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) {
+                            const float v = fmaxf(
+                                fmaxf(act(acc[mb][nb][r], nb), act(acc[mb][nb][r + 1], nb)),
+                                fmaxf(act(acc[mb][nb][r + RDOWN], nb), act(acc[mb][nb][r + RDOWN + 1], nb)));
+                            if (ch[nb] < p.cout) p.out[o + ch[nb]] = v;
+                        }
+                    }
+                }
+        }
+    }
+}
+
+template <int TAPS, int MBW, bool POOL>
+void launch_t(const ConvParams& p, hipStream_t s)
+{
+    long long ntiles;
+    if (TAPS == 9) ntiles = (long long)p.B * p.tiles_x * p.tiles_y;
+    else ntiles = (p.total_px + 255) / 256;
+    const long long nblk = ntiles * p.nslices;
+    if (nblk <= 0) return;
+    hipLaunchKernelGGL((conv_mfma_kernel<TAPS, MBW, POOL>), dim3((unsigned)nblk), dim3(256), 0, s, p);
+}
+
+}  // namespace
+
+void launch_conv_mfma(const ConvParams& p, int taps, int mbw, bool pool, hipStream_t s)
+{
+    if (taps == 1) { launch_t<1, 32, false>(p, s); return; }
+    if (mbw == 32) { pool ? launch_t<9, 32, true>(p, s) : launch_t<9, 32, false>(p, s); }
+    else if (mbw == 16) { pool ? launch_t<9, 16, true>(p, s) : launch_t<9, 16, false>(p, s); }
+    else { pool ? launch_t<9, 8, true>(p, s) : launch_t<9, 8, false>(p, s); }
+}

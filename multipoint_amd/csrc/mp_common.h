@@ -1,0 +1,95 @@
+// Shared declarations for the gfx950 (MI355X / CDNA4) kernels of libmultipoint_hip.so.
+// Internal header: the public C ABI is include/multipoint_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define MP_WAVE 64
+
+// ---------------------------------------------------------------------------------------------
+// conv (implicit GEMM on v_mfma_f32_32x32x2_f32)
+// ---------------------------------------------------------------------------------------------
+// Activations are NHWC fp32.  One workgroup (256 threads = 4 waves) produces a tile of 256 output
+// pixels x 64 output channels; the 256 pixels are 8 "M-blocks" of 32 pixels, an M-block being
+// (32/MBW) rows x MBW columns, stacked vertically:  tile = (256/MBW) rows x MBW cols.
+// Wave w owns M-blocks 2w, 2w+1 and both 32-wide N-blocks of the 64-channel slice.
+struct ConvParams {
+    const float* in;      // [B][H][W][in_cstride], channels [in_coff, in_coff+cin) are read
+    float* out;           // [B][Ho][Wo][out_cstride], channels [out_coff, out_coff+cout) written
+    const float* wpack;   // packed weights, see pack_conv_weights() in api.hip
+    const float* bias;    // [nslices*64] conv bias (zero padded)
+    const float* scale;   // [nslices*64] BN scale  s = gamma / sqrt(var + eps)
+    const float* shift;   // [nslices*64] BN shift  t = beta - mean * s
+    const int* img_list;  // optional: image ids this launch processes (nullptr = 0..B-1)
+    int B, H, W;          // conv input == conv output spatial size (stride 1, 'same' padding)
+    int in_cstride, in_coff, cin;
+    int out_cstride, out_coff, cout;
+    int nslices;          // ceil(cout / 64)
+    int tiles_x, tiles_y; // tiles per image
+    int pad_zero;         // 0: reflection pad (ReflectionPad2d(1)), 1: zero pad (ZeroPad2d(1))
+    int bn_first;         // 0: conv -> ReLU -> BN (reference default), 1: conv -> BN -> ReLU
+    int relu;             // 0: no ReLU (final 1x1 convs)
+    long long total_px;   // TAPS==1 (flat) mode: number of pixels
+};
+
+// first layer (Cin = 1, direct VALU conv, HBM-write bound)
+struct Conv1Params {
+    const float* in;      // [B][H][W]
+    float* out;           // [B][H][W][64]
+    const float* w;       // [9][64]  (tap-major, cout contiguous)
+    const float* bias; const float* scale; const float* shift;   // [64]
+    const int* img_list;
+    int B, H, W;
+    int pad_zero, bn_first;
+};
+
+void launch_conv_mfma(const ConvParams& p, int taps, int mbw, bool pool, hipStream_t s);
+void launch_conv_first(const Conv1Params& p, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// heads post-processing
+// ---------------------------------------------------------------------------------------------
+// logits [B*Hc*Wc][lstride] (65 valid) -> prob [B][Hc*8][Wc*8]  (softmax over 65, drop dustbin,
+// depth-to-space 8) and/or logits_nchw [B][65][Hc][Wc]
+void launch_det_post(const float* logits, int lstride, int B, int Hc, int Wc, float* prob,
+                     float* logits_nchw, hipStream_t s);
+// raw [npx][D] -> out [npx][D] rows divided by max(||row||, 1e-12)   (D multiple of 4, <= 1024)
+void launch_desc_l2norm(const float* raw, float* out, long long npx, int D, int normalize,
+                        hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// keypoint extraction
+// ---------------------------------------------------------------------------------------------
+#define MP_NMS_MAX_R 8   // footprint radius supported by the NMS kernels (box size <= 9)
+struct NmsFootprint {
+    int R;                                   // radius
+    unsigned rowmask[2 * MP_NMS_MAX_R + 1];  // bit (dx+R) of rowmask[dy+R] set <=> IoU > thr
+};
+
+// work map encoding: > 0 undecided candidate (its score), 0 dead / not a candidate, < 0 kept (-score)
+void launch_nms_init(const float* prob, const uint8_t* mask, float min_prob, float* work,
+                     long long n, hipStream_t s);
+void launch_nms_round(float* work, int B, int H, int W, const NmsFootprint& fp, int* remaining,
+                      int round, hipStream_t s);
+// per image: ordered (row-major) list of kept pixels, top-k selection by (score desc, index asc),
+// outputs kp_yx [B][K][2] int32, kp_score [B][K], kp_count [B]; optional dense map prob_nms
+void launch_select_keypoints(const float* work, int B, int H, int W, int topk, int K,
+                             int* list_idx, float* list_score, int list_cap, int* kp_yx,
+                             float* kp_score, int* kp_count, float* prob_nms, hipStream_t s);
+// plain threshold extraction: (map > thr) -> row-major list (torch.nonzero semantics)
+void launch_extract_threshold(const float* map, int B, int H, int W, float thr, int K, int* kp_yx,
+                              float* kp_score, int* kp_count, hipStream_t s);
+
+// bilinear sampling (grid_sample align_corners=True, zeros) + L2 normalise.
+// desc [B][Hc][Wc][D] channels-last; kp_yx [B][K][2]; out [B][K][D]
+void launch_sample_desc(const float* desc, int B, int Hc, int Wc, int D, int H, int W,
+                        const int* kp_yx, const int* kp_count, int K, float* out, hipStream_t s);
+
+// mutual nearest neighbour matching of P pairs; rowbest/colbest: [P][K] packed scratch
+void launch_match_impl(const float* dA, const int* nA, const float* dB, const int* nB,
+                       long long pair_stride, int count_stride, int P, int K, int D, float thr,
+                       unsigned long long* rowbest, unsigned long long* colbest, int* match_idx,
+                       float* match_dist, int* match_count, hipStream_t s);

@@ -1,0 +1,153 @@
+// Box non-maximum suppression on the detector heat map.
+//
+// Replaces utils.box_nms (reference multipoint/utils/utils.py:78-122), i.e. nonzero(prob > min_prob)
+// -> square boxes of side `size` centred on each candidate pixel -> torchvision greedy NMS
+// (iou threshold) -> per-image top-k -> scatter into a dense map.
+//
+// Greedy NMS over a fixed priority order (score descending, row-major index ascending -- the
+// stable descending sort torchvision applies to candidates listed by nonzero()) has a unique
+// answer: a candidate is KEPT iff no kept candidate of higher priority overlaps it with IoU > thr.
+// Because every box has the same size, "IoU > thr" depends only on the pixel offset (dy,dx): a
+// translation-invariant footprint that the host evaluates once with torchvision's fp32 formula.
+// The kernels below run the monotone fixed-point iteration
+//     undecided -> dead   if some footprint neighbour is kept
+//     undecided -> kept   if every higher-priority footprint neighbour is dead
+// Both transitions are sound under arbitrarily stale neighbour reads (a kept neighbour always has
+// higher priority than an undecided pixel it overlaps), so the result is identical to the
+// sequential greedy algorithm regardless of scheduling; only the number of rounds varies.
+// State lives in one fp32 map: >0 undecided (score), 0 dead / never a candidate, <0 kept (-score).
+#include "mp_common.h"
+
+namespace {
+
+constexpr int NT = 32;                     // tile side handled by one workgroup
+
+__global__ __launch_bounds__(256) void nms_init_kernel(const float* __restrict__ prob,
+                                                      const uint8_t* __restrict__ mask, float min_prob,
+                                                      float* __restrict__ work, long long n4)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    f32x4 v = reinterpret_cast<const f32x4*>(prob)[i];
+    if (mask) {
+        const uchar4 m = reinterpret_cast<const uchar4*>(mask)[i];
+        // prob * valid_mask (predict_align_image_pair.py:128, evaluation.py:231-232)
+        v[0] *= m.x ? 1.f : 0.f; v[1] *= m.y ? 1.f : 0.f; v[2] *= m.z ? 1.f : 0.f; v[3] *= m.w ? 1.f : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = (v[e] > min_prob) ? v[e] : 0.f;     // utils.py:97
+    reinterpret_cast<f32x4*>(work)[i] = v;
+}
+
+// flags: [2][B*tiles] ping-pong "tile still has undecided pixels"; remaining[round] = #undecided
+__global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work, int H, int W,
+                                                       int tiles_x, int tiles_y, NmsFootprint fp,
+                                                       int* __restrict__ flags, int ntiles_total,
+                                                       int* __restrict__ remaining, int round)
+{
+    __shared__ float t[(NT + 2 * MP_NMS_MAX_R) * (NT + 2 * MP_NMS_MAX_R)];
+    const int R = fp.R;
+    const int LW = NT + 2 * R;
+    const int tid = threadIdx.x;
+    const int tile_id = blockIdx.x;
+    const int* fin = flags + (round & 1) * ntiles_total;
+    int* fout = flags + ((round + 1) & 1) * ntiles_total;
+    if (round > 0 && fin[tile_id] == 0) {
+        if (tid == 0) fout[tile_id] = 0;
+        return;
+    }
+    int tt = tile_id;
+    const int tx = tt % tiles_x; tt /= tiles_x;
+    const int ty = tt % tiles_y;
+    const int b = tt / tiles_y;
+    const int y0 = ty * NT, x0 = tx * NT;
+    float* img = work + (long long)b * H * W;
+
+    for (int f = tid; f < LW * LW; f += 256) {
+        const int ly = f / LW, lx = f - ly * LW;
+        const int gy = y0 + ly - R, gx = x0 + lx - R;
+        t[f] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(long long)gy * W + gx] : 0.f;
+    }
+    __syncthreads();
+
+    // each thread owns 4 pixels of the 32x32 tile: rows (tid>>5) + 8k, column tid&31
+    const int px = tid & 31, py0 = tid >> 5;
+    for (int iter = 0; iter < 64; ++iter) {
+        float nv[4];
+        int changed = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int py = py0 + 8 * k;
+            const int c = (py + R) * LW + px + R;
+            const float s = t[c];
+            float v = s;
+            if (s > 0.f) {
+                bool kill = false, blocked = false;
+                for (int dy = -R; dy <= R; ++dy) {
+                    const unsigned rm = fp.rowmask[dy + R];
+                    for (int dx = -R; dx <= R; ++dx) {
+                        if (!((rm >> (dx + R)) & 1u) || (dy == 0 && dx == 0)) continue;
+                        const float nb = t[c + dy * LW + dx];
+                        kill |= nb < 0.f;
+                        const bool earlier = (dy < 0) || (dy == 0 && dx < 0);   // lower flat index
+                        blocked |= (nb > s) || (nb == s && earlier);
+                    }
+                }
+                v = kill ? 0.f : (blocked ? s : -s);
+                changed |= (v != s);
+            }
+            nv[k] = v;
+        }
+        const int any = __syncthreads_or(changed);
+        if (!any) break;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[(py0 + 8 * k + R) * LW + px + R] = nv[k];
+        __syncthreads();
+    }
+
+    int und = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int py = py0 + 8 * k;
+        const int gy = y0 + py, gx = x0 + px;
+        const float v = t[(py + R) * LW + px + R];
+        if (gy < H && gx < W) {
+            img[(long long)gy * W + gx] = v;
+            und += v > 0.f;
+        }
+    }
+    const int tot = __syncthreads_count(und > 0) ? 1 : 0;
+    // count undecided pixels exactly (for the convergence check on the host)
+    __shared__ int s_und;
+    if (tid == 0) s_und = 0;
+    __syncthreads();
+    if (und) atomicAdd(&s_und, und);
+    __syncthreads();
+    if (tid == 0) {
+        fout[tile_id] = tot;
+        if (s_und) atomicAdd(&remaining[round], s_und);
+    }
+}
+
+}  // namespace
+
+void launch_nms_init(const float* prob, const uint8_t* mask, float min_prob, float* work,
+                     long long n, hipStream_t s)
+{
+    const long long n4 = n / 4;
+    if (n4 <= 0) return;
+    hipLaunchKernelGGL(nms_init_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, prob,
+                       mask, min_prob, work, n4);
+}
+
+// flags / remaining live behind `remaining`:  remaining[0..63] round counters, then 2*ntiles flags
+void launch_nms_round(float* work, int B, int H, int W, const NmsFootprint& fp, int* remaining,
+                      int round, hipStream_t s)
+{
+    const int tiles_x = (W + NT - 1) / NT, tiles_y = (H + NT - 1) / NT;
+    const int ntiles = B * tiles_x * tiles_y;
+    if (ntiles <= 0) return;
+    int* flags = remaining + 64;
+    hipLaunchKernelGGL(nms_round_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
+                       tiles_y, fp, flags, ntiles, remaining, round);
+}

@@ -1,0 +1,122 @@
+"""Batched detect + describe + match driver: the per-batch loop head of
+utils.compute_descriptor_metrics (reference multipoint/utils/evaluation.py:224-285) re-shaped for the
+GPU.  The reference runs two forwards (optical, thermal), two box_nms calls and a Python loop over
+samples with three cv2 matcher calls each; here both images of all pairs go through ONE forward as an
+interleaved batch (image 2p = optical, 2p+1 = thermal), keypoints stay on the device as fixed-capacity
+lists, and all pairs are matched by one launch.  Nothing synchronises until results are read."""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .utils import utils as U
+
+
+class PairResults:
+    def __init__(self, kp_yx, kp_score, kp_count, desc, match_idx, match_dist, match_count, H, W):
+        self.kp_yx, self.kp_score, self.kp_count = kp_yx, kp_score, kp_count
+        self.desc = desc
+        self.match_idx, self.match_dist, self.match_count = match_idx, match_dist, match_count
+        self.H, self.W = H, W
+
+    @property
+    def num_pairs(self):
+        return self.match_idx.shape[0]
+
+    def to_host(self):
+        """Per-pair python lists (synchronises)."""
+        kp = self.kp_yx.cpu().numpy(); cnt = self.kp_count.cpu().numpy()
+        K = kp.shape[1]
+        mi = self.match_idx.cpu().numpy(); md = self.match_dist.cpu().numpy()
+        desc = self.desc.cpu().numpy()
+        out = []
+        for p in range(self.num_pairs):
+            no, nt = min(int(cnt[2 * p]), K), min(int(cnt[2 * p + 1]), K)
+            q = np.nonzero(mi[p, :no] >= 0)[0]
+            out.append(dict(kp_optical=kp[2 * p, :no].astype(np.int64), kp_thermal=kp[2 * p + 1, :nt].astype(np.int64),
+                            desc_optical=desc[2 * p, :no], desc_thermal=desc[2 * p + 1, :nt],
+                            match_query=q.astype(np.int64), match_train=mi[p, q].astype(np.int64),
+                            match_dist=md[p, q]))
+        return out
+
+
+class PairPipeline:
+    """config: the `prediction:` block of the reference yaml
+    (configs/config_image_pair_dataset_prediction.yaml:40-53)."""
+
+    def __init__(self, net, config, capacity=None, nms_rounds=8):
+        self.net = net
+        self.nms = config.get('nms', 4)
+        self.thr = config.get('detection_threshold', 0.015)
+        self.topk = config.get('topk', 0)
+        self.capacity = capacity
+        self.nms_rounds = nms_rounds
+        m = config.get('matching', {'method': 'bfmatcher', 'method_kwargs': {'crossCheck': True},
+                                    'knn_matches': False})
+        if m.get('knn_matches', False):
+            raise NotImplementedError('knn_matches is outside the accelerated hot path')
+        if m['method'] == 'bfmatcher':
+            if not m.get('method_kwargs', {}).get('crossCheck', False):
+                raise NotImplementedError('bfmatcher needs crossCheck: True')
+            self.match_threshold = -1.0
+        elif m['method'] == 'nnmatcher':
+            self.match_threshold = float(m.get('method_kwargs', {}).get('threshold', 0.7))
+            if self.match_threshold < 0:
+                raise ValueError('\'threshold\' should be non-negative')
+        else:
+            raise ValueError('unknown matching method')
+
+    @staticmethod
+    def interleave(optical, thermal):
+        """(P,1,H,W) x 2 -> (2P,1,H,W) with image 2p = optical[p], 2p+1 = thermal[p]."""
+        P = optical.shape[0]
+        return torch.stack((optical, thermal), dim=1).reshape(2 * P, *optical.shape[1:])
+
+    def run_interleaved(self, images, valid_mask=None, is_optical=None):
+        dev = images.device
+        B, _, H, W = images.shape
+        if B % 2:
+            raise ValueError('interleaved batch must hold an even number of images')
+        if is_optical is None:
+            is_optical = (torch.arange(B) % 2 == 0).reshape(B, 1)
+        out = self.net({'image': images, 'is_optical': is_optical})
+        prob = out['prob']
+        if self.nms > 0:
+            K = self.capacity or (self.topk if self.topk > 0 else 4096)
+            kp, sc, cnt = U.detect_keypoints(prob, self.nms, self.thr, keep_top_k=self.topk, capacity=K,
+                                             valid_mask=valid_mask, max_rounds=self.nms_rounds)
+        else:
+            if valid_mask is not None:
+                prob = prob * valid_mask.to(prob.dtype)
+            kp, sc, cnt = U.extract_keypoints(prob, self.thr, capacity=self.capacity or 4096)
+        K = kp.shape[1]
+        desc = U.interpolate_descriptors_batched(kp, cnt, out['desc'], H, W)        # [B,K,D]
+        D = desc.shape[2]
+        P = B // 2
+        midx = torch.empty((P, K), dtype=torch.int32, device=dev)
+        mdist = torch.empty((P, K), dtype=torch.float32, device=dev)
+        mcnt = torch.empty((P,), dtype=torch.int32, device=dev)
+        h = _lib.get_handle(dev)
+        with torch.cuda.device(dev):
+            h.check(h.lib.mp_match_mutual_nn(
+                h.ptr, _lib.ptr(desc), _lib.ptr(cnt), ctypes.c_void_p(desc.data_ptr() + K * D * 4),
+                ctypes.c_void_p(cnt.data_ptr() + 4), 2 * K * D, 2, P, K, D, float(self.match_threshold),
+                _lib.ptr(midx), _lib.ptr(mdist), _lib.ptr(mcnt), _lib.stream_ptr(dev)))
+        return PairResults(kp, sc, cnt, desc, midx, mdist, mcnt, H, W)
+
+    def __call__(self, optical, thermal, mask_optical=None, mask_thermal=None):
+        images = self.interleave(optical, thermal)
+        mask = None
+        if mask_optical is not None or mask_thermal is not None:
+            ones = torch.ones_like(optical, dtype=torch.bool)
+            mask = self.interleave(mask_optical if mask_optical is not None else ones,
+                                   mask_thermal if mask_thermal is not None else ones)
+        return self.run_interleaved(images, mask)
+
+    def check_converged(self, device=None):
+        """Synchronises; raises if the fixed number of asynchronous NMS rounds was not enough."""
+        n = U.nms_unresolved(device)
+        if n:
+            raise RuntimeError('box_nms: %d candidates undecided after %d rounds; raise nms_rounds'
+                               % (n, self.nms_rounds))

@@ -1,0 +1,3 @@
+# mirrors multipoint/utils/__init__.py for the hot path (matching + utils)
+from .matching import *  # noqa: F401,F403
+from .utils import *  # noqa: F401,F403

@@ -1,0 +1,507 @@
+"""
+TEST INFRASTRUCTURE ONLY.
+
+CPU restatement ("oracle") of the MultiPoint inference hot path of ethz-asl/multipoint.  Only
+``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+package; the product path (``multipoint_amd``) never does and fails loudly without its HIP library.
+
+Every function cites the reference file:line it restates (paths relative to /root/reference).
+Floating-point stages are restated with the same ATen CPU ops the reference dispatches to
+(torch.nn.functional), integer/index stages in numpy / plain C (oracle/nms_greedy.c).
+
+Pinning status (see tests/test_oracle_vs_reference.py and tests/golden/make_golden.py):
+  * forward, depth_to_space, interpolate_descriptors, NNMatcher: PINNED against the imported
+    reference (runs only in the build container, where /root/reference exists) and against the
+    committed golden vectors generated from it.
+  * box_nms (torchvision.ops.nms / batched_nms) and cv2.BFMatcher: third-party code absent from
+    /root/reference and not installable here -> "PARITY UNPINNED" at those two boundaries; the
+    published algorithms are restated (oracle/nms_greedy.c, ``bf_match_crosscheck``).
+"""
+import collections
+import ctypes
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+# --------------------------------------------------------------------------------------------
+# model description (multipoint/models/MultiPoint.py:9-23 default_config, :38-53 channel presets)
+# --------------------------------------------------------------------------------------------
+DEFAULT_MODEL_CONFIG = {
+    'multispectral': True,
+    'descriptor_head': True,
+    'intepolation_mode': 'bilinear',
+    'descriptor_size': 256,
+    'normalize_descriptors': True,
+    'final_batchnorm': True,
+    'reflection_pad': True,
+    'bn_first': False,
+    'double_convolution': True,
+    'channel_version': 0,
+    'verbose': False,
+    'mixed_precision': False,
+    'force_return_logits': False,
+}
+
+# the shipped model_weights/multipoint/params.yaml:1-11
+SHIPPED_MODEL_CONFIG = {
+    'bn_first': False,
+    'descriptor_head': True,
+    'descriptor_size': 64,
+    'final_batchnorm': True,
+    'highres_descriptor': False,
+    'intepolation_mode': 'bilinear',
+    'multispectral': False,
+    'normalize_descriptors': True,
+    'reflection_pad': True,
+    'type': 'MultiPoint',
+}
+
+
+def full_config(cfg=None):
+    out = dict(DEFAULT_MODEL_CONFIG)
+    if cfg:
+        out.update(cfg)
+    return out
+
+
+def _channels(cfg):
+    """MultiPoint.py:38-53."""
+    v = cfg['channel_version']
+    if v == 1:
+        return [1, 32, 64, 96, 128], cfg['descriptor_size']
+    if v == 2:
+        return [1, 8, 16, 32, 64], cfg['descriptor_size']
+    return [1, 64, 64, 128, 128], 256
+
+
+def encoder_layout(cfg):
+    """Sequential indices of (conv, bn) modules in generate_encoder (MultiPoint.py:168-185) and
+    whether a MaxPool2d(2,2) follows the block.  Only double_convolution=True, bn_first=False or
+    True are laid out (indices are the same: pad, conv, X, Y)."""
+    ch, _ = _channels(cfg)
+    out = []
+    idx = 0
+    for stage in range(4):
+        cin, cout = ch[stage], ch[stage + 1]
+        convs = [(cin, cout), (cout, cout)] if cfg['double_convolution'] else [(cin, cout)]
+        for k, (ci, co) in enumerate(convs):
+            conv_idx = idx + 1
+            # getNonlinearity (MultiPoint.py:137-141): (ReLU, BN) or (BN, ReLU)
+            bn_idx = idx + 2 if cfg['bn_first'] else idx + 3
+            last = (k == len(convs) - 1)
+            out.append(dict(conv=conv_idx, bn=bn_idx, cin=ci, cout=co, pool=(last and stage < 3)))
+            idx += 4
+        if stage < 3:
+            idx += 1  # the MaxPool2d module
+    return out
+
+
+def state_dict_spec(cfg=None):
+    """Ordered (key, shape, dtype) list of the reference state_dict (train.py:161-173 format)."""
+    cfg = full_config(cfg)
+    ch, head = _channels(cfg)
+    spec = []
+
+    def conv(prefix, co, ci, k):
+        spec.append((prefix + '.weight', (co, ci, k, k), torch.float32))
+        spec.append((prefix + '.bias', (co,), torch.float32))
+
+    def bn(prefix, c):
+        spec.append((prefix + '.weight', (c,), torch.float32))
+        spec.append((prefix + '.bias', (c,), torch.float32))
+        spec.append((prefix + '.running_mean', (c,), torch.float32))
+        spec.append((prefix + '.running_var', (c,), torch.float32))
+        spec.append((prefix + '.num_batches_tracked', (), torch.int64))
+
+    enc_names = ['encoder_thermal', 'encoder_optical'] if cfg['multispectral'] else ['encoder']
+    for name in enc_names:
+        for l in encoder_layout(cfg):
+            a, b = sorted([('conv', l['conv']), ('bn', l['bn'])], key=lambda t: t[1])
+            for kind, i in (a, b):
+                if kind == 'conv':
+                    conv('%s.%d' % (name, i), l['cout'], l['cin'], 3)
+                else:
+                    bn('%s.%d' % (name, i), l['cout'])
+    heads = [('detector_head_convolutions', 65)]
+    if cfg['descriptor_head']:
+        heads.append(('descriptor_head_convolutions', cfg['descriptor_size']))
+    for name, nout in heads:
+        if cfg['bn_first']:
+            conv(name + '.1', head, ch[4], 3); bn(name + '.2', head)
+        else:
+            conv(name + '.1', head, ch[4], 3); bn(name + '.3', head)
+        conv(name + '.4', nout, head, 1)
+        if cfg['final_batchnorm']:
+            bn(name + '.5', nout)
+    return spec
+
+
+# --------------------------------------------------------------------------------------------
+# deterministic synthetic weights / inputs (numpy default_rng so they reproduce on the GPU box)
+# --------------------------------------------------------------------------------------------
+def make_weights(seed=0, cfg=None, sharpen=True):
+    """Seeded synthetic state_dict in the reference key layout (the pretrained blob
+    model_weights/multipoint/latest.model is listed in /root/reference/.MISSING_LARGE_BLOBS).
+
+    Conv weights ~ U(-b, b), b = sqrt(6 / fan_in) (keeps activations O(1) through ReLU);
+    BN: gamma in [0.5,1.5] with ~10 % negative entries (so BN must stay *before* the max-pool),
+    beta ~ N(0,0.1), running_mean ~ N(0.2,0.1), running_var in [0.5,1.5].
+    ``sharpen``: the final detector BatchNorm2d(65) gets a large gamma and the dustbin a positive
+    beta so that, like a trained net, a few thousand pixels exceed detection_threshold=0.015.
+    """
+    cfg = full_config(cfg)
+    rng = np.random.default_rng(seed)
+    sd = collections.OrderedDict()
+    spec = state_dict_spec(cfg)
+    bn_prefixes = {k.rsplit('.', 1)[0] for k, _, _ in spec if k.endswith('.running_mean')}
+    for key, shape, dtype in spec:
+        prefix, leaf = key.rsplit('.', 1)
+        if dtype == torch.int64:
+            sd[key] = torch.tensor(1000, dtype=torch.int64)
+            continue
+        if len(shape) == 4:
+            fan_in = shape[1] * shape[2] * shape[3]
+            b = np.sqrt(6.0 / fan_in)
+            arr = rng.uniform(-b, b, size=shape)
+        elif leaf == 'bias' and prefix not in bn_prefixes:
+            arr = rng.normal(0.0, 0.05, size=shape)            # conv bias
+        elif leaf == 'weight':
+            arr = rng.uniform(0.5, 1.5, size=shape)
+            flip = rng.uniform(size=shape) < 0.1
+            arr = np.where(flip, -arr, arr)                    # some negative gammas
+        elif leaf == 'bias':
+            arr = rng.normal(0.0, 0.1, size=shape)
+        elif leaf == 'running_mean':
+            arr = rng.normal(0.2, 0.1, size=shape)
+        elif leaf == 'running_var':
+            arr = rng.uniform(0.5, 1.5, size=shape)
+        else:
+            raise AssertionError(key)
+        sd[key] = torch.from_numpy(arr.astype(np.float32))
+    if sharpen and cfg['final_batchnorm']:
+        g = sd['detector_head_convolutions.5.weight']
+        sd['detector_head_convolutions.5.weight'] = (g.abs() * 2.5).contiguous()
+        b = sd['detector_head_convolutions.5.bias'].clone()
+        b[64] = 11.0                                           # dustbin dominates most cells
+        sd['detector_head_convolutions.5.bias'] = b
+    return sd
+
+
+def make_images(seed, B, H, W):
+    """Grayscale fp32 images uniform[0,1), shape (B,1,H,W)."""
+    rng = np.random.default_rng(seed)
+    return torch.from_numpy(rng.random((B, 1, H, W), dtype=np.float32))
+
+
+# --------------------------------------------------------------------------------------------
+# forward (MultiPoint.py:99-185)
+# --------------------------------------------------------------------------------------------
+def _bn_eval(x, sd, p):
+    # nn.BatchNorm2d in eval mode, eps 1e-5 (torch default; MultiPoint.py:139,141)
+    return F.batch_norm(x, sd[p + '.running_mean'], sd[p + '.running_var'],
+                        sd[p + '.weight'], sd[p + '.bias'], training=False, eps=1e-5)
+
+
+def _pad(x, cfg):
+    # MultiPoint.py:33-36: ReflectionPad2d(1) or ZeroPad2d(1)
+    return F.pad(x, (1, 1, 1, 1), mode='reflect') if cfg['reflection_pad'] else F.pad(x, (1, 1, 1, 1))
+
+
+def _block(x, sd, cfg, conv_key, bn_key):
+    # MultiPoint.py:143-148 + :137-141
+    x = F.conv2d(_pad(x, cfg), sd[conv_key + '.weight'], sd[conv_key + '.bias'])
+    if cfg['bn_first']:
+        return F.relu(_bn_eval(x, sd, bn_key))
+    return _bn_eval(F.relu(x), sd, bn_key)
+
+
+def encoder(x, sd, cfg, name='encoder'):
+    """generate_encoder, MultiPoint.py:168-185."""
+    for l in encoder_layout(cfg):
+        x = _block(x, sd, cfg, '%s.%d' % (name, l['conv']), '%s.%d' % (name, l['bn']))
+        if l['pool']:
+            x = F.max_pool2d(x, 2, 2)
+    return x
+
+
+def depth_to_space(x, block_size):
+    """multipoint/utils/utils.py:64-69 (== nn.PixelShuffle(8), MultiPoint.py:75):
+    out[n, c, h*bs+i, w*bs+j] = x[n, (i*bs+j)*C' + c, h, w] with C' = C/bs^2."""
+    N, C, H, W = x.shape
+    bs = block_size
+    x = x.reshape(N, bs, bs, C // (bs * bs), H, W).permute(0, 3, 4, 1, 5, 2)
+    return x.reshape(N, C // (bs * bs), H * bs, W * bs).contiguous()
+
+
+def _head(x, sd, cfg, name):
+    bn_i = 2 if cfg['bn_first'] else 3
+    x = _block(x, sd, cfg, name + '.1', '%s.%d' % (name, bn_i))
+    x = F.conv2d(x, sd[name + '.4.weight'], sd[name + '.4.bias'])
+    if cfg['final_batchnorm']:
+        x = _bn_eval(x, sd, name + '.5')
+    return x
+
+
+def forward(sd, image, cfg=None, is_optical=None, return_logits=False):
+    """MultiPoint.forward_impl (MultiPoint.py:106-135) in eval mode.
+    image: (B,1,H,W) fp32.  Returns dict(prob (B,1,H,W) | logits (B,65,H/8,W/8), desc (B,D,H/8,W/8))."""
+    cfg = full_config(cfg)
+    with torch.no_grad():
+        if cfg['multispectral']:
+            # MultiPoint.py:107-122: route each image through encoder_optical / encoder_thermal
+            B, _, H, W = image.shape
+            ch, _ = _channels(cfg)
+            x = torch.zeros((B, ch[4], H // 8, W // 8), dtype=torch.float32)
+            opt = is_optical[:, 0].bool()
+            if opt.sum() > 0:
+                x[opt] = encoder(image[opt], sd, cfg, 'encoder_optical')
+            if (~opt).sum() > 0:
+                x[~opt] = encoder(image[~opt], sd, cfg, 'encoder_thermal')
+        else:
+            x = encoder(image, sd, cfg, 'encoder')
+        logits = _head(x, sd, cfg, 'detector_head_convolutions')          # MultiPoint.py:150-151
+        out = {}
+        if return_logits:
+            out['prob'], out['logits'] = None, logits
+        else:
+            prob = torch.softmax(logits, dim=1)                           # nn.Softmax2d, :74,156
+            out['prob'] = depth_to_space(prob[:, :-1], 8)                 # :157
+            out['logits'] = None
+        if cfg['descriptor_head']:
+            d = _head(x, sd, cfg, 'descriptor_head_convolutions')         # :160-161
+            if cfg['normalize_descriptors']:
+                d = F.normalize(d, p=2, dim=1)                            # :163-164 (eps 1e-12)
+            out['desc'] = d
+        return out
+
+
+# --------------------------------------------------------------------------------------------
+# box NMS (multipoint/utils/utils.py:78-122 around torchvision nms)
+# --------------------------------------------------------------------------------------------
+_nms_lib = None
+
+
+def _load_nms_lib():
+    global _nms_lib
+    if _nms_lib is None:
+        path = os.path.join(_HERE, '_build', 'libnms_greedy.so')
+        if not os.path.exists(path):
+            raise RuntimeError('oracle C library missing: run __graft_entry__.build() '
+                               '(gcc -O2 -shared -fPIC -o %s oracle/nms_greedy.c)' % path)
+        lib = ctypes.CDLL(path)
+        lib.oracle_nms_greedy.restype = ctypes.c_int64
+        lib.oracle_nms_greedy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
+                                          ctypes.c_float, ctypes.c_void_p]
+        _nms_lib = lib
+    return _nms_lib
+
+
+def nms_greedy(boxes, scores, iou):
+    """torchvision.ops.nms semantics (oracle/nms_greedy.c). boxes (n,4) f32, scores (n,) f32.
+    Returns kept candidate indices in descending-score (stable) order, int64."""
+    boxes = np.ascontiguousarray(boxes, dtype=np.float32)
+    scores = np.ascontiguousarray(scores, dtype=np.float32)
+    n = scores.shape[0]
+    keep = np.empty(max(n, 1), dtype=np.int64)
+    nk = _load_nms_lib().oracle_nms_greedy(boxes.ctypes.data, scores.ctypes.data, n,
+                                           ctypes.c_float(iou), keep.ctypes.data)
+    return keep[:nk].copy()
+
+
+def nms_greedy_py(boxes, scores, iou):
+    """Same algorithm in pure numpy/Python (small cases; cross-checks the C build)."""
+    boxes = np.asarray(boxes, dtype=np.float32)
+    scores = np.asarray(scores, dtype=np.float32)
+    order = np.argsort(-scores, kind='stable')
+    area = (boxes[:, 2] - boxes[:, 0]) * (boxes[:, 3] - boxes[:, 1])
+    sup = np.zeros(len(scores), dtype=bool)
+    keep = []
+    for a, i in enumerate(order):
+        if sup[i]:
+            continue
+        keep.append(i)
+        rest = order[a + 1:]
+        xx1 = np.maximum(boxes[i, 0], boxes[rest, 0]); yy1 = np.maximum(boxes[i, 1], boxes[rest, 1])
+        xx2 = np.minimum(boxes[i, 2], boxes[rest, 2]); yy2 = np.minimum(boxes[i, 3], boxes[rest, 3])
+        w = np.maximum(np.float32(0), xx2 - xx1); h = np.maximum(np.float32(0), yy2 - yy1)
+        inter = (w * h).astype(np.float32)
+        ovr = inter / (area[i] + area[rest] - inter)
+        sup[rest[ovr > np.float32(iou)]] = True
+    return np.asarray(keep, dtype=np.int64)
+
+
+def box_nms(prob, size, min_prob, iou=0.1, keep_top_k=0, use_c=True):
+    """utils.py:78-122.  prob: numpy (H,W) or (B,1,H,W) fp32.  Returns the dense NMS'ed map.
+
+    :97  points = (prob > min_prob).nonzero()                 (row-major)
+    :101 boxes = cat(points[:,2:] - size*0.5, points[:,2:] + size*0.5)   (fp32)
+    :103 batched_nms -> coordinate-offset trick: boxes + idx * (boxes.max() + 1), one nms call
+    :109-116 per-image top-k = first k indices of that image in descending-score order
+    :119-120 scatter kept scores into zeros_like(prob)
+    """
+    prob = np.asarray(prob, dtype=np.float32)
+    if prob.ndim not in (2, 4):
+        raise ValueError('The probability must be either 2D (H,W), or 4D (B, 1, H, W)')
+    fn = nms_greedy if use_c else nms_greedy_py
+    pts = np.argwhere(prob > np.float32(min_prob))
+    scores = prob[tuple(pts.T)]
+    out = np.zeros_like(prob)
+    if pts.shape[0] == 0:
+        return out
+    half = np.float32(size * 0.5)
+    if prob.ndim == 4:
+        yx = pts[:, 2:].astype(np.float32)
+        boxes = np.concatenate([yx - half, yx + half], axis=1)
+        idxs = pts[:, 0]
+        max_coordinate = boxes.max()
+        offsets = idxs.astype(np.float32) * (max_coordinate + np.float32(1))
+        keep = fn(boxes + offsets[:, None], scores, iou)
+        if keep_top_k > 0:
+            sel = [keep[idxs[keep] == b][:keep_top_k] for b in range(prob.shape[0])]
+            keep = np.concatenate(sel) if sel else keep
+    else:
+        yx = pts.astype(np.float32)
+        boxes = np.concatenate([yx - half, yx + half], axis=1)
+        keep = fn(boxes, scores, iou)
+        if keep_top_k > 0:
+            keep = keep[:keep_top_k]
+    out[tuple(pts[keep].T)] = scores[keep]
+    return out
+
+
+def keypoints_from_map(prob_hw, thr):
+    """predict_align_image_pair.py:170-171 / evaluation.py:262-263:
+    torch.nonzero((prob.squeeze() > thr).float()) -> (N,2) int64 (y,x), row-major."""
+    return np.argwhere(np.asarray(prob_hw) > np.float32(thr)).astype(np.int64)
+
+
+# --------------------------------------------------------------------------------------------
+# descriptor sampling (multipoint/utils/utils.py:159-167)
+# --------------------------------------------------------------------------------------------
+def interpolate_descriptors(keypoints, desc_lowres, H, W):
+    """Manual restatement of F.grid_sample(bilinear, zeros padding, align_corners=True) + normalize.
+    keypoints (N,2) int (y,x); desc_lowres numpy (D,Hc,Wc) fp32; all arithmetic in fp32 in the
+    order of utils.py:162-163 and ATen's grid_sampler_2d CPU kernel:
+        g = kp / (S*0.5) - 1 ; i = ((g + 1) / 2) * (Sc - 1)
+        out = nw*w_nw + ne*w_ne + sw*w_sw + se*w_se   (corner weights = products of distances)
+    then x / max(||x||_2, 1e-12)."""
+    kp = np.asarray(keypoints)
+    d = np.asarray(desc_lowres, dtype=np.float32)
+    D, Hc, Wc = d.shape
+    f = np.float32
+    gy = kp[:, 0].astype(f) / f(float(H) * 0.5) - f(1.0)
+    gx = kp[:, 1].astype(f) / f(float(W) * 0.5) - f(1.0)
+    iy = ((gy + f(1)) / f(2)) * f(Hc - 1)
+    ix = ((gx + f(1)) / f(2)) * f(Wc - 1)
+    y0 = np.floor(iy); x0 = np.floor(ix)
+    y1 = y0 + f(1); x1 = x0 + f(1)
+    w_nw = (x1 - ix) * (y1 - iy); w_ne = (ix - x0) * (y1 - iy)
+    w_sw = (x1 - ix) * (iy - y0); w_se = (ix - x0) * (iy - y0)
+
+    def tap(yy, xx):
+        ok = (yy >= 0) & (yy <= Hc - 1) & (xx >= 0) & (xx <= Wc - 1)
+        yi = np.clip(yy, 0, Hc - 1).astype(np.int64); xi = np.clip(xx, 0, Wc - 1).astype(np.int64)
+        v = d[:, yi, xi].T                                   # (N,D)
+        return np.where(ok[:, None], v, f(0))
+
+    out = (tap(y0, x0) * w_nw[:, None]).astype(f)
+    out = out + tap(y0, x1) * w_ne[:, None]
+    out = out + tap(y1, x0) * w_sw[:, None]
+    out = out + tap(y1, x1) * w_se[:, None]
+    out = out.astype(f)
+    nrm = np.sqrt((out.astype(f) ** 2).sum(axis=1, dtype=f))
+    return (out / np.maximum(nrm, f(1e-12))[:, None]).astype(f)
+
+
+def interpolate_descriptors_torch(keypoints, desc_lowres, H, W):
+    """The same stage through the ATen ops the reference calls (utils.py:159-167), used by the
+    CPU-baseline timing leg and to pin ``interpolate_descriptors`` above."""
+    kp = torch.as_tensor(np.asarray(keypoints)).float().clone()
+    kp[:, 0] = (kp[:, 0] / (float(H) * 0.5)) - 1.0
+    kp[:, 1] = (kp[:, 1] / (float(W) * 0.5)) - 1.0
+    grid = torch.flip(kp.view(1, 1, -1, 2), [3])
+    d = torch.as_tensor(np.asarray(desc_lowres)).unsqueeze(0)
+    s = F.grid_sample(d, grid, align_corners=True)[0, :, 0, :].transpose(0, 1)
+    return F.normalize(s, p=2, dim=1).numpy()
+
+
+# --------------------------------------------------------------------------------------------
+# matching (multipoint/utils/matching.py)
+# --------------------------------------------------------------------------------------------
+def nn_match(desc1, desc2, threshold=None):
+    """NNMatcher.match, matching.py:41-72.  desc1 (N,D), desc2 (M,D) fp32 unit rows.
+    Returns (query_idx int64[K], train_idx int64[K], distance f32[K]) ordered by query index.
+    threshold=None disables the ``scores < nn_thresh`` test (:56) -- used to restate
+    cv2.BFMatcher(NORM_L2, crossCheck=True) (matching.py:7,31) as plain mutual NN."""
+    d1 = np.asarray(desc1, dtype=np.float32); d2 = np.asarray(desc2, dtype=np.float32)
+    if d1.shape[0] == 0 or d2.shape[0] == 0:                              # :46-47
+        z = np.zeros(0, dtype=np.int64)
+        return z, z.copy(), np.zeros(0, dtype=np.float32)
+    dmat = np.dot(d1, d2.T)                                               # :50
+    dmat = np.sqrt(2 - 2 * np.clip(dmat, -1, 1))                          # :51
+    idx = np.argmin(dmat, axis=1)                                         # :53 lowest index wins
+    scores = dmat[np.arange(dmat.shape[0]), idx]                          # :54
+    keep = np.ones_like(scores, dtype=bool) if threshold is None else scores < threshold   # :56
+    idx2 = np.argmin(dmat, axis=0)                                        # :58
+    keep_bi = np.arange(len(idx)) == idx2[idx]                            # :59
+    keep = np.logical_and(keep, keep_bi)                                  # :60
+    q = np.arange(d1.shape[0])[keep]
+    return q.astype(np.int64), idx[keep].astype(np.int64), scores[keep].astype(np.float32)
+
+
+def distance_matrix(desc1, desc2):
+    """matching.py:50-51 (the N x M matrix itself; used for near-tie analysis in tests)."""
+    d1 = np.asarray(desc1, dtype=np.float32); d2 = np.asarray(desc2, dtype=np.float32)
+    return np.sqrt(2 - 2 * np.clip(np.dot(d1, d2.T), -1, 1))
+
+
+def bf_match_crosscheck(desc1, desc2):
+    """cv2.BFMatcher(cv2.NORM_L2, crossCheck=True).match(d1, d2) (matching.py:7,31), restated from
+    OpenCV's published BFMatcher::knnMatchImpl semantics (opencv-python==4.2.0.34 pinned in
+    requirements.txt:1, not installable here -> PARITY UNPINNED): plain Euclidean distance matrix,
+    (i,j) kept iff j is i's nearest train descriptor and i is j's nearest query descriptor,
+    lowest index on exact ties, DMatch.distance = ||d1_i - d2_j||_2."""
+    d1 = np.asarray(desc1, dtype=np.float32); d2 = np.asarray(desc2, dtype=np.float32)
+    if d1.shape[0] == 0 or d2.shape[0] == 0:
+        z = np.zeros(0, dtype=np.int64)
+        return z, z.copy(), np.zeros(0, dtype=np.float32)
+    diff = d1[:, None, :] - d2[None, :, :]
+    dmat = np.sqrt((diff * diff).sum(-1, dtype=np.float32))
+    idx = np.argmin(dmat, axis=1); idx2 = np.argmin(dmat, axis=0)
+    keep = np.arange(len(idx)) == idx2[idx]
+    q = np.arange(d1.shape[0])[keep]
+    return q.astype(np.int64), idx[keep].astype(np.int64), dmat[q, idx[keep]].astype(np.float32)
+
+
+# --------------------------------------------------------------------------------------------
+# whole path on one batch of pairs (evaluation.py:224-285 loop head), used by the CPU baseline
+# --------------------------------------------------------------------------------------------
+def process_pairs(sd, cfg, optical, thermal, nms=4, detection_threshold=0.015, topk=1000,
+                  mask_optical=None, mask_thermal=None):
+    """optical/thermal: (P,1,H,W) torch fp32.  Returns per-pair dicts with keypoints, descriptors
+    and mutual-NN matches, following evaluation.py:226-282."""
+    H, W = optical.shape[2:]
+    out_o = forward(sd, optical, cfg, is_optical=torch.ones(optical.shape[0], 1, dtype=torch.bool))
+    out_t = forward(sd, thermal, cfg, is_optical=torch.zeros(thermal.shape[0], 1, dtype=torch.bool))
+    po = out_o['prob'].numpy(); pt = out_t['prob'].numpy()
+    if mask_optical is not None:
+        po = po * np.asarray(mask_optical, dtype=np.float32)
+    if mask_thermal is not None:
+        pt = pt * np.asarray(mask_thermal, dtype=np.float32)
+    if nms > 0:
+        pt = box_nms(pt, nms, detection_threshold, keep_top_k=topk)
+        po = box_nms(po, nms, detection_threshold, keep_top_k=topk)
+    res = []
+    for i in range(optical.shape[0]):
+        kpo = keypoints_from_map(po[i, 0], detection_threshold)
+        kpt = keypoints_from_map(pt[i, 0], detection_threshold)
+        do = interpolate_descriptors(kpo, out_o['desc'][i].numpy(), H, W)
+        dt = interpolate_descriptors(kpt, out_t['desc'][i].numpy(), H, W)
+        q, t, dist = nn_match(do, dt, None)
+        res.append(dict(kp_optical=kpo, kp_thermal=kpt, desc_optical=do, desc_thermal=dt,
+                        match_query=q, match_train=t, match_dist=dist))
+    return res
