@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Benchmark of the MultiPoint inference hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one pass of the full hot path (detect + describe + match) over one batch of synthetic
+pairs already resident in HBM:  BASELINE.json configs[2] -- 32 pairs (64 grayscale 480x640 images) per
+GPU: encoder + detector/descriptor heads (fp32) -> box-NMS (size 4, iou 0.1, thr 0.015) -> top-k 1000
+-> bilinear descriptor sampling + L2 norm -> mutual-NN match.  Pairs shard independently over ranks
+(weak scaling, no data-path collective); RCCL only gathers the per-pair metric records.
+
+Prints ONE JSON line on rank 0 (see README / DESIGN.md section "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+GFLOP_PER_IMAGE_480x640 = 51.6317        # SURVEY.md Appendix B (12 convolutions)
+PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+PAIRS_PER_GPU = 32
+H, W = 480, 640
+PRED_CFG = {'nms': 4, 'detection_threshold': 0.015, 'topk': 1000, 'cpu_nms': False,
+            'matching': {'method': 'bfmatcher', 'method_kwargs': {'crossCheck': True}, 'knn_matches': False}}
+
+
+def conv_flops_per_image(h, w):
+    """2*k^2*Cin*Cout*Hout*Wout over the 12 convolutions of the shipped config."""
+    layers = [(1, 64, 3, 1), (64, 64, 3, 1), (64, 64, 3, 2), (64, 64, 3, 2), (64, 128, 3, 4), (128, 128, 3, 4),
+              (128, 128, 3, 8), (128, 128, 3, 8), (128, 256, 3, 8), (256, 65, 1, 8), (128, 256, 3, 8),
+              (256, 64, 1, 8)]
+    return sum(2.0 * k * k * ci * co * (h // s) * (w // s) for ci, co, k, s in layers)
+
+
+def make_batch(rank, n_pairs, device):
+    """Interleaved batch: image 2p = optical, 2p+1 = thermal of global pair id rank*n_pairs + p."""
+    from multipoint_amd.datasets import SyntheticPairs
+    imgs = np.empty((2 * n_pairs, 1, H, W), dtype=np.float32)
+    for p in range(n_pairs):
+        o, t = SyntheticPairs.make_pair(0, rank * n_pairs + p, H, W)
+        imgs[2 * p], imgs[2 * p + 1] = o, t
+    return torch.from_numpy(imgs).to(device)
+
+
+def cpu_baseline(sd, cfg, n_pairs=8):
+    """The oracle (CPU restatement of the reference path, ATen CPU ops) timed on this box's host cores
+    on a bounded sample of the same workload.  A reported baseline, not the optimisation target."""
+    from oracle import mp_oracle as O
+    from multipoint_amd.datasets import SyntheticPairs
+    torch.set_num_threads(os.cpu_count() or 1)
+    pairs = [SyntheticPairs.make_pair(0, p, H, W) for p in range(n_pairs)]
+    opt = torch.from_numpy(np.stack([p[0] for p in pairs])); th = torch.from_numpy(np.stack([p[1] for p in pairs]))
+    O.process_pairs(sd, cfg, opt[:1], th[:1], nms=PRED_CFG['nms'], detection_threshold=PRED_CFG['detection_threshold'],
+                    topk=PRED_CFG['topk'])                                   # warm-up
+    t0 = time.perf_counter()
+    res = O.process_pairs(sd, cfg, opt, th, nms=PRED_CFG['nms'], detection_threshold=PRED_CFG['detection_threshold'],
+                          topk=PRED_CFG['topk'])
+    dt = time.perf_counter() - t0
+    return {'value': n_pairs / dt, 'unit': 'image-pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
+            'sample': '%d pairs 480x640, full path (oracle.process_pairs: ATen-CPU forward, C greedy NMS, '
+                      'numpy sampling + NNMatcher), %.1f s' % (n_pairs, dt)}, res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--pairs-per-gpu', type=int, default=PAIRS_PER_GPU)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--forward-only', action='store_true', help='configs[1]: encoder+heads only')
+    args = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
+    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
+                     % (args.gpus, args.gpus))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        sys.exit('bench.py needs an MI355X; torch.cuda.is_available() is False')
+    torch.cuda.set_device(local_rank)
+    device = torch.device('cuda', local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
+
+    import multipoint_amd.models as models
+    from multipoint_amd.pipeline import PairPipeline
+    from multipoint_amd.dist import gather_pair_metrics
+    from oracle import mp_oracle as O          # weights generator + cpu_baseline leg only
+
+    cfg = dict(O.SHIPPED_MODEL_CONFIG)
+    sd = O.make_weights(0, cfg)
+    net = models.MultiPoint(cfg); net.load_state_dict(sd); net.to(device); net.eval()
+    pipe = PairPipeline(net, PRED_CFG, capacity=PRED_CFG['topk'], nms_rounds=8)
+    P = args.pairs_per_gpu
+    images = make_batch(rank, P, device)
+    flags = (torch.arange(2 * P) % 2 == 0).reshape(-1, 1)
+
+    def step():
+        if args.forward_only:
+            return net({'image': images, 'is_optical': flags})
+        return pipe.run_interleaved(images, None, flags)
+
+    def fence():
+        torch.cuda.synchronize(device)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(args.warmup):
+        res = step()
+    fence()
+    if not args.forward_only:
+        pipe.check_converged(device)
+    net.profile(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    dt = time.perf_counter() - t0
+    prof = net.profile_read()
+    net.profile(False)
+    t = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    # per-pair metric records, gathered over RCCL (the only collective of the path)
+    metrics = None
+    if not args.forward_only:
+        pipe.check_converged(device)
+        rec = torch.stack([torch.arange(P, device=device, dtype=torch.int32) + rank * P,
+                           res.kp_count[0::2].clamp(max=res.kp_yx.shape[1]),
+                           res.kp_count[1::2].clamp(max=res.kp_yx.shape[1]), res.match_count], dim=1)
+        metrics = gather_pair_metrics(rec).cpu().numpy()
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # roofline of the dominant kernel: conv_mfma_kernel<9,32,pool> on encoder conv2 (64->64 @480x640,
+    # 44 % of all FLOPs), timed with hipEvents on the launch stream inside the timed region
+    by_name = {}
+    for name, ms, flop in prof:
+        by_name.setdefault(name, []).append((ms, flop))
+    dom = by_name.get('enc.conv2', [])
+    roof = None
+    if dom:
+        ms = float(np.mean([m for m, _ in dom])); flop = dom[0][1]
+        ach = flop / (ms * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
+                'kernel': 'conv_mfma_kernel<9,32,pool> (encoder conv2 64->64 @480x640 + ReLU/BN/maxpool)',
+                'ms_per_launch': round(ms, 4), 'flop_per_launch': flop}
+    conv_ms = sum(float(np.mean([m for m, _ in v])) for k, v in by_name.items())
+    conv_flop = sum(v[0][1] for v in by_name.values())
+    layers = {k: round(float(np.mean([m for m, _ in v])), 4) for k, v in by_name.items()}
+
+    total_pairs = P * world * args.steps
+    value = total_pairs / dt
+    gflop_pair = 2 * conv_flops_per_image(H, W) / 1e9
+    out = {
+        'metric': 'image-pairs/sec (detect+desc+match) @ 480x640' if not args.forward_only
+                  else 'image-pairs/sec (encoder+heads forward only) @ 480x640',
+        'value': round(value, 2), 'unit': 'image-pairs/s', 'n_gpus': world, 'steps': args.steps,
+        'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'BASELINE configs[2]: %d pairs (=%d images) 480x640 per GPU, full path: fp32 '
+                               'encoder+heads, box-NMS size 4 + top-k 1000, bilinear desc sampling, mutual-NN match'
+                               % (P, 2 * P) if not args.forward_only else
+                               'BASELINE configs[1]: %d pairs 480x640 per GPU, forward only' % P,
+                   'pairs_per_gpu': P, 'height': H, 'width': W, 'topk': PRED_CFG['topk'], 'nms': PRED_CFG['nms'],
+                   'weights': 'seeded synthetic state_dict (reference key layout)', 'parallelism': 'dp%d' % world},
+        'roofline': roof,
+        'conv_mfma_frac_whole_path': round(value / world * gflop_pair / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+        'forward_tflops': round(conv_flop / (conv_ms * 1e-3) / 1e12, 2) if conv_ms > 0 else None,
+        'layer_ms': layers,
+    }
+    if metrics is not None:
+        out['pair_metrics'] = {'pairs': int(metrics.shape[0]), 'mean_kp_optical': float(metrics[:, 1].mean()),
+                               'mean_kp_thermal': float(metrics[:, 2].mean()),
+                               'mean_matches': float(metrics[:, 3].mean())}
+    if world == 1 and not args.no_cpu_baseline:
+        cb, cres = cpu_baseline(sd, cfg)
+        out['cpu_baseline'] = cb
+        if not args.forward_only:
+            # parity in the same run: GPU vs CPU descriptors on the keypoints both found
+            host = res.to_host()
+            errs, same_kp = [], 0
+            for p in range(min(len(cres), P)):
+                a, b = cres[p], host[p]
+                if a['kp_optical'].shape == b['kp_optical'].shape and np.array_equal(a['kp_optical'], b['kp_optical']):
+                    same_kp += 1
+                    if len(a['desc_optical']):
+                        errs.append(float(np.abs(a['desc_optical'] - b['desc_optical']).max()))
+            out['parity'] = {'pairs_checked': min(len(cres), P), 'pairs_with_identical_optical_keypoints': same_kp,
+                             'desc_max_abs_err': max(errs) if errs else None}
+    else:
+        out['cpu_baseline'] = None
+    print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

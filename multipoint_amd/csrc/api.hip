@@ -292,6 +292,7 @@ void run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride,
     p.pad_zero = h->cfg.reflection_pad ? 0 : 1;
     p.bn_first = h->cfg.bn_first;
     p.relu = L.relu ? 1 : 0;
+    { const char* e = getenv("MP_DBG"); p.dbg = e ? atoi(e) : 0; }
     int mbw = 32;
     if (L.taps == 9) {
         mbw = pick_mbw(H, W);
@@ -509,7 +510,7 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
     float* Lg = Q + nQ;
     float* Dr = Lg + nL;
     int* lists = reinterpret_cast<int*>(Dr + nD);
-    h->prof_used = 0;
+    if (h->prof_used > 4000) h->prof_used = 0;      // profile ring: entries accumulate until read
 
     // encoder(s): multispectral routes each image by is_optical (MultiPoint.py:107-122)
     int nsets = 1, counts[2] = {B, 0};
@@ -672,6 +673,7 @@ int mp_profile_read(mp_handle* h, const char** names, float* ms, double* flop, i
         if (flop) flop[i] = e.flop;
         ++*n;
     }
+    h->prof_used = 0;
     return MP_OK;
 }
 

@@ -243,7 +243,7 @@ class MultiPoint:
 
     def profile_read(self):
         h = self._handle
-        cap = 64
+        cap = 4096
         names = (ctypes.c_char_p * cap)()
         ms = (ctypes.c_float * cap)()
         flop = (ctypes.c_double * cap)()

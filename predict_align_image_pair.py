@@ -1,0 +1,171 @@
+#!/usr/bin/env python3
+"""Drop-in for the hot path of the reference's predict_align_image_pair.py: same flags
+(-y -m -v -i -r -p -e -tk -th -s), same yaml keys, same model_weights/<name>/{params.yaml,<version>.model}
+format, same three timing prints (reference predict_align_image_pair.py:141-143) -- computed on an
+MI355X through libmultipoint_hip.so.  The matplotlib/cv2 visualisation of -p and the metric
+arithmetic of -e (NN-mAP, M-score, RANSAC homography) are outside the accelerated path: -p prints a
+text summary of keypoints/matches (and can save them with --save-npz), -e runs the batched
+detect+describe+match driver over the dataset and reports counts and throughput."""
+import argparse
+import os
+import random
+import time
+
+import numpy as np
+import torch
+import yaml
+
+import multipoint_amd.datasets as datasets
+import multipoint_amd.models as models
+import multipoint_amd.utils as utils
+from multipoint_amd.pipeline import PairPipeline
+
+
+def synchronize():
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description='Predict the keypoints of an image')
+    parser.add_argument('-y', '--yaml-config', default='configs/config_image_pair_dataset_prediction.yaml', help='YAML config file')
+    parser.add_argument('-m', '--model-dir', default='model_weights/multipoint', help='Directory of the model')
+    parser.add_argument('-v', '--version', default='latest', help='Model version (name of the param file), none for no weights')
+    parser.add_argument('-i', '--index', default=0, type=int, help='Index of the sample to predict and show')
+    parser.add_argument('-r', '--radius', default=4, type=int, help='Radius of the keypoint circle')
+    parser.add_argument('-p', dest='plot', action='store_true', help='If set the prediction the results are displayed')
+    parser.add_argument('-e', dest='evaluation', action='store_true', help='If set the evaluation metrics are computed')
+    parser.add_argument('-tk', dest='threshold_keypoints', default=4, type=int, help='Distance below which two keypoints are considered a match')
+    parser.add_argument('-th', dest='threshold_homography', default=1, type=int, help='Homography correctness threshold')
+    parser.add_argument('-s', '--seed', default=0, type=int, help='Seed of the random generators')
+    parser.add_argument('--save-npz', default=None, help='(extension) write keypoints/descriptors/matches of the sample here')
+    return parser
+
+
+def load_network(config, model_dir, version, device, seed=0):
+    net = getattr(models, config['model']['type'])(config['model'])
+    if version != 'none':
+        weights = torch.load(os.path.join(model_dir, version + '.model'), map_location=torch.device('cpu'))
+        weights = utils.fix_model_weigth_keys(weights)
+        net.load_state_dict(weights)
+        del weights
+    else:
+        net.init_random_weights(seed)
+    net.to(device)
+    net.eval()
+    return net
+
+
+def select_device(config):
+    if not config['prediction']['allow_gpu'] or not torch.cuda.is_available():
+        raise RuntimeError('this implementation runs on an MI355X only: prediction.allow_gpu must be true and '
+                           'a GPU must be visible (there is no CPU fallback; the reference runs on CPU)')
+    return torch.device('cuda:0')
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    random.seed(args.seed)
+    np.random.seed(args.seed)
+    torch.manual_seed(args.seed)
+
+    with open(args.yaml_config, 'r') as f:
+        config = yaml.load(f, Loader=yaml.FullLoader)
+    with open(os.path.join(args.model_dir, 'params.yaml'), 'r') as f:
+        config['model'] = yaml.load(f, Loader=yaml.FullLoader)['model']      # overwrite the model params
+
+    device = select_device(config)
+    print('Predicting on device: {}'.format(device))
+
+    dataset = getattr(datasets, config['dataset']['type'])(config['dataset'])
+    loader_dataset = torch.utils.data.DataLoader(dataset, batch_size=config['prediction']['batchsize'],
+                                                 shuffle=False, num_workers=config['prediction']['num_worker'])
+    net = load_network(config, args.model_dir, args.version, device, args.seed)
+    pred = config['prediction']
+
+    with torch.no_grad():
+        if args.evaluation:
+            pipe = PairPipeline(net, pred, capacity=pred['topk'] if pred['topk'] > 0 else 4096)
+            n_pairs, n_opt, n_th, n_match = 0, [], [], []
+            synchronize(); t0 = time.time()
+            for data in loader_dataset:
+                data = utils.data_to_device(data, device)
+                res = pipe(data['optical']['image'], data['thermal']['image'],
+                           data['optical']['valid_mask'], data['thermal']['valid_mask'])
+                K = res.kp_yx.shape[1]
+                cnt = res.kp_count.clamp(max=K).cpu().numpy()
+                n_opt += cnt[0::2].tolist(); n_th += cnt[1::2].tolist()
+                n_match += res.match_count.cpu().numpy().tolist()
+                n_pairs += res.num_pairs
+            pipe.check_converged(device)
+            synchronize(); dt = time.time() - t0
+            results = {'n_kp_optical': np.array(n_opt), 'n_kp_thermal': np.array(n_th), 'n_matches': np.array(n_match),
+                       'pairs_per_second': n_pairs / dt, 'config': config,
+                       'threshold_keypoints': args.threshold_keypoints, 'threshold_homography': args.threshold_homography}
+            print('Pairs: {}  ({:.1f} pairs/s)'.format(n_pairs, n_pairs / dt))
+            print('Mean optical keypoints: {}'.format(np.mean(n_opt)))
+            print('Mean thermal keypoints: {}'.format(np.mean(n_th)))
+            print('Mean mutual-NN matches: {}'.format(np.mean(n_match)))
+            target_dir = os.path.join(args.model_dir, 'descriptor_evaluation')
+            os.makedirs(target_dir, exist_ok=True)
+            np.save(os.path.join(target_dir, os.path.split(args.model_dir.strip('/'))[-1] + '_' +
+                                 time.strftime('%Y-%m-%d_%H-%M-%S', time.gmtime())), results)
+
+        # get the sample and move it to the right device
+        synchronize()
+        t_start = time.time()
+        data = dataset[args.index]
+        data = utils.data_to_device(data, device)
+        data = utils.data_unsqueeze(data, 0)
+
+        synchronize()
+        t_1 = time.time()
+        out_optical = net(data['optical'])
+        out_thermal = net(data['thermal'])
+        synchronize()
+        t_2 = time.time()
+
+        if pred['nms'] > 0:
+            out_optical['prob'] = utils.box_nms(out_optical['prob'], pred['nms'], pred['detection_threshold'],
+                                                keep_top_k=pred['topk'], on_cpu=pred['cpu_nms'],
+                                                valid_mask=data['optical']['valid_mask'])
+            out_thermal['prob'] = utils.box_nms(out_thermal['prob'], pred['nms'], pred['detection_threshold'],
+                                                keep_top_k=pred['topk'], on_cpu=pred['cpu_nms'],
+                                                valid_mask=data['thermal']['valid_mask'])
+        else:
+            out_optical['prob'] = out_optical['prob'] * data['optical']['valid_mask']
+            out_thermal['prob'] = out_thermal['prob'] * data['thermal']['valid_mask']
+        synchronize()
+        t_3 = time.time()
+        print('Loading the data took: {} s'.format(t_1 - t_start))
+        print('Two forward passes took: {} s'.format(t_2 - t_1))
+        print('Box nms: {} s'.format(t_3 - t_2))
+
+        if args.plot or args.save_npz:
+            H, W = data['optical']['image'].shape[2:]
+            thr = pred['detection_threshold']
+            pred_optical = torch.nonzero((out_optical['prob'][0].squeeze() > thr).float())
+            pred_thermal = torch.nonzero((out_thermal['prob'][0].squeeze() > thr).float())
+            desc_optical = utils.interpolate_descriptors(pred_optical, out_optical['desc'][0], H, W)
+            desc_thermal = utils.interpolate_descriptors(pred_thermal, out_thermal['desc'][0], H, W)
+            matches = utils.get_matches(desc_optical.cpu().numpy(), desc_thermal.cpu().numpy(),
+                                        pred['matching']['method'], pred['matching']['knn_matches'],
+                                        **pred['matching']['method_kwargs'])
+            print('--------------------------------------------------------')
+            print('Optical keypoints: {}'.format(pred_optical.shape[0]))
+            print('Thermal keypoints: {}'.format(pred_thermal.shape[0]))
+            print('Matches ({}): {}'.format(pred['matching']['method'], len(matches)))
+            if matches:
+                d = np.array([m.distance for m in matches])
+                print('Match distance: min {:.4f} mean {:.4f} max {:.4f}'.format(d.min(), d.mean(), d.max()))
+            print('--------------------------------------------------------')
+            if args.save_npz:
+                np.savez_compressed(args.save_npz, kp_optical=pred_optical.cpu().numpy(), kp_thermal=pred_thermal.cpu().numpy(),
+                                    desc_optical=desc_optical.cpu().numpy(), desc_thermal=desc_thermal.cpu().numpy(),
+                                    match_query=np.array([m.queryIdx for m in matches]),
+                                    match_train=np.array([m.trainIdx for m in matches]),
+                                    match_distance=np.array([m.distance for m in matches], dtype=np.float32))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Drop-in for the hot path of the reference's predict_keypoints.py (flags -y -m -v -i -r -p -e -b -t
+-mask -s): forward + box_nms (without the valid-mask multiply, reference predict_keypoints.py:136-156)
+for a single sample or a batch (-b).  Drawing (-p) is replaced by a text summary; the repeatability /
+detector-mAP evaluation (-e) is CPU post-processing outside the accelerated path."""
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+import yaml
+
+import multipoint_amd.datasets as datasets
+import multipoint_amd.utils as utils
+from predict_align_image_pair import load_network, select_device
+
+
+def build_parser():
+    parser = argparse.ArgumentParser(description='Predict the keypoints of an image')
+    parser.add_argument('-y', '--yaml-config', default='configs/config_image_pair_dataset_prediction.yaml', help='YAML config file')
+    parser.add_argument('-m', '--model-dir', default='model_weights/multipoint', help='Directory of the model')
+    parser.add_argument('-v', '--version', default='latest', help='Model version (name of the param file)')
+    parser.add_argument('-i', '--index', default=0, type=int, help='Index of the sample to predict and show')
+    parser.add_argument('-r', '--radius', default=4, type=int, help='Radius of the keypoint circle')
+    parser.add_argument('-p', dest='plot', action='store_true', help='If set the prediction the results are displayed')
+    parser.add_argument('-e', dest='evaluation', action='store_true', help='If set the evaluation metrics are computed')
+    parser.add_argument('-b', dest='batch', action='store_true', help='If set a batch of images is predicted and displayed instead of a single image')
+    parser.add_argument('-t', dest='threshold', default=3, type=int, help='Distance threshold for two keypoints to be considered a match')
+    parser.add_argument('-mask', dest='mask', action='store_true', help='If set invalid image pixels will be set to 0')
+    parser.add_argument('-s', '--seed', default=0, type=int, help='Seed of the random generators')
+    return parser
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    with open(args.yaml_config, 'r') as f:
+        config = yaml.load(f, Loader=yaml.FullLoader)
+    with open(os.path.join(args.model_dir, 'params.yaml'), 'r') as f:
+        config['model'] = yaml.load(f, Loader=yaml.FullLoader)['model']
+    device = select_device(config)
+    print('Predicting on device: {}'.format(device))
+    dataset = getattr(datasets, config['dataset']['type'])(config['dataset'])
+    loader_dataset = torch.utils.data.DataLoader(dataset, batch_size=config['prediction']['batchsize'],
+                                                 shuffle=False, num_workers=config['prediction']['num_worker'])
+    net = load_network(config, args.model_dir, args.version, device, args.seed)
+    pred = config['prediction']
+
+    with torch.no_grad():
+        if args.evaluation:
+            raise NotImplementedError('repeatability / detector mAP (-e) is CPU post-processing outside the '
+                                      'accelerated hot path; use predict_align_image_pair.py -e for the batched driver')
+        t_start = time.time()
+        if args.batch:
+            for i in range(args.index + 1):
+                data = next(iter(loader_dataset))
+        else:
+            data = dataset[args.index]
+        data = utils.data_to_device(data, device)
+        if not args.batch:
+            data = utils.data_unsqueeze(data, 0)
+
+        def nms(prob):
+            if pred['nms'] > 0:
+                return utils.box_nms(prob, pred['nms'], pred['detection_threshold'], keep_top_k=pred['topk'],
+                                     on_cpu=pred['cpu_nms'])
+            return prob
+
+        outs = {}
+        if dataset.returns_pair():
+            for side in ('optical', 'thermal'):
+                out = net(data[side])
+                out['prob'] = nms(out['prob'])
+                outs[side] = out
+        else:
+            out = net(data)
+            out['prob'] = nms(out['prob'])
+            outs['image'] = out
+        torch.cuda.synchronize()
+        print('Prediction took: {} s'.format(time.time() - t_start))
+        for side, out in outs.items():
+            n = (out['prob'] > pred['detection_threshold']).flatten(1).sum(1).cpu().numpy()
+            print('{} keypoints per image: {}'.format(side, n.tolist()))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,49 @@
+"""CPU, world_size 2 over gloo: the multi-GPU path (pair sharding + the metric gather, which is the
+only collective of the hot path)."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _worker(rank, world, port, n_pairs, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from multipoint_amd.dist import shard_pairs, gather_pair_metrics
+    mine = shard_pairs(n_pairs, rank, world)
+    # a per-pair record that only depends on the pair id (stands in for kp/match counts)
+    rec = torch.tensor([[p, 3 * p + 1, 7 * p % 5, p * p] for p in mine], dtype=torch.int32).reshape(-1, 4)
+    allrec = gather_pair_metrics(rec)
+    torch.save(allrec, os.path.join(out_dir, 'rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_and_gather_world2(tmp_path):
+    n_pairs, world = 7, 2          # ragged: rank 0 owns 4 pairs, rank 1 owns 3
+    mp.spawn(_worker, args=(world, _free_port(), n_pairs, str(tmp_path)), nprocs=world, join=True)
+    a = torch.load(tmp_path / 'rank0.pt'); b = torch.load(tmp_path / 'rank1.pt')
+    assert torch.equal(a, b)
+    assert a.shape == (n_pairs, 4)
+    ids = sorted(a[:, 0].tolist())
+    assert ids == list(range(n_pairs))                      # every pair exactly once
+    for row in a.tolist():
+        p = row[0]
+        assert row == [p, 3 * p + 1, 7 * p % 5, p * p]      # identical to a single-rank run
+
+
+def test_shard_pairs_partition():
+    from multipoint_amd.dist import shard_pairs, gather_pair_metrics
+    for world in (1, 2, 4, 8):
+        parts = [shard_pairs(37, r, world) for r in range(world)]
+        assert sorted(sum(parts, [])) == list(range(37))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+    x = torch.arange(6).reshape(3, 2)
+    assert torch.equal(gather_pair_metrics(x), x)            # no process group: identity

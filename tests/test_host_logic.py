@@ -1,0 +1,176 @@
+"""CPU: host-side logic of the product package and the C-ABI library surface (no compute calls:
+there is no GPU here).  Also checks that the product never falls back to a CPU path."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from multipoint_amd import _lib
+    return _lib
+
+
+def test_library_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, 'include', 'multipoint_hip.h')).read()
+    declared = set(re.findall(r'\b(mp_[a-z_0-9]+)\s*\(', header))
+    assert {'mp_create', 'mp_forward', 'mp_box_nms', 'mp_detect_keypoints', 'mp_sample_descriptors',
+            'mp_match_mutual_nn', 'mp_load_weights'} <= declared
+    dll = ctypes.CDLL(lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(dll, name), 'library does not export %s' % name
+    assert declared == set(lib.SIGNATURES), 'ctypes binding and header disagree'
+    assert b'gfx950' in lib.load_library().mp_version()
+
+
+def test_library_is_gfx950_only():
+    out = subprocess.run(['/opt/rocm/lib/llvm/bin/clang-offload-bundler', '--list', '--type=o',
+                          '--input=%s' % os.path.join(ROOT, 'multipoint_amd', 'libmultipoint_hip.so')],
+                         capture_output=True, text=True)
+    if out.returncode == 0 and out.stdout.strip():
+        assert 'gfx950' in out.stdout and 'gfx942' not in out.stdout and 'sm_' not in out.stdout
+
+
+def test_no_cpu_fallback(lib):
+    """Without a GPU every compute entry raises; nothing silently routes to the oracle / torch CPU."""
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    import multipoint_amd.models as M
+    import multipoint_amd.utils as U
+    net = M.MultiPoint({'multispectral': False, 'descriptor_size': 64})
+    with pytest.raises(RuntimeError, match='no CPU fallback'):
+        net.to('cuda')
+    with pytest.raises(RuntimeError):
+        U.box_nms(torch.rand(16, 16), 4, 0.015)
+    with pytest.raises(RuntimeError):
+        U.get_matches(np.eye(4, 64, dtype=np.float32), np.eye(4, 64, dtype=np.float32), 'nnmatcher')
+    with pytest.raises(RuntimeError):
+        U.interpolate_descriptors(torch.zeros(3, 2, dtype=torch.int64), torch.rand(64, 4, 4), 32, 32)
+    h = ctypes.c_void_p()
+    rc = lib.load_library().mp_create(ctypes.byref(h), 0)
+    assert rc != 0 and not h
+    assert lib.load_library().mp_last_error(None)
+
+
+def test_product_does_not_import_oracle():
+    pkg = os.path.join(ROOT, 'multipoint_amd')
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(dirpath, f)).read()
+                assert 'oracle' not in src.replace('test_oracle', ''), '%s mentions the oracle' % f
+    for f in ('predict_align_image_pair.py', 'predict_keypoints.py'):
+        assert 'oracle' not in open(os.path.join(ROOT, f)).read()
+
+
+def test_state_dict_layout_matches_oracle_spec(oracle):
+    import multipoint_amd.models as M
+    for cfg in (oracle.SHIPPED_MODEL_CONFIG, {'multispectral': True}, {'bn_first': True, 'multispectral': False},
+                {'final_batchnorm': False, 'descriptor_head': False}):
+        ours = [(k, tuple(s), d) for k, s, d in M.MultiPoint(dict(cfg)).state_dict_spec()]
+        theirs = [(k, tuple(s), d) for k, s, d in oracle.state_dict_spec(cfg)]
+        assert ours == theirs
+    n = sum(int(np.prod(s)) if len(s) else 1 for _, s, _ in M.MultiPoint(dict(oracle.SHIPPED_MODEL_CONFIG)).state_dict_spec())
+    assert n == 1257169                                           # state-dict elements
+
+
+def test_load_state_dict_is_strict(oracle):
+    import multipoint_amd.models as M
+    cfg = dict(oracle.SHIPPED_MODEL_CONFIG)
+    sd = oracle.make_weights(0, cfg)
+    net = M.MultiPoint(cfg)
+    net.load_state_dict(sd)
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    bad = dict(sd); bad.pop('encoder.5.bias')
+    with pytest.raises(RuntimeError, match='Missing key'):
+        M.MultiPoint(cfg).load_state_dict(bad)
+    bad = dict(sd); bad['encoder.99.weight'] = torch.zeros(1)
+    with pytest.raises(RuntimeError, match='Unexpected key'):
+        M.MultiPoint(cfg).load_state_dict(bad)
+    bad = dict(sd); bad['encoder.5.weight'] = torch.zeros(64, 32, 3, 3)
+    with pytest.raises(RuntimeError, match='size mismatch'):
+        M.MultiPoint(cfg).load_state_dict(bad)
+    # prefixed keys as written by DataParallel checkpoints are fixed by fix_model_weigth_keys
+    import multipoint_amd.utils as U
+    pre = {'module__' + k: v for k, v in sd.items()}
+    M.MultiPoint(cfg).load_state_dict(U.fix_model_weigth_keys(pre))
+    with pytest.raises(ValueError):
+        M.MultiPoint({'channel_version': 1})
+    with pytest.raises(ValueError):
+        net.set_force_return_logits(1)
+    with pytest.raises(NotImplementedError):
+        net.train()
+    rnd = M.MultiPoint(cfg).init_random_weights(3).state_dict()
+    assert list(rnd.keys()) == list(sd.keys())
+
+
+def test_argument_errors_mirror_reference():
+    import multipoint_amd.utils as U
+    with pytest.raises(ValueError, match='either 2D'):
+        U.box_nms(torch.rand(2, 16, 16), 4, 0.015)                # utils.py:90-91
+    with pytest.raises(ValueError, match='unknown matching method'):
+        U.get_matches(np.zeros((2, 64), np.float32), np.zeros((2, 64), np.float32), 'nope')   # matching.py:18-19
+    with pytest.raises(ValueError, match='non-negative'):
+        U.get_matches(np.zeros((2, 64), np.float32), np.zeros((2, 64), np.float32), 'nnmatcher', threshold=-0.1)
+    with pytest.raises(NotImplementedError):
+        U.get_matches(np.zeros((2, 64), np.float32), np.zeros((2, 64), np.float32), 'flann')
+    with pytest.raises(NotImplementedError):
+        U.get_matches(np.zeros((2, 64), np.float32), np.zeros((2, 64), np.float32), 'bfmatcher', True, crossCheck=True)
+    assert U.get_matches(np.zeros((0, 64), np.float32), np.zeros((2, 64), np.float32), 'nnmatcher') == []   # matching.py:46-47
+
+
+def test_plumbing_helpers():
+    import multipoint_amd.utils as U
+    d = {'a': torch.zeros(2), 'b': {'c': torch.ones(3), 'name': 'x'}}
+    out = U.data_unsqueeze(U.data_to_device(d, 'cpu'), 0)
+    assert out['a'].shape == (1, 2) and out['b']['c'].shape == (1, 3) and out['b']['name'] == 'x'
+    assert U.dict_update({'a': {'b': 1, 'c': 2}}, {'a': {'b': 3}, 'd': 4}) == {'a': {'b': 3, 'c': 2}, 'd': 4}
+
+
+def test_synthetic_dataset_schema():
+    from multipoint_amd.datasets import SyntheticPairs, ImagePairDataset
+    ds = SyntheticPairs({'num_samples': 3, 'height': 64, 'width': 96})
+    s = ds[1]
+    assert ds.returns_pair() and len(ds) == 3
+    for side, flag in (('optical', True), ('thermal', False)):
+        e = s[side]
+        assert e['image'].shape == (1, 64, 96) and e['image'].dtype == torch.float32
+        assert e['valid_mask'].dtype == torch.bool and e['valid_mask'].all()
+        assert bool(e['is_optical'][0]) is flag
+    assert torch.equal(ds[1]['optical']['image'], s['optical']['image'])         # deterministic
+    assert not torch.equal(ds[0]['optical']['image'], s['optical']['image'])
+    with pytest.raises(IndexError):
+        ds[3]
+    with pytest.raises(ValueError):
+        SyntheticPairs({'height': 60, 'width': 64})
+    with pytest.raises(ValueError):
+        ImagePairDataset({'filename': None})
+    loader = torch.utils.data.DataLoader(ds, batch_size=2)
+    b = next(iter(loader))
+    assert b['optical']['image'].shape == (2, 1, 64, 96) and b['thermal']['is_optical'].shape == (2, 1)
+
+
+def test_cli_surface():
+    for script, flags in (('predict_align_image_pair.py', ['-y', '-m', '-v', '-i', '-r', '-p', '-e', '-tk', '-th', '-s']),
+                          ('predict_keypoints.py', ['-y', '-m', '-v', '-i', '-r', '-p', '-e', '-b', '-t', '-mask', '-s'])):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, script), '--help'], capture_output=True, text=True, cwd=ROOT)
+        assert out.returncode == 0
+        for f in flags:
+            assert re.search(r'(^|[\s\[])%s\b' % re.escape(f), out.stdout), (script, f)
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(ROOT, 'configs', 'config_image_pair_dataset_prediction.yaml')))
+    assert set(cfg['prediction']) >= {'allow_gpu', 'num_worker', 'batchsize', 'detection_threshold', 'nms', 'cpu_nms',
+                                      'topk', 'reprojection_threshold', 'matching'}
+    assert set(cfg['prediction']['matching']) == {'method', 'method_kwargs', 'knn_matches'}
+    params = yaml.safe_load(open(os.path.join(ROOT, 'model_weights', 'multipoint', 'params.yaml')))['model']
+    assert params['type'] == 'MultiPoint' and params['descriptor_size'] == 64 and params['multispectral'] is False

@@ -1,0 +1,85 @@
+"""CPU: the oracle (oracle/mp_oracle.py) against the committed golden vectors that were produced by
+importing the reference itself (tests/golden/make_golden.py).  This is what pins the oracle on the
+GPU box, where /root/reference does not exist."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name))
+
+
+def test_forward_64x64_full(oracle, golden_dir):
+    g = _load(golden_dir, 'forward_64x64.npz')
+    sd = oracle.make_weights(int(g['weight_seed']), oracle.SHIPPED_MODEL_CONFIG)
+    img = oracle.make_images(int(g['image_seed']), int(g['B']), int(g['H']), int(g['W']))
+    out = oracle.forward(sd, img, oracle.SHIPPED_MODEL_CONFIG)
+    assert out['prob'].shape == (2, 1, 64, 64) and out['desc'].shape == (2, 64, 8, 8)
+    assert np.abs(out['prob'].numpy() - g['prob']).max() <= 1e-6
+    assert np.abs(out['desc'].numpy() - g['desc']).max() <= 1e-6
+
+
+def test_forward_240x320_samples(oracle, golden_dir):
+    g = _load(golden_dir, 'forward_240x320.npz')
+    sd = oracle.make_weights(int(g['weight_seed']), oracle.SHIPPED_MODEL_CONFIG)
+    img = oracle.make_images(int(g['image_seed']), 1, 240, 320)
+    out = oracle.forward(sd, img, oracle.SHIPPED_MODEL_CONFIG)
+    p = out['prob'].numpy().ravel(); d = out['desc'].numpy().ravel()
+    assert np.abs(p[g['prob_idx']] - g['prob_val']).max() <= 1e-6
+    assert np.abs(d[g['desc_idx']] - g['desc_val']).max() <= 1e-6
+    assert abs(p.astype(np.float64).sum() - float(g['prob_sum'])) <= 1e-3
+    assert abs(np.abs(d.astype(np.float64)).sum() - float(g['desc_abs_sum'])) <= 1e-2
+    # the synthetic detector is "trained-like": a few thousand candidates, not 69 % of all pixels
+    assert 500 < int((p > 0.015).sum()) < 20000
+
+
+@pytest.mark.parametrize('name,upd', [('multispectral', {'multispectral': True}), ('zero_pad', {'reflection_pad': False}),
+                                      ('bn_first', {'bn_first': True}), ('desc256', {'descriptor_size': 256}),
+                                      ('no_final_bn', {'final_batchnorm': False}),
+                                      ('no_normalize', {'normalize_descriptors': False})])
+def test_forward_variants(oracle, golden_dir, name, upd):
+    g = _load(golden_dir, 'forward_variants.npz')
+    cfg = dict(oracle.SHIPPED_MODEL_CONFIG); cfg.update(upd)
+    sd = oracle.make_weights(int(g['weight_seed']), cfg)
+    img = oracle.make_images(int(g['image_seed']), 3, 32, 48)
+    flags = torch.tensor([[True], [False], [True]])
+    out = oracle.forward(sd, img, cfg, is_optical=flags)
+    assert np.abs(out['prob'].numpy() - g[name + '_prob']).max() <= 1e-6
+    assert np.abs(out['desc'].numpy() - g[name + '_desc']).max() <= 2e-6 * max(1.0, np.abs(g[name + '_desc']).max())
+
+
+def test_forward_logits(oracle, golden_dir):
+    g = _load(golden_dir, 'forward_variants.npz')
+    sd = oracle.make_weights(0, oracle.SHIPPED_MODEL_CONFIG)
+    out = oracle.forward(sd, oracle.make_images(int(g['image_seed']), 3, 32, 48), oracle.SHIPPED_MODEL_CONFIG,
+                         return_logits=True)
+    assert out['prob'] is None
+    assert np.abs(out['logits'].numpy() - g['logits']).max() <= 1e-5
+
+
+def test_sampling(oracle, golden_dir):
+    g = _load(golden_dir, 'sampling.npz')
+    rows = oracle.interpolate_descriptors(g['keypoints'], g['desc'], int(g['H']), int(g['W']))
+    assert rows.shape == g['rows'].shape
+    assert np.abs(rows - g['rows']).max() <= 1e-6
+    rows_t = oracle.interpolate_descriptors_torch(g['keypoints'], g['desc'], int(g['H']), int(g['W']))
+    assert np.abs(rows_t - g['rows']).max() <= 1e-7
+    assert np.abs(np.linalg.norm(rows, axis=1) - 1).max() < 1e-5
+
+
+def test_matcher(oracle, golden_dir):
+    g = _load(golden_dir, 'matcher.npz')
+    q, t, d = oracle.nn_match(g['d1'], g['d2'], float(g['threshold']))
+    assert np.array_equal(q, g['query']) and np.array_equal(t, g['train'])
+    assert np.abs(d - g['distance']).max() <= 1e-6
+    assert len(q) >= 80          # the fixture holds 100 true correspondences
+
+
+def test_depth_to_space(oracle, golden_dir):
+    g = _load(golden_dir, 'depth_to_space.npz')
+    x = torch.from_numpy(g['x'])
+    assert np.array_equal(oracle.depth_to_space(x, 8).numpy(), g['d2s'])
+    assert np.array_equal(g['s2d'], g['x'])

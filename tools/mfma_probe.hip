@@ -1,0 +1,77 @@
+// Developer microbenchmark (GPU box): what limits the fp32 MFMA loop of conv_mfma_kernel?
+// Variants: bit0 = LDS A reads per step, bit1 = global B loads per step; blocks/CU via LDS size.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include <cstdlib>
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int V>
+__global__ __launch_bounds__(256, 3) void probe(const float* __restrict__ w, float* out, int iters, int lds_bytes_used)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    for (int i = tid; i < 4096; i += 256) lds[i] = lds_bytes_used < 0 ? 0.f : __uint_as_float(0x3f000000u | ((i * 2654435761u) >> 9)) - 0.75f;
+    __syncthreads();
+    f32x16 acc[4];
+    for (int a = 0; a < 4; ++a) for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    const f32x4* wp = reinterpret_cast<const f32x4*>(w) + lane;
+    const int ab = (V & 4) ? ((lane & 31) * 36 + (lane >> 5) * 4) : lane * 4;
+    f32x4 a0 = *reinterpret_cast<f32x4*>(&lds[lane * 4]), a1 = *reinterpret_cast<f32x4*>(&lds[lane * 4 + 256]);
+    f32x4 b0 = wp[0], b1 = wp[64];
+    for (int it = 0; it < iters; ++it) {
+        asm volatile("" : "+v"(wp));
+#pragma unroll
+        for (int s = 0; s < 36; ++s) {
+            f32x4 na0 = a0, na1 = a1, nb0 = b0, nb1 = b1;
+            if (V & 1) {
+                na0 = *reinterpret_cast<f32x4*>(&lds[ab + ((s * 36 + 8) & 1023)]);
+                na1 = *reinterpret_cast<f32x4*>(&lds[ab + 1224 + ((s * 36) & 1023)]);
+            }
+            if (V & 2) { nb0 = wp[(s * 128)]; nb1 = wp[s * 128 + 64]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b0[e], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[e], b1[e], acc[1], 0, 0, 0);
+                acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b0[e], acc[2], 0, 0, 0);
+                acc[3] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[e], b1[e], acc[3], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+        }
+    }
+    float s = 0.f;
+    for (int a = 0; a < 4; ++a) for (int r = 0; r < 16; ++r) s += acc[a][r];
+    if (s == 123.456f) out[tid] = s;
+}
+
+template <int V>
+void run(const float* w, float* out, int blocks_per_cu, int iters)
+{
+    const int lds = blocks_per_cu == 1 ? 150000 : blocks_per_cu == 2 ? 80000 : blocks_per_cu == 3 ? 50000 : 36000;
+    hipFuncSetAttribute(reinterpret_cast<const void*>(probe<V>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    const int grid = 256 * blocks_per_cu;
+    hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+    probe<V><<<grid, 256, lds>>>(w, out, 2, lds);
+    hipDeviceSynchronize();
+    hipEventRecord(a);
+    probe<V><<<grid, 256, lds>>>(w, out, iters, lds);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    const double flop = (double)grid * 4 * iters * 36 * 16 * 4096.0;
+    printf("V=%d blocks/CU=%d  %.3f ms  %.1f TF/s (%.1f%% of 157.3)  err=%s\n", V, blocks_per_cu, ms, flop / ms / 1e9,
+           flop / ms / 1e9 / 157.3 * 100, hipGetErrorString(hipGetLastError()));
+}
+
+int main(int argc, char** argv)
+{
+    float *w, *out;
+    hipMalloc(&w, 36 * 128 * 16 * 4 + 4096); hipMalloc(&out, 4096);
+    const int mode = argc > 1 ? atoi(argv[1]) : 0;
+    { std::vector<float> hw(36 * 128 * 16 + 1024); unsigned x = 12345; for (auto& v : hw) { x = x * 1664525u + 1013904223u; v = mode ? ((x >> 8) / 16777216.0f - 0.5f) * 0.2f : 0.f; } hipMemcpy(w, hw.data(), hw.size() * 4, hipMemcpyHostToDevice); }
+    printf("weights %s\n", mode ? "random" : "zero");
+    for (int bpc = 1; bpc <= 3; ++bpc) { run<0>(w, out, bpc, 400); run<1>(w, out, bpc, 400); run<2>(w, out, bpc, 400); run<3>(w, out, bpc, 400); }
+    return 0;
+}
