@@ -500,16 +500,17 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
     const long long npx = (long long)B * Hc * Wc;
     const int D = h->cfg.descriptor_size;
     const int headc = h->cfg.descriptor_head ? 512 : 256;
-    // workspace: P (B*H*W*64) | Q (B*H*W*16) | logits (npx*80) | desc raw (npx*D) | img lists
+    // workspace: P (B*H*W*64) | Q (B*H*W*16) | X encoder output (npx*128) | logits (npx*80) | img lists
     const size_t nP = (size_t)B * H * W * 64, nQ = (size_t)B * H * W * 16;
-    const size_t nL = (size_t)npx * 80, nD = (size_t)npx * (h->cfg.descriptor_head ? D : 0);
+    const size_t nL = (size_t)npx * 80, nD = (size_t)npx * 128;
     int rc;
     if ((rc = ensure(h, h->ws, (nP + nQ + nL + nD) * 4 + 2 * 1024 * 4 + 256))) return rc;
     float* P = static_cast<float*>(h->ws.p);
     float* Q = P + nP;
     float* Lg = Q + nQ;
-    float* Dr = Lg + nL;
-    int* lists = reinterpret_cast<int*>(Dr + nD);
+    float* X = Lg + nL;      // encoder output: separate from the ping-pong buffers, because with two
+                             // encoders the second pass would overwrite the first pass's result
+    int* lists = reinterpret_cast<int*>(X + nD);
     if (h->prof_used > 4000) h->prof_used = 0;      // profile ring: entries accumulate until read
 
     // encoder(s): multispectral routes each image by is_optical (MultiPoint.py:107-122)
@@ -544,14 +545,13 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
         float* dst = Q;
         for (int i = 0; i < 7; ++i) {
             const ConvLayer& L = E.conv[i];
-            run_conv(h, L, src, L.cin, 0, dst, L.cout, 0, nb, hh, ww, lptr[e], s);
+            run_conv(h, L, src, L.cin, 0, i == 6 ? X : dst, L.cout, 0, nb, hh, ww, lptr[e], s);
             if (L.pool) { hh /= 2; ww /= 2; }
             float* t = src; src = dst; dst = t;
         }
-        // 7 layers: P->Q->P->Q->P->Q->P->Q : encoder output ends in Q
     }
     // heads
-    run_conv(h, h->heads3, Q, 128, 0, P, headc, 0, B, Hc, Wc, nullptr, s);
+    run_conv(h, h->heads3, X, 128, 0, P, headc, 0, B, Hc, Wc, nullptr, s);
     run_conv(h, h->det1, P, headc, 0, Lg, 80, 0, B, Hc, Wc, nullptr, s);
     if (prob || logits) {
         prof_begin(h, "det.softmax_shuffle", 0.0, s);
