@@ -155,7 +155,8 @@ void pack_conv_weights(const std::vector<const float*>& srcs, const std::vector<
     int cout = 0;
     for (int c : couts) cout += c;
     const int nslices = (cout + 63) / 64, nchunks = cin / 32;
-    out.assign((size_t)nslices * nchunks * taps * 4 * 2 * 64 * 4, 0.f);
+    // + 2 steps of zero padding: the kernel's weight prefetch runs two steps past the last slice
+    out.assign((size_t)nslices * nchunks * taps * 4 * 2 * 64 * 4 + 2 * 2 * 64 * 4, 0.f);
     size_t o = 0;
     for (int s = 0; s < nslices; ++s)
         for (int c = 0; c < nchunks; ++c)
@@ -292,7 +293,6 @@ void run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride,
     p.pad_zero = h->cfg.reflection_pad ? 0 : 1;
     p.bn_first = h->cfg.bn_first;
     p.relu = L.relu ? 1 : 0;
-    { const char* e = getenv("MP_DBG"); p.dbg = e ? atoi(e) : 0; }
     int mbw = 32;
     if (L.taps == 9) {
         mbw = pick_mbw(H, W);

@@ -46,7 +46,7 @@ __device__ __forceinline__ int reflect_clamp(int v, int n)
 }
 
 template <int TAPS, int MBW, bool POOL>
-__global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvParams p)
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
 {
     using G = Geo<TAPS, MBW>;
     __shared__ __attribute__((aligned(16))) float lds[G::NPIX * PS];
@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvParams p)
     }
 
     // ---- A-fragment LDS base of this lane (M-block 2*wave, tap (0,0), k-group 0) ----
-    const int a_base = (p.dbg & 8) ? lane * 4 : (((2 * wave) * G::MBH + li / MBW) * G::LW + (li % MBW)) * PS + half * 4;
+    const int a_base = (((2 * wave) * G::MBH + li / MBW) * G::LW + (li % MBW)) * PS + half * 4;
     constexpr int A_MB = G::MBH * G::LW * PS;     // second M-block of the wave
 
     const int nchunks = p.cin / CK;
@@ -126,19 +126,28 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    const int reps = (p.dbg & 16) ? 400 : (p.dbg & 4) ? 4 : 1;
-    for (int cc = 0; cc < nchunks * reps; ++cc) {
-        const int c = cc % nchunks;
-        if (!((p.dbg & 1) && cc > 0)) {
-        // -------- stage the (tile+halo) x 32-channel chunk into LDS --------
-        f32x4 stg[G::NITER];
+    // -------- operand pipelines --------------------------------------------------------------
+    // B (weights): one linear stream over (chunk, step) straight from L2 into VGPRs, fetched two
+    //   steps ahead and NEVER restarted inside a tile (a restart at every chunk boundary stalls
+    //   all co-resident waves at once: measured 95 % -> 88 % of peak in tools/mfma_probe2.hip).
+    //   The last two prefetches of a tile run past the slice (padding in the packed buffer).
+    // A (activations): chunk c+1 is fetched global -> VGPR while chunk c is being multiplied
+    //   (one 16-byte load per step, steps S0..), and moved VGPR -> LDS between two barriers.
+    constexpr int RB = (G::STEPS % 3 == 0) ? 3 : 4;      // B ring size: must divide STEPS
+    static_assert(G::STEPS % RB == 0 && G::STEPS % 2 == 0, "operand rings must stay aligned across chunks");
+    f32x4 af[2][2], bf[RB][2], stg[G::NITER];
+    bf[0][0] = wp[0];   bf[0][1] = wp[64];
+    bf[1][0] = wp[128]; bf[1][1] = wp[128 + 64];
 #pragma unroll
-        for (int j = 0; j < G::NITER; ++j) {
-            stg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (goff[j] >= 0)
-                stg[j] = *reinterpret_cast<const f32x4*>(in_base + goff[j] + c * CK);
-        }
-        if (cc > 0) __syncthreads();            // previous chunk fully consumed
+    for (int j = 0; j < G::NITER; ++j) {
+        stg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (goff[j] >= 0) stg[j] = *reinterpret_cast<const f32x4*>(in_base + goff[j]);
+    }
+    constexpr int S0 = (TAPS == 9) ? 6 : 0;               // first step that issues a staging load
+    constexpr int PER_STEP = (TAPS == 9) ? 1 : 2;         // staging loads per step
+
+    for (int c = 0; c < nchunks; ++c) {
+        if (c > 0) __syncthreads();                        // chunk c-1 fully consumed
 #pragma unroll
         for (int j = 0; j < G::NITER; ++j) {
             const int f = tid + j * 256;
@@ -146,22 +155,16 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvParams p)
                 *reinterpret_cast<f32x4*>(&lds[(f >> 3) * PS + (f & 7) * 4]) = stg[j];
         }
         __syncthreads();
-        }
 
-        // -------- 9 taps x 4 k-groups, 16 MFMAs each.  Software pipeline pinned with sched_barrier:
-        //          B (weights, L2) is fetched two steps ahead, A (LDS) one step ahead ------------
         const f32x4* wc = wp + (long long)c * (G::STEPS * 128);
-        f32x4 af[2][2], bf[3][2];
+        const bool more = c + 1 < nchunks;
+        const float* in_next = in_base + (c + 1) * CK;
         af[0][0] = *reinterpret_cast<const f32x4*>(&lds[a_base]);
         af[0][1] = *reinterpret_cast<const f32x4*>(&lds[a_base + A_MB]);
-        bf[0][0] = wc[0];   bf[0][1] = wc[64];
-        bf[1][0] = wc[128]; bf[1][1] = wc[128 + 64];
 #pragma unroll
         for (int s = 0; s < G::STEPS; ++s) {
-            if (s + 2 < G::STEPS) {
-                bf[(s + 2) % 3][0] = wc[(s + 2) * 128];
-                bf[(s + 2) % 3][1] = wc[(s + 2) * 128 + 64];
-            }
+            bf[(s + 2) % RB][0] = wc[(s + 2) * 128];
+            bf[(s + 2) % RB][1] = wc[(s + 2) * 128 + 64];
             if (s + 1 < G::STEPS) {
                 const int sn = s + 1;
                 const int tap = sn >> 2, gg = sn & 3;
@@ -170,25 +173,28 @@ __global__ __launch_bounds__(256, 3) void conv_mfma_kernel(const ConvParams p)
                 af[sn & 1][0] = *reinterpret_cast<const f32x4*>(&lds[a_base + aoff]);
                 af[sn & 1][1] = *reinterpret_cast<const f32x4*>(&lds[a_base + A_MB + aoff]);
             }
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < PER_STEP; ++u) {
+                    const int j = (s - S0) * PER_STEP + u;
+                    if (s >= S0 && j < G::NITER) {
+                        stg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        if (goff[j] >= 0) stg[j] = *reinterpret_cast<const f32x4*>(in_next + goff[j]);
+                    }
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][0][e], bf[s % 3][0][e], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][0][e], bf[s % 3][1][e], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][1][e], bf[s % 3][0][e], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][1][e], bf[s % 3][1][e], acc[1][1], 0, 0, 0);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][0][e], bf[s % RB][0][e], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][0][e], bf[s % RB][1][e], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][1][e], bf[s % RB][0][e], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][1][e], bf[s % RB][1][e], acc[1][1], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 
-    if (p.dbg & 2) {
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-            for (int b = 0; b < 2; ++b) asm volatile("" :: "v"(acc[a][b]));
-        return;
-    }
     // ---------------- epilogue: bias -> (ReLU, BN) | (BN, ReLU) -> [2x2 max] -> store --------
     float bia[2], scl[2], sft[2];
     int ch[2];
@@ -285,14 +291,9 @@ void launch_t(const ConvParams& p, hipStream_t s)
     long long ntiles;
     if (TAPS == 9) ntiles = (long long)p.B * p.tiles_x * p.tiles_y;
     else ntiles = (p.total_px + 255) / 256;
-    long long nblk = ntiles * p.nslices;
+    const long long nblk = ntiles * p.nslices;
     if (nblk <= 0) return;
-    if (p.dbg & 16) nblk = 768;
-    unsigned dyn = 0;
-    if (p.dbg & 32) { dyn = 60000; nblk = (p.dbg & 16) ? 256 : nblk; }
-    if (p.dbg & 64) { dyn = 20000; nblk = (p.dbg & 16) ? 512 : nblk; }
-    if (dyn) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_mfma_kernel<TAPS, MBW, POOL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)dyn);
-    hipLaunchKernelGGL((conv_mfma_kernel<TAPS, MBW, POOL>), dim3((unsigned)nblk), dim3(256), dyn, s, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<TAPS, MBW, POOL>), dim3((unsigned)nblk), dim3(256), 0, s, p);
 }
 
 }  // namespace

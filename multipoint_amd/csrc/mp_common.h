@@ -33,7 +33,6 @@ struct ConvParams {
     int bn_first;         // 0: conv -> ReLU -> BN (reference default), 1: conv -> BN -> ReLU
     int relu;             // 0: no ReLU (final 1x1 convs)
     long long total_px;   // TAPS==1 (flat) mode: number of pixels
-    int dbg;              // developer experiments (MP_DBG env), 0 in production
 };
 
 // first layer (Cin = 1, direct VALU conv, HBM-write bound)

@@ -27,12 +27,13 @@ __global__ __launch_bounds__(256, 3) void probe(const float* __restrict__ w, flo
     for (int it = 0; it < iters; ++it) {
         int zoff = 0; asm volatile("" : "+v"(zoff));
         const f32x4* wp = wp0 + zoff + (it % wchunks) * (36 * 128);
+        if (MODE == 5) { b0 = wp[0]; b1 = wp[64]; c0 = wp[128]; c1 = wp[192]; a0 = *reinterpret_cast<f32x4*>(&lds[ab + (it & 7) * 4]); a1 = *reinterpret_cast<f32x4*>(&lds[ab + 1224 + (it & 7) * 4]); }
 #pragma unroll
         for (int s = 0; s < 36; ++s) {
             f32x4 na0, na1, n0 = c0, n1 = c1;
             na0 = *reinterpret_cast<f32x4*>(&lds[ab + ((s * 36 + 8) & 1023)]);
             na1 = *reinterpret_cast<f32x4*>(&lds[ab + 1224 + ((s * 36) & 1023)]);
-            if (MODE == 1) { n0 = wp[(s * 128)]; n1 = wp[s * 128 + 64]; }
+            if (MODE == 1 || MODE == 5) { n0 = wp[(s * 128)]; n1 = wp[s * 128 + 64]; }
             if (MODE == 2) { n0 = wp[(s * 128)]; }
             if (MODE == 3) {
                 float* slot = ring + ((s + 2) % 3) * 512;
@@ -90,6 +91,6 @@ int main()
     for (auto& v : hw) { x = x * 1664525u + 1013904223u; v = ((x >> 8) / 16777216.0f - 0.5f) * 0.2f; }
     hipMemcpy(w, hw.data(), n * 4, hipMemcpyHostToDevice);
     run<1>(w, out, 3, 300, 1);
-    for (int wc : {1, 2, 4, 8, 16}) { run<1>(w, out, 3, 304, wc); run<1>(w, out, 2, 304, wc); }
+    for (int bpc = 1; bpc <= 3; ++bpc) { run<1>(w, out, bpc, 304, 2); run<5>(w, out, bpc, 304, 2); }
     return 0;
 }
