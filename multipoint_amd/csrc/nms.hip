@@ -39,14 +39,21 @@ __global__ __launch_bounds__(256) void nms_init_kernel(const float* __restrict__
     reinterpret_cast<f32x4*>(work)[i] = v;
 }
 
-// flags: [2][B*tiles] ping-pong "tile still has undecided pixels"; remaining[round] = #undecided
+// flags: [2][B*tiles] ping-pong "tile still has undecided pixels"; remaining[round] = #undecided.
+// Work inside a tile is list driven: the undecided pixels are kept as a compact LDS list, one thread
+// per list entry, so an iteration costs O(#undecided) instead of O(tile) -- candidates are sparse
+// (a few % of the pixels) and most of them are decided after two or three iterations.
+// RT > 0: footprint radius known at compile time (fully unrolled scan, row masks in SGPRs).
+template <int RT>
 __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work, int H, int W,
                                                        int tiles_x, int tiles_y, NmsFootprint fp,
                                                        int* __restrict__ flags, int ntiles_total,
                                                        int* __restrict__ remaining, int round)
 {
     __shared__ float t[(NT + 2 * MP_NMS_MAX_R) * (NT + 2 * MP_NMS_MAX_R)];
-    const int R = fp.R;
+    __shared__ unsigned short list[2][NT * NT];
+    __shared__ int cnt[2];
+    const int R = RT > 0 ? RT : fp.R;
     const int LW = NT + 2 * R;
     const int tid = threadIdx.x;
     const int tile_id = blockIdx.x;
@@ -63,69 +70,85 @@ __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work
     const int y0 = ty * NT, x0 = tx * NT;
     float* img = work + (long long)b * H * W;
 
+    if (tid < 2) cnt[tid] = 0;
+    __syncthreads();
     for (int f = tid; f < LW * LW; f += 256) {
         const int ly = f / LW, lx = f - ly * LW;
         const int gy = y0 + ly - R, gx = x0 + lx - R;
-        t[f] = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(long long)gy * W + gx] : 0.f;
+        const float v = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(long long)gy * W + gx] : 0.f;
+        t[f] = v;
+        if (v > 0.f && ly >= R && ly < R + NT && lx >= R && lx < R + NT)
+            list[0][atomicAdd(&cnt[0], 1)] = (unsigned short)f;
     }
     __syncthreads();
 
-    // each thread owns 4 pixels of the 32x32 tile: rows (tid>>5) + 8k, column tid&31
-    const int px = tid & 31, py0 = tid >> 5;
+    int cur = 0;
     for (int iter = 0; iter < 64; ++iter) {
+        const int n = cnt[cur];
+        if (n == 0) break;
+        if (tid == 0) cnt[cur ^ 1] = 0;
         float nv[4];
+        int pos[4];
         int changed = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const int py = py0 + 8 * k;
-            const int c = (py + R) * LW + px + R;
-            const float s = t[c];
-            float v = s;
-            if (s > 0.f) {
+            const int i = tid + k * 256;
+            pos[k] = -1;
+            nv[k] = 0.f;
+            if (i < n) {
+                const int c = list[cur][i];
+                const float s = t[c];
                 bool kill = false, blocked = false;
-                for (int dy = -R; dy <= R; ++dy) {
-                    const unsigned rm = fp.rowmask[dy + R];
-                    for (int dx = -R; dx <= R; ++dx) {
-                        if (!((rm >> (dx + R)) & 1u) || (dy == 0 && dx == 0)) continue;
-                        const float nb = t[c + dy * LW + dx];
-                        kill |= nb < 0.f;
-                        const bool earlier = (dy < 0) || (dy == 0 && dx < 0);   // lower flat index
-                        blocked |= (nb > s) || (nb == s && earlier);
+                auto visit = [&](int dy, int dx) {
+                    const float nb = t[c + dy * LW + dx];
+                    kill |= nb < 0.f;
+                    const bool earlier = (dy < 0) || (dy == 0 && dx < 0);       // lower flat index
+                    blocked |= (nb > s) || (nb == s && earlier);
+                };
+                if constexpr (RT > 0) {
+#pragma unroll
+                    for (int dy = -RT; dy <= RT; ++dy) {
+                        const unsigned rm = fp.rowmask[dy + RT];
+#pragma unroll
+                        for (int dx = -RT; dx <= RT; ++dx)
+                            if (((rm >> (dx + RT)) & 1u) && (dy != 0 || dx != 0)) visit(dy, dx);
+                    }
+                } else {
+                    for (int dy = -R; dy <= R; ++dy) {
+                        const unsigned rm = fp.rowmask[dy + R];
+                        for (int dx = -R; dx <= R; ++dx)
+                            if (((rm >> (dx + R)) & 1u) && (dy != 0 || dx != 0)) visit(dy, dx);
                     }
                 }
-                v = kill ? 0.f : (blocked ? s : -s);
-                changed |= (v != s);
+                pos[k] = c;
+                nv[k] = kill ? 0.f : (blocked ? s : -s);
+                changed |= (nv[k] != s);
             }
-            nv[k] = v;
         }
-        const int any = __syncthreads_or(changed);
-        if (!any) break;
+        const int any = __syncthreads_or(changed);          // all reads of t[] done
+        if (!any) break;                                     // nothing can change without new halo data
 #pragma unroll
-        for (int k = 0; k < 4; ++k) t[(py0 + 8 * k + R) * LW + px + R] = nv[k];
+        for (int k = 0; k < 4; ++k)
+            if (pos[k] >= 0) {
+                t[pos[k]] = nv[k];
+                if (nv[k] > 0.f) list[cur ^ 1][atomicAdd(&cnt[cur ^ 1], 1)] = (unsigned short)pos[k];
+            }
         __syncthreads();
+        cur ^= 1;
     }
 
-    int und = 0;
+    // each thread owns 4 pixels of the 32x32 tile: rows (tid>>5) + 8k, column tid&31
+    const int px = tid & 31, py0 = tid >> 5;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int py = py0 + 8 * k;
         const int gy = y0 + py, gx = x0 + px;
-        const float v = t[(py + R) * LW + px + R];
-        if (gy < H && gx < W) {
-            img[(long long)gy * W + gx] = v;
-            und += v > 0.f;
-        }
+        if (gy < H && gx < W) img[(long long)gy * W + gx] = t[(py + R) * LW + px + R];
     }
-    const int tot = __syncthreads_count(und > 0) ? 1 : 0;
-    // count undecided pixels exactly (for the convergence check on the host)
-    __shared__ int s_und;
-    if (tid == 0) s_und = 0;
-    __syncthreads();
-    if (und) atomicAdd(&s_und, und);
-    __syncthreads();
     if (tid == 0) {
-        fout[tile_id] = tot;
-        if (s_und) atomicAdd(&remaining[round], s_und);
+        const int und = cnt[cur];
+        fout[tile_id] = und > 0;
+        if (und) atomicAdd(&remaining[round], und);
     }
 }
 
@@ -148,6 +171,13 @@ void launch_nms_round(float* work, int B, int H, int W, const NmsFootprint& fp, 
     const int ntiles = B * tiles_x * tiles_y;
     if (ntiles <= 0) return;
     int* flags = remaining + 64;
-    hipLaunchKernelGGL(nms_round_kernel, dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
-                       tiles_y, fp, flags, ntiles, remaining, round);
+    if (fp.R == 3)
+        hipLaunchKernelGGL(nms_round_kernel<3>, dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
+                           tiles_y, fp, flags, ntiles, remaining, round);
+    else if (fp.R == 1)
+        hipLaunchKernelGGL(nms_round_kernel<1>, dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
+                           tiles_y, fp, flags, ntiles, remaining, round);
+    else
+        hipLaunchKernelGGL(nms_round_kernel<0>, dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
+                           tiles_y, fp, flags, ntiles, remaining, round);
 }
