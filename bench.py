@@ -40,6 +40,18 @@ def conv_flops_per_image(h, w):
     return sum(2.0 * k * k * ci * co * (h // s) * (w // s) for ci, co, k, s in layers)
 
 
+def pmc_traffic():
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_pmc_hbm_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes of this
+    same bench command); None if the file is absent.  PMC counters cannot be collected from inside the timed run."""
+    path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm_traffic.json')
+    try:
+        with open(path) as f:
+            return float(json.load(f)['dominant_kernel_mean_traffic_bytes_per_launch'])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def make_batch(rank, n_pairs, device):
     """Interleaved batch: image 2p = optical, 2p+1 = thermal of global pair id rank*n_pairs + p."""
     from multipoint_amd.datasets import SyntheticPairs
@@ -50,12 +62,12 @@ def make_batch(rank, n_pairs, device):
     return torch.from_numpy(imgs).to(device)
 
 
-def cpu_baseline(sd, cfg, n_pairs=8):
+def cpu_baseline(sd, cfg, n_pairs=16):
     """The oracle (CPU restatement of the reference path, ATen CPU ops) timed on this box's host cores
     on a bounded sample of the same workload.  A reported baseline, not the optimisation target."""
     from oracle import mp_oracle as O
     from multipoint_amd.datasets import SyntheticPairs
-    torch.set_num_threads(os.cpu_count() or 1)
+    torch.set_num_threads(min(os.cpu_count() or 1, 64))      # more threads only add contention at this size
     pairs = [SyntheticPairs.make_pair(0, p, H, W) for p in range(n_pairs)]
     opt = torch.from_numpy(np.stack([p[0] for p in pairs])); th = torch.from_numpy(np.stack([p[1] for p in pairs]))
     O.process_pairs(sd, cfg, opt[:1], th[:1], nms=PRED_CFG['nms'], detection_threshold=PRED_CFG['detection_threshold'],
@@ -152,20 +164,28 @@ def main():
             dist.destroy_process_group()
         return
 
-    # roofline of the dominant kernel: conv_mfma_kernel<9,32,pool> on encoder conv2 (64->64 @480x640,
-    # 44 % of all FLOPs), timed with hipEvents on the launch stream inside the timed region
+    # roofline of the dominant kernel: conv_mfma_kernel<9,32,true> = the three pooled encoder convolutions
+    # (conv2 64->64 @480x640, conv4 64->64 @240x320, conv6 128->128 @120x160: 59 % of all FLOPs), every
+    # launch timed with hipEvents on the launch stream inside the timed region.  achieved = FLOPs of
+    # these launches / their time; ms_per_launch is the mean over launches (comparable with the
+    # AverageNs of the same kernel in profiles/*kernel_stats.csv).
     by_name = {}
     for name, ms, flop in prof:
         by_name.setdefault(name, []).append((ms, flop))
-    dom = by_name.get('enc.conv2', [])
+    dom_names = ['enc.conv2', 'enc.conv4', 'enc.conv6']
     roof = None
-    if dom:
-        ms = float(np.mean([m for m, _ in dom])); flop = dom[0][1]
-        ach = flop / (ms * 1e-3) / 1e12
+    if all(n in by_name for n in dom_names):
+        ms_all = [m for n in dom_names for m, _ in by_name[n]]
+        fl_all = [f for n in dom_names for _, f in by_name[n]]
+        ach = sum(fl_all) / (sum(ms_all) * 1e-3) / 1e12
+        c2 = float(np.mean([m for m, _ in by_name['enc.conv2']]))
         roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
-                'kernel': 'conv_mfma_kernel<9,32,pool> (encoder conv2 64->64 @480x640 + ReLU/BN/maxpool)',
-                'ms_per_launch': round(ms, 4), 'flop_per_launch': flop}
+                'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(),
+                'kernel': 'conv_mfma_kernel<9,32,true> (3x3 conv + bias/ReLU/BN + 2x2 max-pool; encoder conv2, conv4, conv6)',
+                'launches_per_step': 3, 'ms_per_launch': round(float(np.mean(ms_all)), 4),
+                'flop_per_launch': float(np.mean(fl_all)),
+                'largest_launch': {'layer': 'enc.conv2 64->64 @480x640', 'ms': round(c2, 4),
+                                   'tflops': round(by_name['enc.conv2'][0][1] / (c2 * 1e-3) / 1e12, 2)}}
     conv_ms = sum(float(np.mean([m for m, _ in v])) for k, v in by_name.items())
     conv_flop = sum(v[0][1] for v in by_name.values())
     layers = {k: round(float(np.mean([m for m, _ in v])), 4) for k, v in by_name.items()}

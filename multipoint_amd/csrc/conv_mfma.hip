@@ -10,7 +10,9 @@
 //   A[m][k]  = in[pixel m shifted by tap][cin]      (LDS halo tile, read as ds_read_b128)
 //   B[k][n]  = packed weights, streamed from L2 straight into VGPRs in MFMA-fragment order
 //              (1 KiB fully coalesced global_load_dwordx4 per 32-wide N-block per 8 k)
-//   D        = 32x32 fp32 tiles, 16 VGPRs each: col = lane&31 (channel), row = pixel
+//   D        = 32x32 fp32 tiles, 16 VGPRs each.  The weight fragment is passed as the MFMA *A* operand and
+//              the pixel fragment as *B*, so lane = pixel and each register quad = 4 consecutive channels
+//              (16-byte stores in the epilogue)
 // Workgroup = 256 threads = 4 waves, tile = 256 pixels x 64 channels; wave = 2x2 MFMA tiles
 // (64 accumulator VGPRs).  K is walked in chunks of 32 input channels: per chunk the LDS tile is
 // (tile+halo) x 32 ch = ~48 KiB, so three workgroups share a CU and their load/compute phases
@@ -49,6 +51,9 @@ template <int TAPS, int MBW, bool POOL>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
 {
     using G = Geo<TAPS, MBW>;
+    // SWAP: weights as the MFMA A operand -> lane = pixel, register quad = 4 consecutive channels
+    // (16-byte stores).  The pooled epilogue keeps lane = channel: its 2x2 window is then in-lane.
+    constexpr bool SWAP = !POOL;
     __shared__ __attribute__((aligned(16))) float lds[G::NPIX * PS];
 
     const int tid = threadIdx.x;
@@ -186,103 +191,140 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][0][e], bf[s % RB][0][e], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][0][e], bf[s % RB][1][e], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][1][e], bf[s % RB][0][e], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][1][e], bf[s % RB][1][e], acc[1][1], 0, 0, 0);
+                acc[0][0] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s % RB][0][e], af[s & 1][0][e], acc[0][0], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][0][e], bf[s % RB][0][e], acc[0][0], 0, 0, 0);
+                acc[0][1] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s % RB][1][e], af[s & 1][0][e], acc[0][1], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][0][e], bf[s % RB][1][e], acc[0][1], 0, 0, 0);
+                acc[1][0] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s % RB][0][e], af[s & 1][1][e], acc[1][0], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][1][e], bf[s % RB][0][e], acc[1][0], 0, 0, 0);
+                acc[1][1] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s % RB][1][e], af[s & 1][1][e], acc[1][1], 0, 0, 0)
+                                 : __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][1][e], bf[s % RB][1][e], acc[1][1], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
     }
 
     // ---------------- epilogue: bias -> (ReLU, BN) | (BN, ReLU) -> [2x2 max] -> store --------
-    float bia[2], scl[2], sft[2];
-    int ch[2];
+    if constexpr (POOL) {
+        // lane = channel (li), register r = pixel (r&3) + 8*(r>>2) + 4*half of the M-block
+        float bia[2], scl[2], sft[2];
+        int ch[2];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        ch[nb] = slice * 64 + nb * 32 + li;
-        bia[nb] = p.bias[ch[nb]]; scl[nb] = p.scale[ch[nb]]; sft[nb] = p.shift[ch[nb]];
-    }
-    auto act = [&](float v, int nb) -> float {
-        v += bia[nb];
-        if (p.bn_first) {
-            v = v * scl[nb] + sft[nb];
-            if (p.relu) v = fmaxf(v, 0.f);
-        } else {
-            if (p.relu) v = fmaxf(v, 0.f);
-            v = v * scl[nb] + sft[nb];
+        for (int nb = 0; nb < 2; ++nb) {
+            ch[nb] = slice * 64 + nb * 32 + li;
+            bia[nb] = p.bias[ch[nb]]; scl[nb] = p.scale[ch[nb]]; sft[nb] = p.shift[ch[nb]];
         }
-        return v;
-    };
+        auto act = [&](float v, int nb) -> float {
+            v += bia[nb];
+            if (p.bn_first) {
+                v = v * scl[nb] + sft[nb];
+                if (p.relu) v = fmaxf(v, 0.f);
+            } else {
+                if (p.relu) v = fmaxf(v, 0.f);
+                v = v * scl[nb] + sft[nb];
+            }
+            return v;
+        };
 
-    if constexpr (TAPS == 1) {
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const long long gp = px0 + (2 * wave + mb) * 32 + i;
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-                    if (gp < p.total_px && ch[nb] < p.cout)
-                        p.out[gp * p.out_cstride + p.out_coff + ch[nb]] = act(acc[mb][nb][r], nb);
-            }
-    } else if constexpr (!POOL) {
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int oy = y0 + (2 * wave + mb) * G::MBH + i / MBW;
-                const int ox = x0 + i % MBW;
-                if (oy < p.H && ox < p.W) {
-                    const long long o = (((long long)img * p.H + oy) * p.W + ox) * p.out_cstride + p.out_coff;
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
-                        if (ch[nb] < p.cout) p.out[o + ch[nb]] = act(acc[mb][nb][r], nb);
-                }
-            }
-    } else {
-        const int Ho = p.H >> 1, Wo = p.W >> 1;
-        // partner registers of the 2x2 window: +1 column = r+1; +1 row depends on the M-block shape
-        if constexpr (MBW == 32) {
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int oy = (y0 + 2 * wave) >> 1, ox = (x0 + i) >> 1;
-                if (oy < Ho && ox < Wo) {
-                    const long long o = (((long long)img * Ho + oy) * Wo + ox) * p.out_cstride + p.out_coff;
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb) {
-                        const float v = fmaxf(fmaxf(act(acc[0][nb][r], nb), act(acc[0][nb][r + 1], nb)),
-                                              fmaxf(act(acc[1][nb][r], nb), act(acc[1][nb][r + 1], nb)));
-                        if (ch[nb] < p.cout) p.out[o + ch[nb]] = v;
-                    }
-                }
-            }
-        } else {
-            constexpr int RDOWN = (MBW == 16) ? 8 : 4;      // register holding the pixel one row down
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
+        {
+            const int Ho = p.H >> 1, Wo = p.W >> 1;
+            // partner registers of the 2x2 window: +1 column = r+1; +1 row depends on the M-block shape
+            if constexpr (MBW == 32) {
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
-                    if ((r & RDOWN) != 0) continue;          // only top rows of each 2-row pair
                     const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const int oy = (y0 + (2 * wave + mb) * G::MBH + i / MBW) >> 1;
-                    const int ox = (x0 + i % MBW) >> 1;
+                    const int oy = (y0 + 2 * wave) >> 1, ox = (x0 + i) >> 1;
                     if (oy < Ho && ox < Wo) {
                         const long long o = (((long long)img * Ho + oy) * Wo + ox) * p.out_cstride + p.out_coff;
 #pragma unroll
                         for (int nb = 0; nb < 2; ++nb) {
-                            const float v = fmaxf(
-                                fmaxf(act(acc[mb][nb][r], nb), act(acc[mb][nb][r + 1], nb)),
-                                fmaxf(act(acc[mb][nb][r + RDOWN], nb), act(acc[mb][nb][r + RDOWN + 1], nb)));
+                            const float v = fmaxf(fmaxf(act(acc[0][nb][r], nb), act(acc[0][nb][r + 1], nb)),
+                                                  fmaxf(act(acc[1][nb][r], nb), act(acc[1][nb][r + 1], nb)));
                             if (ch[nb] < p.cout) p.out[o + ch[nb]] = v;
                         }
                     }
                 }
+            } else {
+                constexpr int RDOWN = (MBW == 16) ? 8 : 4;      // register holding the pixel one row down
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        if ((r & RDOWN) != 0) continue;          // only top rows of each 2-row pair
+                        const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
+                        const int oy = (y0 + (2 * wave + mb) * G::MBH + i / MBW) >> 1;
+                        const int ox = (x0 + i % MBW) >> 1;
+                        if (oy < Ho && ox < Wo) {
+                            const long long o = (((long long)img * Ho + oy) * Wo + ox) * p.out_cstride + p.out_coff;
+#pragma unroll
+                            for (int nb = 0; nb < 2; ++nb) {
+                                const float v = fmaxf(
+                                    fmaxf(act(acc[mb][nb][r], nb), act(acc[mb][nb][r + 1], nb)),
+                                    fmaxf(act(acc[mb][nb][r + RDOWN], nb), act(acc[mb][nb][r + RDOWN + 1], nb)));
+                                if (ch[nb] < p.cout) p.out[o + ch[nb]] = v;
+                            }
+                        }
+                    }
+            }
         }
+        return;
     }
+    // non-pooled variants
+    // D layout (weights as the MFMA A operand): lane = pixel (lane&31) of the M-block, register r =
+    // channel (r&3) + 8*(r>>2) + 4*half of the N-block: every register quad is 4 consecutive channels
+    // of one pixel -> one 16-byte store.
+    auto act4 = [&](const f32x16& a, int rg, const f32x4& b4, const f32x4& s4, const f32x4& t4) -> f32x4 {
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = a[rg * 4 + e] + b4[e];
+            if (p.bn_first) {
+                x = x * s4[e] + t4[e];
+                if (p.relu) x = fmaxf(x, 0.f);
+            } else {
+                if (p.relu) x = fmaxf(x, 0.f);
+                x = x * s4[e] + t4[e];
+            }
+            v[e] = x;
+        }
+        return v;
+    };
+    auto store4 = [&](float* dst, int ch0, const f32x4& v) {
+        if (ch0 + 3 < p.cout) {
+            *reinterpret_cast<f32x4*>(dst + ch0) = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (ch0 + e < p.cout) dst[ch0 + e] = v[e];
+        }
+    };
+
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+            const int ch0 = slice * 64 + nb * 32 + rg * 8 + half * 4;
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + ch0);
+            const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.scale + ch0);
+            const f32x4 t4 = *reinterpret_cast<const f32x4*>(p.shift + ch0);
+            if constexpr (TAPS == 1) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const long long gp = px0 + (2 * wave + mb) * 32 + li;
+                    if (gp < p.total_px)
+                        store4(p.out + gp * p.out_cstride + p.out_coff, ch0, act4(acc[mb][nb], rg, b4, s4, t4));
+                }
+            } else if constexpr (!POOL) {
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+                    const int oy = y0 + (2 * wave + mb) * G::MBH + li / MBW;
+                    const int ox = x0 + li % MBW;
+                    if (oy < p.H && ox < p.W)
+                        store4(p.out + (((long long)img * p.H + oy) * p.W + ox) * p.out_cstride + p.out_coff, ch0,
+                               act4(acc[mb][nb], rg, b4, s4, t4));
+                }
+            }
+        }
 }
 
 template <int TAPS, int MBW, bool POOL>
