@@ -145,8 +145,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     bf[1][0] = wp[128]; bf[1][1] = wp[128 + 64];
 #pragma unroll
     for (int j = 0; j < G::NITER; ++j) {
-        stg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (goff[j] >= 0) stg[j] = *reinterpret_cast<const f32x4*>(in_base + goff[j]);
+        stg[j] = *reinterpret_cast<const f32x4*>(in_base + (goff[j] >= 0 ? goff[j] : 0));
     }
     constexpr int S0 = (TAPS == 9) ? 6 : 0;               // first step that issues a staging load
     constexpr int PER_STEP = (TAPS == 9) ? 1 : 2;         // staging loads per step
@@ -156,14 +155,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
 #pragma unroll
         for (int j = 0; j < G::NITER; ++j) {
             const int f = tid + j * 256;
-            if (f < G::NF4)
-                *reinterpret_cast<f32x4*>(&lds[(f >> 3) * PS + (f & 7) * 4]) = stg[j];
+            if (f < G::NF4)      // padding slots (zero pad / beyond the image) are zeroed here, at the consumer
+                *reinterpret_cast<f32x4*>(&lds[(f >> 3) * PS + (f & 7) * 4]) =
+                    (goff[j] >= 0) ? stg[j] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
         __syncthreads();
 
         const f32x4* wc = wp + (long long)c * (G::STEPS * 128);
         const bool more = c + 1 < nchunks;
-        const float* in_next = in_base + (c + 1) * CK;
+        const float* in_next = in_base + (more ? (c + 1) * CK : 0);     // dummy (re-reads chunk 0) on the last chunk
         af[0][0] = *reinterpret_cast<const f32x4*>(&lds[a_base]);
         af[0][1] = *reinterpret_cast<const f32x4*>(&lds[a_base + A_MB]);
 #pragma unroll
@@ -178,14 +178,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
                 af[sn & 1][0] = *reinterpret_cast<const f32x4*>(&lds[a_base + aoff]);
                 af[sn & 1][1] = *reinterpret_cast<const f32x4*>(&lds[a_base + A_MB + aoff]);
             }
-            if (more) {
+            // UNCONDITIONAL loads (dummy address when the slot is padding / there is no next chunk):
+            // a load under a branch makes hipcc's s_waitcnt vmcnt(N) conservative, and every step
+            // of the staging window then waits for the previous step's HBM load.
 #pragma unroll
-                for (int u = 0; u < PER_STEP; ++u) {
-                    const int j = (s - S0) * PER_STEP + u;
-                    if (s >= S0 && j < G::NITER) {
-                        stg[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-                        if (goff[j] >= 0) stg[j] = *reinterpret_cast<const f32x4*>(in_next + goff[j]);
-                    }
+            for (int u = 0; u < PER_STEP; ++u) {
+                const int j = (s - S0) * PER_STEP + u;
+                if (s >= S0 && j < G::NITER) {
+                    stg[j] = *reinterpret_cast<const f32x4*>(in_next + (goff[j] >= 0 ? goff[j] : 0));
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
