@@ -164,28 +164,23 @@ def main():
             dist.destroy_process_group()
         return
 
-    # roofline of the dominant kernel: conv_mfma_kernel<9,32,true> = the three pooled encoder convolutions
-    # (conv2 64->64 @480x640, conv4 64->64 @240x320, conv6 128->128 @120x160: 59 % of all FLOPs), every
-    # launch timed with hipEvents on the launch stream inside the timed region.  achieved = FLOPs of
-    # these launches / their time; ms_per_launch is the mean over launches (comparable with the
-    # AverageNs of the same kernel in profiles/*kernel_stats.csv).
+    # roofline of the dominant kernel: conv_mfma_kernel<9,32,true,true> = encoder conv1 (1->64, computed on the
+    # VALU inside the tile loader) fused into conv2 (64->64 @480x640, MFMA) + bias/ReLU/BN + 2x2 max-pool: one
+    # launch per step, 44 % of all FLOPs and of the time.  Timed with hipEvents on the launch stream inside
+    # the timed region; algorithmic FLOPs = conv1 + conv2 = 2*9*(1*64 + 64*64)*H*W per image.
     by_name = {}
     for name, ms, flop in prof:
         by_name.setdefault(name, []).append((ms, flop))
-    dom_names = ['enc.conv2', 'enc.conv4', 'enc.conv6']
     roof = None
-    if all(n in by_name for n in dom_names):
-        ms_all = [m for n in dom_names for m, _ in by_name[n]]
-        fl_all = [f for n in dom_names for _, f in by_name[n]]
-        ach = sum(fl_all) / (sum(ms_all) * 1e-3) / 1e12
-        c2 = float(np.mean([m for m, _ in by_name['enc.conv2']]))
+    dom = by_name.get('enc.conv1+2') or by_name.get('enc.conv2')
+    if dom:
+        ms = float(np.mean([m for m, _ in dom])); flop = dom[0][1]
+        ach = flop / (ms * 1e-3) / 1e12
         roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(),
-                'kernel': 'conv_mfma_kernel<9,32,true> (3x3 conv + bias/ReLU/BN + 2x2 max-pool; encoder conv2, conv4, conv6)',
-                'launches_per_step': 3, 'ms_per_launch': round(float(np.mean(ms_all)), 4),
-                'flop_per_launch': float(np.mean(fl_all)),
-                'largest_launch': {'layer': 'enc.conv2 64->64 @480x640', 'ms': round(c2, 4),
-                                   'tflops': round(by_name['enc.conv2'][0][1] / (c2 * 1e-3) / 1e12, 2)}}
+                'kernel': 'conv_mfma_kernel<9,32,true,true> (encoder conv1 fused into conv2 64->64 @480x640 + '
+                          'bias/ReLU/BN + 2x2 max-pool)' if 'enc.conv1+2' in by_name else 'conv_mfma_kernel<9,32,true,false> (enc.conv2)',
+                'launches_per_step': 1, 'ms_per_launch': round(ms, 4), 'flop_per_launch': flop}
     conv_ms = sum(float(np.mean([m for m, _ in v])) for k, v in by_name.items())
     conv_flop = sum(v[0][1] for v in by_name.values())
     layers = {k: round(float(np.mean([m for m, _ in v])), 4) for k, v in by_name.items()}

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -56,6 +57,7 @@ struct mp_handle {
     DevBuf ws3;                     // matching arg-min arrays
     DevBuf nms_state;               // 64 round counters + tile flags
     int last_nms_rounds = 0;
+    bool fuse_first = true;         // fuse the Cin=1 block into the second convolution (MP_NO_FUSE=1 disables)
     int* pinned = nullptr;          // small pinned host scratch (img lists, counters)
     bool prof = false;
     std::vector<ProfEntry> prof_entries;
@@ -281,7 +283,8 @@ void prof_end(mp_handle* h, hipStream_t s)
 }
 
 void run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, int in_coff, float* out,
-              int out_cstride, int out_coff, int B, int H, int W, const int* img_list, hipStream_t s)
+              int out_cstride, int out_coff, int B, int H, int W, const int* img_list, hipStream_t s,
+              const FirstLayer* fuse = nullptr, const float* images = nullptr)
 {
     ConvParams p{};
     p.in = in; p.out = out; p.wpack = L.wpack; p.bias = L.bias; p.scale = L.scale; p.shift = L.shift;
@@ -301,8 +304,10 @@ void run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride,
     } else {
         p.total_px = (long long)B * H * W;
     }
-    prof_begin(h, L.name, 2.0 * L.taps * L.cin * L.cout * (double)B * H * W, s);
-    launch_conv_mfma(p, L.taps, mbw, L.pool, s);
+    prof_begin(h, fuse ? "enc.conv1+2" : L.name,
+               2.0 * L.taps * L.cin * L.cout * (double)B * H * W + (fuse ? 2.0 * 9 * 64 * (double)B * H * W : 0.0), s);
+    if (fuse) { p.img = images; p.w1 = fuse->w; p.b1 = fuse->bias; p.s1 = fuse->scale; p.t1 = fuse->shift; }
+    launch_conv_mfma(p, L.taps, mbw, L.pool, fuse != nullptr, s);
     prof_end(h, s);
 }
 
@@ -404,6 +409,7 @@ int mp_create(mp_handle** out, int device)
                                       prop.gcnArchName);
     mp_handle* hh = new mp_handle();
     hh->device = device;
+    { const char* e = getenv("MP_NO_FUSE"); hh->fuse_first = !(e && e[0] == '1'); }
     if (hipHostMalloc(reinterpret_cast<void**>(&hh->pinned), 4096) != hipSuccess) {
         delete hh;
         return fail(h, MP_ENOMEM, "mp_create: hipHostMalloc failed");
@@ -537,15 +543,19 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
         c1.in = images; c1.out = P; c1.w = E.first.w; c1.bias = E.first.bias; c1.scale = E.first.scale;
         c1.shift = E.first.shift; c1.img_list = lptr[e]; c1.B = nb; c1.H = H; c1.W = W;
         c1.pad_zero = h->cfg.reflection_pad ? 0 : 1; c1.bn_first = h->cfg.bn_first;
-        prof_begin(h, "enc.conv1", 2.0 * 9 * 64 * (double)nb * H * W, s);
-        launch_conv_first(c1, s);
-        prof_end(h, s);
+        const bool fuse1 = h->fuse_first;
+        if (!fuse1) {
+            prof_begin(h, "enc.conv1", 2.0 * 9 * 64 * (double)nb * H * W, s);
+            launch_conv_first(c1, s);
+            prof_end(h, s);
+        }
         int hh = H, ww = W;
         float* src = P;
         float* dst = Q;
         for (int i = 0; i < 7; ++i) {
             const ConvLayer& L = E.conv[i];
-            run_conv(h, L, src, L.cin, 0, i == 6 ? X : dst, L.cout, 0, nb, hh, ww, lptr[e], s);
+            run_conv(h, L, src, L.cin, 0, i == 6 ? X : dst, L.cout, 0, nb, hh, ww, lptr[e], s,
+                     (i == 0 && fuse1) ? &E.first : nullptr, images);
             if (L.pool) { hh /= 2; ww /= 2; }
             float* t = src; src = dst; dst = t;
         }

@@ -47,14 +47,24 @@ __device__ __forceinline__ int reflect_clamp(int v, int n)
     return v >= n ? n - 1 : v;              // (only reachable for pixels outside the image tile)
 }
 
-template <int TAPS, int MBW, bool POOL>
+// FUSE1: the input of this convolution is the first encoder block (ReflectionPad -> Conv2d(1,64,3) -> ReLU
+// -> BN, reference encoder modules 0-3) of the image: instead of reading a 64-channel tensor from HBM
+// (78.6 MB written + re-read per 480x640 image) the (tile+halo) x 32-channel chunk is COMPUTED from a
+// (tile + 2-pixel ring) image patch held in LDS, on the VALU, in the shadow of the MFMAs.
+template <int TAPS, int MBW, bool POOL, bool FUSE1>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
 {
     using G = Geo<TAPS, MBW>;
+    static_assert(!FUSE1 || TAPS == 9, "first-layer fusion is a 3x3 feature");
+    constexpr int ITW = G::TW + 4, ITH = G::TH + 4;          // image patch of the fused first layer
+    constexpr int FUSE_FLOATS = FUSE1 ? (ITH * ITW + 9 * 64 + 3 * 64) : 0;
     // SWAP: weights as the MFMA A operand -> lane = pixel, register quad = 4 consecutive channels
     // (16-byte stores).  The pooled epilogue keeps lane = channel: its 2x2 window is then in-lane.
     constexpr bool SWAP = !POOL;
-    __shared__ __attribute__((aligned(16))) float lds[G::NPIX * PS];
+    __shared__ __attribute__((aligned(16))) float lds[G::NPIX * PS + FUSE_FLOATS];
+    float* const w1s = lds + G::NPIX * PS;              // [9][64] first-layer weights (16-byte aligned)
+    float* const p1s = w1s + 9 * 64;                    // bias | scale | shift, 64 each
+    float* const its = p1s + 3 * 64;                    // image patch [ITH][ITW]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -106,7 +116,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
                 } else {
                     gy = reflect_clamp(gy, p.H); gx = reflect_clamp(gx, p.W);
                 }
-                if (!zero) off = (gy * p.W + gx) * p.in_cstride + c4 * 4;
+                if constexpr (FUSE1) {
+                    // centre of the first-layer window inside the image patch (patch origin = tile - 2);
+                    // pixels of partial tiles far outside the image are clamped (their outputs are not stored)
+                    const int qy = min(max(gy, y0 - 1), y0 + G::TH), qx = min(max(gx, x0 - 1), x0 + G::TW);
+                    if (!zero) off = (qy - y0 + 2) * ITW + (qx - x0 + 2);
+                } else {
+                    if (!zero) off = (gy * p.W + gx) * p.in_cstride + c4 * 4;
+                }
             } else {
                 if (px0 + lp < p.total_px) off = lp * p.in_cstride + c4 * 4;
             }
@@ -143,9 +160,58 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     f32x4 af[2][2], bf[RB][2], stg[G::NITER];
     bf[0][0] = wp[0];   bf[0][1] = wp[64];
     bf[1][0] = wp[128]; bf[1][1] = wp[128 + 64];
+
+    // first-layer value of one staging slot: 4 channels (chunk*32 + (tid&7)*4 ..) of the pixel whose
+    // window centre is its[off]; same k-ordered fmaf chain as conv_first_kernel.
+    auto fused_slot = [&](int off, int chunk) -> f32x4 {
+        const int ch = chunk * CK + (tid & 7) * 4;
+        f32x4 a = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < G::NITER; ++j) {
-        stg[j] = *reinterpret_cast<const f32x4*>(in_base + (goff[j] >= 0 ? goff[j] : 0));
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const float x = its[off + (kh - 1) * ITW + (kw - 1)];
+                const f32x4 wv = *reinterpret_cast<const f32x4*>(&w1s[(kh * 3 + kw) * 64 + ch]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) a[e] = fmaf(x, wv[e], a[e]);
+            }
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(&p1s[ch]);
+        const f32x4 s4 = *reinterpret_cast<const f32x4*>(&p1s[64 + ch]);
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(&p1s[128 + ch]);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = a[e] + b4[e];
+            if (p.bn_first) v = fmaxf(v * s4[e] + t4[e], 0.f);
+            else v = fmaxf(v, 0.f) * s4[e] + t4[e];
+            a[e] = v;
+        }
+        return a;
+    };
+
+    if constexpr (FUSE1) {
+        const float* image = p.img + (long long)img * p.H * p.W;
+        for (int f = tid; f < ITH * ITW; f += 256) {
+            const int r = f / ITW, c = f - r * ITW;
+            int gy = y0 - 2 + r, gx = x0 - 2 + c;
+            float v;
+            if (p.pad_zero) {
+                const bool zero = (gy < 0) | (gy >= p.H) | (gx < 0) | (gx >= p.W);
+                gy = min(max(gy, 0), p.H - 1); gx = min(max(gx, 0), p.W - 1);
+                v = zero ? 0.f : image[gy * p.W + gx];
+            } else {
+                v = image[reflect_clamp(gy, p.H) * p.W + reflect_clamp(gx, p.W)];
+            }
+            its[f] = v;
+        }
+        for (int f = tid; f < 9 * 64; f += 256) w1s[f] = p.w1[f];
+        if (tid < 64) { p1s[tid] = p.b1[tid]; p1s[64 + tid] = p.s1[tid]; p1s[128 + tid] = p.t1[tid]; }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < G::NITER; ++j) stg[j] = fused_slot(goff[j] >= 0 ? goff[j] : ITW + 1, 0);
+    } else {
+#pragma unroll
+        for (int j = 0; j < G::NITER; ++j)
+            stg[j] = *reinterpret_cast<const f32x4*>(in_base + (goff[j] >= 0 ? goff[j] : 0));
     }
     constexpr int S0 = (TAPS == 9) ? 6 : 0;               // first step that issues a staging load
     constexpr int PER_STEP = (TAPS == 9) ? 1 : 2;         // staging loads per step
@@ -185,7 +251,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
             for (int u = 0; u < PER_STEP; ++u) {
                 const int j = (s - S0) * PER_STEP + u;
                 if (s >= S0 && j < G::NITER) {
-                    stg[j] = *reinterpret_cast<const f32x4*>(in_next + (goff[j] >= 0 ? goff[j] : 0));
+                    if constexpr (FUSE1) {
+                        if (more) stg[j] = fused_slot(goff[j] >= 0 ? goff[j] : ITW + 1, c + 1);
+                    } else {
+                        stg[j] = *reinterpret_cast<const f32x4*>(in_next + (goff[j] >= 0 ? goff[j] : 0));
+                    }
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -327,7 +397,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
         }
 }
 
-template <int TAPS, int MBW, bool POOL>
+template <int TAPS, int MBW, bool POOL, bool FUSE1>
 void launch_t(const ConvParams& p, hipStream_t s)
 {
     long long ntiles;
@@ -335,15 +405,21 @@ void launch_t(const ConvParams& p, hipStream_t s)
     else ntiles = (p.total_px + 255) / 256;
     const long long nblk = ntiles * p.nslices;
     if (nblk <= 0) return;
-    hipLaunchKernelGGL((conv_mfma_kernel<TAPS, MBW, POOL>), dim3((unsigned)nblk), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<TAPS, MBW, POOL, FUSE1>), dim3((unsigned)nblk), dim3(256), 0, s, p);
 }
 
 }  // namespace
 
-void launch_conv_mfma(const ConvParams& p, int taps, int mbw, bool pool, hipStream_t s)
+void launch_conv_mfma(const ConvParams& p, int taps, int mbw, bool pool, bool fuse1, hipStream_t s)
 {
-    if (taps == 1) { launch_t<1, 32, false>(p, s); return; }
-    if (mbw == 32) { pool ? launch_t<9, 32, true>(p, s) : launch_t<9, 32, false>(p, s); }
-    else if (mbw == 16) { pool ? launch_t<9, 16, true>(p, s) : launch_t<9, 16, false>(p, s); }
-    else { pool ? launch_t<9, 8, true>(p, s) : launch_t<9, 8, false>(p, s); }
+    if (taps == 1) { launch_t<1, 32, false, false>(p, s); return; }
+    if (fuse1) {            // always the pooled second encoder convolution
+        if (mbw == 32) launch_t<9, 32, true, true>(p, s);
+        else if (mbw == 16) launch_t<9, 16, true, true>(p, s);
+        else launch_t<9, 8, true, true>(p, s);
+        return;
+    }
+    if (mbw == 32) { pool ? launch_t<9, 32, true, false>(p, s) : launch_t<9, 32, false, false>(p, s); }
+    else if (mbw == 16) { pool ? launch_t<9, 16, true, false>(p, s) : launch_t<9, 16, false, false>(p, s); }
+    else { pool ? launch_t<9, 8, true, false>(p, s) : launch_t<9, 8, false, false>(p, s); }
 }

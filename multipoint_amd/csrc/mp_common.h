@@ -24,6 +24,9 @@ struct ConvParams {
     const float* scale;   // [nslices*64] BN scale  s = gamma / sqrt(var + eps)
     const float* shift;   // [nslices*64] BN shift  t = beta - mean * s
     const int* img_list;  // optional: image ids this launch processes (nullptr = 0..B-1)
+    // fused first encoder block (FUSE1 variants): the image and the Cin=1 layer's parameters
+    const float* img;     // [B][H][W]
+    const float *w1, *b1, *s1, *t1;   // [9][64] tap-major weights, bias, BN scale, BN shift
     int B, H, W;          // conv input == conv output spatial size (stride 1, 'same' padding)
     int in_cstride, in_coff, cin;
     int out_cstride, out_coff, cout;
@@ -46,7 +49,7 @@ struct Conv1Params {
     int pad_zero, bn_first;
 };
 
-void launch_conv_mfma(const ConvParams& p, int taps, int mbw, bool pool, hipStream_t s);
+void launch_conv_mfma(const ConvParams& p, int taps, int mbw, bool pool, bool fuse1, hipStream_t s);
 void launch_conv_first(const Conv1Params& p, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
