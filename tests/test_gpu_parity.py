@@ -36,7 +36,8 @@ def shipped(oracle):
 
 
 # ------------------------------------------------------------------------------------------ forward
-@pytest.mark.parametrize('B,H,W', [(2, 64, 64), (1, 240, 320), (3, 72, 104), (1, 16, 16), (2, 480, 640), (5, 40, 264)])
+@pytest.mark.parametrize('B,H,W', [(2, 64, 64), (1, 240, 320), (3, 72, 104), (1, 16, 16), (2, 480, 640), (5, 40, 264),
+                                   (1, 1024, 1280), (2, 24, 2048), (1, 1032, 16)])
 def test_forward_matches_oracle(oracle, shipped, B, H, W):
     net, sd = shipped
     img = oracle.make_images(100 + H, B, H, W)
