@@ -47,6 +47,12 @@ typedef struct mp_model_config {
     int bn_first;               /* MultiPoint.py:137-141 */
     int double_convolution;     /* must be 1 */
     int channel_version;        /* must be 0: channels [1,64,64,128,128], heads 256 */
+    /* model.type 'SuperPointMagicLeap' (multipoint/models/SuperPointMagicLeap.py): same layer shapes, no
+     * BatchNorm, zero padding, state_dict keys conv1a..conv4b / convPa,convPb / convDa,convDb, heat map =
+     * exp(x) / (sum exp(x) + 1e-5) without max subtraction (generate_heatmap, :68-85). */
+    int batchnorm;              /* 1: BatchNorm2d after every 3x3 conv (MultiPoint), 0: none (MagicLeap) */
+    int key_layout;             /* 0: MultiPoint nn.Sequential keys, 1: SuperPointMagicLeap keys */
+    int softmax_mode;           /* 0: nn.Softmax2d, 1: MagicLeap generate_heatmap arithmetic */
 } mp_model_config;
 
 /* one entry of the reference state_dict (torch.save(net.state_dict()), train.py:161-173), host fp32 */

@@ -19,7 +19,8 @@ c_void_p, c_int, c_float, c_ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, 
 class ModelConfig(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ('multispectral', 'descriptor_head', 'descriptor_size',
                                      'normalize_descriptors', 'final_batchnorm', 'reflection_pad',
-                                     'bn_first', 'double_convolution', 'channel_version')]
+                                     'bn_first', 'double_convolution', 'channel_version', 'batchnorm',
+                                     'key_layout', 'softmax_mode')]
 
 
 class Tensor(ctypes.Structure):

@@ -218,22 +218,29 @@ const char* kEncNames[7] = {"enc.conv2", "enc.conv3", "enc.conv4", "enc.conv5", 
 
 int build_encoder(mp_handle* h, TensorMap& tm, Encoder& E, const std::string& prefix)
 {
-    // generate_encoder (MultiPoint.py:168-185): Sequential indices, 4 modules per conv block
+    // MultiPoint: generate_encoder (MultiPoint.py:168-185): Sequential indices, 4 modules per conv block
     // (pad, conv, X, Y) and one MaxPool2d after blocks 2, 4, 6.
+    // SuperPointMagicLeap (SuperPointMagicLeap.py:16-23): named convolutions, no BatchNorm.
     static const int conv_idx[8] = {1, 5, 10, 14, 19, 23, 28, 32};
+    static const char* ml_names[8] = {"conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b"};
     static const int chan[9] = {1, 64, 64, 64, 64, 128, 128, 128, 128};
     static const bool pool[8] = {false, true, false, true, false, true, false, false};
     const int bn_off = h->cfg.bn_first ? 1 : 2;
+    auto conv_key = [&](int i) {
+        return h->cfg.key_layout == 1 ? std::string(ml_names[i]) : prefix + "." + std::to_string(conv_idx[i]);
+    };
+    auto bn_key = [&](int i) {
+        return h->cfg.batchnorm ? prefix + "." + std::to_string(conv_idx[i] + bn_off) : std::string();
+    };
     std::string err;
     {   // first layer (Cin = 1): [tap][cout]
-        const std::string ck = prefix + "." + std::to_string(conv_idx[0]);
-        const std::string bk = prefix + "." + std::to_string(conv_idx[0] + bn_off);
+        const std::string ck = conv_key(0), bk = bn_key(0);
         const float* w = tm.get(ck + ".weight", 64 * 9, err); if (!w) return fail(h, MP_EINVAL, err);
         const float* b = tm.get(ck + ".bias", 64, err); if (!b) return fail(h, MP_EINVAL, err);
-        std::vector<float> wt(9 * 64), bias(b, b + 64), s, t;
+        std::vector<float> wt(9 * 64), bias(b, b + 64), s(64, 1.f), t(64, 0.f);
         for (int co = 0; co < 64; ++co)
             for (int k = 0; k < 9; ++k) wt[k * 64 + co] = w[co * 9 + k];
-        if (!bn_terms(tm, bk, 64, 64, s, t, err)) return fail(h, MP_EINVAL, err);
+        if (!bk.empty() && !bn_terms(tm, bk, 64, 64, s, t, err)) return fail(h, MP_EINVAL, err);
         int rc;
         if ((rc = upload(h, wt, &E.first.w))) return rc;
         if ((rc = upload(h, bias, &E.first.bias))) return rc;
@@ -241,9 +248,7 @@ int build_encoder(mp_handle* h, TensorMap& tm, Encoder& E, const std::string& pr
         if ((rc = upload(h, t, &E.first.shift))) return rc;
     }
     for (int i = 1; i < 8; ++i) {
-        const std::string ck = prefix + "." + std::to_string(conv_idx[i]);
-        const std::string bk = prefix + "." + std::to_string(conv_idx[i] + bn_off);
-        int rc = build_conv(h, tm, E.conv[i - 1], kEncNames[i - 1], {ck}, {bk}, {chan[i + 1]}, chan[i], 9,
+        int rc = build_conv(h, tm, E.conv[i - 1], kEncNames[i - 1], {conv_key(i)}, {bn_key(i)}, {chan[i + 1]}, chan[i], 9,
                             pool[i], true);
         if (rc) return rc;
     }
@@ -454,28 +459,34 @@ int mp_load_weights(mp_handle* h, const mp_model_config* cfg, const mp_tensor* t
         tm.m[tensors[i].name] = &tensors[i];
     }
     int rc;
+    if (cfg->key_layout == 1 && (cfg->multispectral || cfg->batchnorm || cfg->final_batchnorm))
+        return fail(h, MP_EINVAL, "unsupported model config: SuperPointMagicLeap key layout has one encoder and no BatchNorm");
+    if (!cfg->batchnorm && cfg->key_layout == 0)
+        return fail(h, MP_EINVAL, "unsupported model config: MultiPoint key layout always has BatchNorm2d");
     if (cfg->multispectral) {
         if ((rc = build_encoder(h, tm, h->enc[0], "encoder_thermal"))) return rc;
         if ((rc = build_encoder(h, tm, h->enc[1], "encoder_optical"))) return rc;
     } else {
         if ((rc = build_encoder(h, tm, h->enc[0], "encoder"))) return rc;
     }
+    // head key names: MultiPoint nn.Sequential (MultiPoint.py:62-88) or SuperPointMagicLeap (:25-29)
+    const bool ml = cfg->key_layout == 1;
     const std::string det = "detector_head_convolutions", dsc = "descriptor_head_convolutions";
     const std::string bn3 = cfg->bn_first ? ".2" : ".3";
+    const std::string det3 = ml ? "convPa" : det + ".1", dsc3 = ml ? "convDa" : dsc + ".1";
+    const std::string det1k = ml ? "convPb" : det + ".4", dsc1k = ml ? "convDb" : dsc + ".4";
+    const std::string det3bn = cfg->batchnorm ? det + bn3 : std::string(), dsc3bn = cfg->batchnorm ? dsc + bn3 : std::string();
+    const std::string det1bn = cfg->final_batchnorm ? det + ".5" : std::string();
+    const std::string dsc1bn = cfg->final_batchnorm ? dsc + ".5" : std::string();
     // both 3x3 head convs read the same encoder output: one launch with N = 256 (+256)
     if (cfg->descriptor_head)
-        rc = build_conv(h, tm, h->heads3, "heads.conv3x3", {det + ".1", dsc + ".1"}, {det + bn3, dsc + bn3},
-                        {256, 256}, 128, 9, false, true);
+        rc = build_conv(h, tm, h->heads3, "heads.conv3x3", {det3, dsc3}, {det3bn, dsc3bn}, {256, 256}, 128, 9, false, true);
     else
-        rc = build_conv(h, tm, h->heads3, "heads.conv3x3", {det + ".1"}, {det + bn3}, {256}, 128, 9, false, true);
+        rc = build_conv(h, tm, h->heads3, "heads.conv3x3", {det3}, {det3bn}, {256}, 128, 9, false, true);
     if (rc) return rc;
-    if ((rc = build_conv(h, tm, h->det1, "det.conv1x1", {det + ".4"},
-                         {cfg->final_batchnorm ? det + ".5" : std::string()}, {65}, 256, 1, false, false)))
-        return rc;
+    if ((rc = build_conv(h, tm, h->det1, "det.conv1x1", {det1k}, {det1bn}, {65}, 256, 1, false, false))) return rc;
     if (cfg->descriptor_head &&
-        (rc = build_conv(h, tm, h->desc1, "desc.conv1x1", {dsc + ".4"},
-                         {cfg->final_batchnorm ? dsc + ".5" : std::string()}, {cfg->descriptor_size}, 256, 1,
-                         false, false)))
+        (rc = build_conv(h, tm, h->desc1, "desc.conv1x1", {dsc1k}, {dsc1bn}, {cfg->descriptor_size}, 256, 1, false, false)))
         return rc;
     // strict=True semantics of load_state_dict: no unexpected keys
     for (auto& kv : tm.m)
@@ -565,7 +576,7 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
     run_conv(h, h->det1, P, headc, 0, Lg, 80, 0, B, Hc, Wc, nullptr, s);
     if (prob || logits) {
         prof_begin(h, "det.softmax_shuffle", 0.0, s);
-        launch_det_post(Lg, 80, B, Hc, Wc, prob, logits, s);
+        launch_det_post(Lg, 80, B, Hc, Wc, prob, logits, h->cfg.softmax_mode, s);
         prof_end(h, s);
     }
     if (desc) {

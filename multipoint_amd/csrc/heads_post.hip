@@ -13,7 +13,7 @@ namespace {
 // block; registers i = 0..7 hold channel 8i+j.  For a fixed i the wave writes 64 contiguous floats.
 __global__ __launch_bounds__(256) void det_post_kernel(const float* __restrict__ logits, int lstride,
                                                       int B, int Hc, int Wc, float* __restrict__ prob,
-                                                      float* __restrict__ logits_nchw)
+                                                      float* __restrict__ logits_nchw, int mode)
 {
     const int lane = threadIdx.x & 63;
     const int groups_x = (Wc + 7) >> 3;
@@ -43,15 +43,21 @@ __global__ __launch_bounds__(256) void det_post_kernel(const float* __restrict__
     }
     if (!prob) return;
 
-    float m = d;
+    // mode 0: nn.Softmax2d (max-subtracted); mode 1: SuperPointMagicLeap.generate_heatmap
+    // (multipoint/models/SuperPointMagicLeap.py:72-73): exp(x) / (sum(exp(x)) + 1e-5), no max subtraction
+    float m = 0.f;
+    if (mode == 0) {
+        m = d;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) m = fmaxf(m, v[i]);
-    m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
+        for (int i = 0; i < 8; ++i) m = fmaxf(m, v[i]);
+        m = fmaxf(m, __shfl_xor(m, 1)); m = fmaxf(m, __shfl_xor(m, 2)); m = fmaxf(m, __shfl_xor(m, 4));
+    }
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) { v[i] = expf(v[i] - m); s += v[i]; }
     s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4);
     s += expf(d - m);
+    if (mode == 1) s += 0.00001f;
 
     const int H = Hc * 8, W = Wc * 8;
     if (valid) {
@@ -87,12 +93,12 @@ __global__ __launch_bounds__(256) void desc_l2norm_kernel(const float* __restric
 }  // namespace
 
 void launch_det_post(const float* logits, int lstride, int B, int Hc, int Wc, float* prob,
-                     float* logits_nchw, hipStream_t s)
+                     float* logits_nchw, int mode, hipStream_t s)
 {
     const long long waves = (long long)B * Hc * ((Wc + 7) / 8);
     if (waves <= 0) return;
     hipLaunchKernelGGL(det_post_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, logits,
-                       lstride, B, Hc, Wc, prob, logits_nchw);
+                       lstride, B, Hc, Wc, prob, logits_nchw, mode);
 }
 
 void launch_desc_l2norm(const float* raw, float* out, long long npx, int D, int normalize,

@@ -58,7 +58,7 @@ void launch_conv_first(const Conv1Params& p, hipStream_t s);
 // logits [B*Hc*Wc][lstride] (65 valid) -> prob [B][Hc*8][Wc*8]  (softmax over 65, drop dustbin,
 // depth-to-space 8) and/or logits_nchw [B][65][Hc][Wc]
 void launch_det_post(const float* logits, int lstride, int B, int Hc, int Wc, float* prob,
-                     float* logits_nchw, hipStream_t s);
+                     float* logits_nchw, int mode, hipStream_t s);
 // raw [npx][D] -> out [npx][D] rows divided by max(||row||, 1e-12)   (D multiple of 4, <= 1024)
 void launch_desc_l2norm(const float* raw, float* out, long long npx, int D, int normalize,
                         hipStream_t s);

@@ -113,7 +113,7 @@ class MultiPoint:
                 continue
             new_state[k] = v.detach().to('cpu', dtype).contiguous().clone()
         if errors:
-            raise RuntimeError('Error(s) in loading state_dict for MultiPoint:\n\t' + '\n\t'.join(errors))
+            raise RuntimeError('Error(s) in loading state_dict for %s:\n\t' % type(self).__name__ + '\n\t'.join(errors))
         if strict or all(k in new_state for k in expected):
             self._state = collections.OrderedDict((k, new_state[k]) for k in expected)
             self._uploaded = False
@@ -177,12 +177,16 @@ class MultiPoint:
             raise ValueError('set_force_return_logits: The input value needs to be a bool')
         self.config['force_return_logits'] = value
 
+    # extra mp_model_config fields of this model class (include/multipoint_hip.h)
+    _abi_extra = {'batchnorm': 1, 'key_layout': 0, 'softmax_mode': 0}
+
     def _upload(self):
         c = self.config
-        cfg = _lib.ModelConfig(*(int(bool(c[k])) if k not in ('descriptor_size', 'channel_version') else int(c[k])
-                                 for k in ('multispectral', 'descriptor_head', 'descriptor_size',
-                                           'normalize_descriptors', 'final_batchnorm', 'reflection_pad',
-                                           'bn_first', 'double_convolution', 'channel_version')))
+        vals = [int(c[k]) if k in ('descriptor_size', 'channel_version') else int(bool(c[k]))
+                for k in ('multispectral', 'descriptor_head', 'descriptor_size', 'normalize_descriptors',
+                          'final_batchnorm', 'reflection_pad', 'bn_first', 'double_convolution', 'channel_version')]
+        vals += [self._abi_extra['batchnorm'], self._abi_extra['key_layout'], self._abi_extra['softmax_mode']]
+        cfg = _lib.ModelConfig(*vals)
         keep = []
         arr = []
         for k, v in self._state.items():

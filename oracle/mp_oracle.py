@@ -280,6 +280,54 @@ def forward(sd, image, cfg=None, is_optical=None, return_logits=False):
 
 
 # --------------------------------------------------------------------------------------------
+# SuperPointMagicLeap (multipoint/models/SuperPointMagicLeap.py)
+# --------------------------------------------------------------------------------------------
+MAGICLEAP_LAYERS = (('conv1a', 64, 1, 3), ('conv1b', 64, 64, 3), ('conv2a', 64, 64, 3), ('conv2b', 64, 64, 3),
+                    ('conv3a', 128, 64, 3), ('conv3b', 128, 128, 3), ('conv4a', 128, 128, 3), ('conv4b', 128, 128, 3),
+                    ('convPa', 256, 128, 3), ('convPb', 65, 256, 1), ('convDa', 256, 128, 3), ('convDb', 256, 256, 1))
+
+
+def make_weights_magicleap(seed=0):
+    """Seeded synthetic SuperPointMagicLeap state_dict (SuperPointMagicLeap.py:16-29 key layout)."""
+    rng = np.random.default_rng(seed)
+    sd = collections.OrderedDict()
+    for name, co, ci, k in MAGICLEAP_LAYERS:
+        b = np.sqrt(6.0 / (ci * k * k))
+        sd[name + '.weight'] = torch.from_numpy(rng.uniform(-b, b, size=(co, ci, k, k)).astype(np.float32))
+        sd[name + '.bias'] = torch.from_numpy(rng.normal(0.0, 0.05, size=(co,)).astype(np.float32))
+    sd['convPb.weight'] = sd['convPb.weight'] * 6.0           # sharper detector, dustbin dominant
+    bias = sd['convPb.bias'].clone(); bias[64] = 6.0; sd['convPb.bias'] = bias
+    return sd
+
+
+def forward_magicleap(sd, image):
+    """SuperPointMagicLeap.forward (:31-66) + generate_heatmap (:68-85).  image (B,1,H,W) fp32."""
+    with torch.no_grad():
+        def cv(x, n, relu=True):
+            k = sd[n + '.weight'].shape[-1]
+            y = F.conv2d(x, sd[n + '.weight'], sd[n + '.bias'], padding=k // 2)
+            return F.relu(y) if relu else y
+        x = cv(cv(image, 'conv1a'), 'conv1b'); x = F.max_pool2d(x, 2, 2)
+        x = cv(cv(x, 'conv2a'), 'conv2b'); x = F.max_pool2d(x, 2, 2)
+        x = cv(cv(x, 'conv3a'), 'conv3b'); x = F.max_pool2d(x, 2, 2)
+        x = cv(cv(x, 'conv4a'), 'conv4b')
+        semi = cv(cv(x, 'convPa'), 'convPb', relu=False)
+        desc = cv(cv(x, 'convDa'), 'convDb', relu=False)
+        dn = torch.norm(desc, p=2, dim=1)
+        desc = desc.div(torch.unsqueeze(dn, 1))
+        # generate_heatmap: numpy, float32, no max subtraction
+        out = torch.zeros(image.shape)
+        for i, sample in enumerate(semi):
+            dense = np.exp(sample.numpy())
+            dense = dense / (np.sum(dense, axis=0) + .00001)
+            nodust = dense[:-1].transpose(1, 2, 0)
+            Hc, Wc = image.shape[-2] // 8, image.shape[-1] // 8
+            hm = np.reshape(nodust, [Hc, Wc, 8, 8]).transpose(0, 2, 1, 3).reshape(Hc * 8, Wc * 8)
+            out[i, 0] = torch.from_numpy(hm)
+        return {'logits': semi, 'desc': desc, 'prob': out}
+
+
+# --------------------------------------------------------------------------------------------
 # box NMS (multipoint/utils/utils.py:78-122 around torchvision nms)
 # --------------------------------------------------------------------------------------------
 _nms_lib = None

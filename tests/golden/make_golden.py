@@ -6,6 +6,7 @@ Fixtures are data (inputs + the reference's outputs), never reference source:
   forward_64x64.npz      full prob/desc of MultiPoint.forward on a 2x1x64x64 batch (shipped params.yaml)
   forward_240x320.npz    512 sampled (index, value) pairs of prob/desc + fp64 checksums (BASELINE configs[0] shape)
   forward_variants.npz   multispectral / zero-pad / bn_first / descriptor_size 256 variants at 32x48
+  forward_magicleap.npz  SuperPointMagicLeap.forward (logits, desc, heat map) at 2x1x32x48
   sampling.npz           utils.interpolate_descriptors(kp, desc, H, W) rows
   matcher.npz            NNMatcher(0.7).match(d1, d2) (query, train, distance) lists
   depth_to_space.npz     utils.depth_to_space / space_to_depth
@@ -74,6 +75,17 @@ def main():
         lo = net({'image': O.make_images(13, 3, 32, 48)})
     variants['logits'] = lo['logits'].numpy()
     np.savez_compressed(os.path.join(HERE, 'forward_variants.npz'), weight_seed=3, image_seed=13, **variants)
+
+    # SuperPointMagicLeap (second model.type of the reference)
+    ml = models.SuperPointMagicLeap().eval()
+    msd = O.make_weights_magicleap(4)
+    assert list(ml.state_dict().keys()) == list(msd.keys())
+    ml.load_state_dict(msd)
+    im = O.make_images(14, 2, 32, 48)
+    with torch.no_grad():
+        mo = ml({'image': im})
+    np.savez_compressed(os.path.join(HERE, 'forward_magicleap.npz'), weight_seed=4, image_seed=14,
+                        logits=mo['logits'].numpy(), desc=mo['desc'].numpy(), prob=mo['prob'].numpy())
 
     # sampling: keypoints incl. borders / corners
     rng = np.random.default_rng(5)

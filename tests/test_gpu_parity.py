@@ -92,6 +92,27 @@ def test_force_return_logits(oracle, shipped, golden_dir):
     assert np.abs(out['logits'].cpu().numpy() - g['logits']).max() <= 1e-4
 
 
+def test_superpoint_magicleap_model(oracle, golden_dir):
+    """model.type 'SuperPointMagicLeap' (zero pad, no BatchNorm, D = 256, exp/(sum+1e-5) heat map) against the
+    reference's own output and the oracle at a larger size."""
+    import multipoint_amd.models as M
+    g = np.load(os.path.join(golden_dir, 'forward_magicleap.npz'))
+    sd = oracle.make_weights_magicleap(int(g['weight_seed']))
+    net = M.SuperPointMagicLeap(); net.load_state_dict(sd); net.to('cuda'); net.eval()
+    out = net({'image': oracle.make_images(int(g['image_seed']), 2, 32, 48).cuda()})
+    assert set(out) == {'logits', 'desc', 'prob'}
+    assert np.abs(out['logits'].cpu().numpy() - g['logits']).max() <= 1e-4
+    assert np.abs(out['desc'].cpu().numpy() - g['desc']).max() <= DESC_TOL
+    assert np.abs(out['prob'].cpu().numpy() - g['prob']).max() <= PROB_TOL
+    img = oracle.make_images(3, 2, 240, 320)
+    ref = oracle.forward_magicleap(sd, img)
+    out = net({'image': img.cuda()})
+    assert (out['prob'].cpu() - ref['prob']).abs().max().item() <= PROB_TOL
+    assert (out['desc'].cpu() - ref['desc']).abs().max().item() <= DESC_TOL
+    with pytest.raises(RuntimeError, match='Missing key'):
+        M.SuperPointMagicLeap().load_state_dict({k: v for k, v in sd.items() if k != 'convDb.bias'})
+
+
 def test_forward_errors(oracle, shipped):
     net, _ = shipped
     with pytest.raises(ValueError, match='divisible by 8'):
@@ -160,6 +181,25 @@ def test_box_nms_edge_cases(oracle, U):
         U.box_nms(torch.rand(16, 24, device='cuda'), 40, 0.015)               # footprint radius unsupported
     m = U.extract_keypoints(torch.from_numpy(ramp).cuda(), 0.5)
     assert np.array_equal(m[0][0, :int(m[2][0])].cpu().numpy(), np.argwhere(ramp > 0.5))
+
+
+def test_box_nms_async_rounds_and_overflow(oracle, U):
+    """The pipeline enqueues a fixed number of fixed-point rounds without synchronising; convergence is
+    checked afterwards.  A monotone ramp forces a dependency chain across many 32x32 tiles."""
+    ramp = np.linspace(0.02, 0.9, 64 * 640, dtype=np.float32).reshape(1, 1, 64, 640)
+    t = torch.from_numpy(ramp).cuda()
+    kp, sc, cnt = U.detect_keypoints(t, 4, 0.015, keep_top_k=0, capacity=4096, max_rounds=1)
+    assert U.nms_unresolved() > 0                              # one round is not enough for this input
+    kp, sc, cnt = U.detect_keypoints(t, 4, 0.015, keep_top_k=0, capacity=4096, max_rounds=64)
+    assert U.nms_unresolved() == 0
+    ref = oracle.keypoints_from_map(oracle.box_nms(ramp[0, 0], 4, 0.015), 0.015)
+    assert int(cnt[0]) == len(ref) and np.array_equal(kp[0, :len(ref)].cpu().numpy(), ref)
+    # capacity overflow with keep_top_k == 0: the count reports all survivors, the list holds the first K
+    kp2, sc2, cnt2 = U.detect_keypoints(t, 4, 0.015, keep_top_k=0, capacity=16)
+    assert int(cnt2[0]) == len(ref) and np.array_equal(kp2[0].cpu().numpy(), ref[:16])
+    # top-k larger than the number of survivors
+    kp3, sc3, cnt3 = U.detect_keypoints(t, 4, 0.015, keep_top_k=100000, capacity=8192)
+    assert int(cnt3[0]) == len(ref)
 
 
 # ------------------------------------------------------------------------------- sampling / matching

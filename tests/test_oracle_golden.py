@@ -83,3 +83,12 @@ def test_depth_to_space(oracle, golden_dir):
     x = torch.from_numpy(g['x'])
     assert np.array_equal(oracle.depth_to_space(x, 8).numpy(), g['d2s'])
     assert np.array_equal(g['s2d'], g['x'])
+
+
+def test_forward_magicleap(oracle, golden_dir):
+    g = _load(golden_dir, 'forward_magicleap.npz')
+    sd = oracle.make_weights_magicleap(int(g['weight_seed']))
+    out = oracle.forward_magicleap(sd, oracle.make_images(int(g['image_seed']), 2, 32, 48))
+    assert np.abs(out['logits'].numpy() - g['logits']).max() <= 1e-5
+    assert np.abs(out['desc'].numpy() - g['desc']).max() <= 1e-6
+    assert np.abs(out['prob'].numpy() - g['prob']).max() <= 1e-6

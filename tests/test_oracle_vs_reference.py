@@ -91,3 +91,19 @@ def test_product_host_helpers_match_reference(ref):
         theirs = models.MultiPoint(dict(cfg)).state_dict()
         assert [k for k, _, _ in ours] == list(theirs.keys())
         assert all(tuple(theirs[k].shape) == tuple(s) for k, s, _ in ours)
+
+
+def test_magicleap_vs_reference(oracle, ref):
+    models, utils = ref
+    net = models.SuperPointMagicLeap().eval()
+    sd = oracle.make_weights_magicleap(8)
+    assert list(net.state_dict().keys()) == list(sd.keys())
+    net.load_state_dict(sd)
+    img = oracle.make_images(9, 2, 64, 96)
+    with torch.no_grad():
+        r = net({'image': img})
+    o = oracle.forward_magicleap(sd, img)
+    for k in ('logits', 'desc', 'prob'):
+        assert (r[k] - o[k]).abs().max().item() <= 1e-6
+    import multipoint_amd.models as M
+    assert [k for k, _, _ in M.SuperPointMagicLeap().state_dict_spec()] == list(sd.keys())
