@@ -154,6 +154,7 @@ def main():
     metrics = None
     if not args.forward_only:
         pipe.check_converged(device)
+        res.wait()
         rec = torch.stack([torch.arange(P, device=device, dtype=torch.int32) + rank * P,
                            res.kp_count[0::2].clamp(max=res.kp_yx.shape[1]),
                            res.kp_count[1::2].clamp(max=res.kp_yx.shape[1]), res.match_count], dim=1)

@@ -101,8 +101,8 @@ int mp_detect_keypoints(mp_handle* h, const float* prob, const unsigned char* va
                         int W, float size, float min_prob, float iou, int keep_top_k, int K,
                         int* kp_yx, float* kp_score, int* kp_count, int max_rounds, void* stream);
 
-/* number of still-undecided NMS candidates of the last mp_box_nms / mp_detect_keypoints call
- * (0 = exact result).  Synchronises `stream`. */
+/* number of still-undecided NMS candidates summed over all mp_box_nms / mp_detect_keypoints calls since
+ * the previous mp_nms_unresolved (0 = every result exact); resets the counter.  Synchronises `stream`. */
 int mp_nms_unresolved(mp_handle* h, int* unresolved, void* stream);
 
 /* replaces torch.nonzero(map > thr) on an arbitrary dense map. */

@@ -56,6 +56,7 @@ struct mp_handle {
     DevBuf ws2;                     // NMS work map + kept lists
     DevBuf ws3;                     // matching arg-min arrays
     DevBuf nms_state;               // 64 round counters + tile flags
+    int* nms_total = nullptr;       // device: undecided candidates summed over all calls since the last read
     int last_nms_rounds = 0;
     bool fuse_first = true;         // fuse the Cin=1 block into the second convolution (MP_NO_FUSE=1 disables)
     int* pinned = nullptr;          // small pinned host scratch (img lists, counters)
@@ -376,6 +377,11 @@ int nms_common(mp_handle* h, const float* prob, const unsigned char* mask, int B
         if (h->pinned[0] == 0) break;
     }
     h->last_nms_rounds = round;
+    if (!h->nms_total) {
+        MP_HIP(hipMalloc(reinterpret_cast<void**>(&h->nms_total), 4));
+        MP_HIP(hipMemsetAsync(h->nms_total, 0, 4, s));
+    }
+    launch_nms_accumulate(remaining + (round - 1), h->nms_total, s);
     launch_select_keypoints(work, B, H, W, topk, K, list_idx, list_score, H * W, kp_yx, kp_score, kp_count,
                             prob_nms, s);
     MP_HIP(hipGetLastError());
@@ -432,6 +438,7 @@ void mp_destroy(mp_handle* h)
     if (h->ws2.p) (void)hipFree(h->ws2.p);
     if (h->ws3.p) (void)hipFree(h->ws3.p);
     if (h->nms_state.p) (void)hipFree(h->nms_state.p);
+    if (h->nms_total) (void)hipFree(h->nms_total);
     if (h->pinned) (void)hipHostFree(h->pinned);
     for (auto& e : h->prof_entries) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     delete h;
@@ -616,9 +623,9 @@ int mp_nms_unresolved(mp_handle* h, int* unresolved, void* stream)
     if (!h || !unresolved) return MP_EINVAL;
     hipStream_t s = static_cast<hipStream_t>(stream);
     *unresolved = 0;
-    if (h->last_nms_rounds <= 0 || !h->nms_state.p) return MP_OK;
-    const int* remaining = static_cast<const int*>(h->nms_state.p);
-    MP_HIP(hipMemcpyAsync(h->pinned, remaining + (h->last_nms_rounds - 1), 4, hipMemcpyDeviceToHost, s));
+    if (!h->nms_total) return MP_OK;
+    MP_HIP(hipMemcpyAsync(h->pinned, h->nms_total, 4, hipMemcpyDeviceToHost, s));
+    MP_HIP(hipMemsetAsync(h->nms_total, 0, 4, s));
     MP_HIP(hipStreamSynchronize(s));
     *unresolved = h->pinned[0];
     return MP_OK;

@@ -152,7 +152,18 @@ __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work
     }
 }
 
+__global__ void nms_accumulate_kernel(const int* __restrict__ remaining_last, int* __restrict__ total)
+{
+    if (threadIdx.x == 0 && *remaining_last) atomicAdd(total, *remaining_last);
+}
+
 }  // namespace
+
+// adds the undecided count of the final round to a persistent counter (read + reset by mp_nms_unresolved)
+void launch_nms_accumulate(const int* remaining_last, int* total, hipStream_t s)
+{
+    hipLaunchKernelGGL(nms_accumulate_kernel, dim3(1), dim3(64), 0, s, remaining_last, total);
+}
 
 void launch_nms_init(const float* prob, const uint8_t* mask, float min_prob, float* work,
                      long long n, hipStream_t s)

@@ -19,6 +19,13 @@ class PairResults:
         self.desc = desc
         self.match_idx, self.match_dist, self.match_count = match_idx, match_dist, match_count
         self.H, self.W = H, W
+        self.done = None            # event recorded on the stream that produced these tensors
+
+    def wait(self):
+        """Make the current stream wait for the post-processing stream that produced the results."""
+        if self.done is not None:
+            torch.cuda.current_stream(self.kp_yx.device).wait_event(self.done)
+        return self
 
     @property
     def num_pairs(self):
@@ -26,6 +33,7 @@ class PairResults:
 
     def to_host(self):
         """Per-pair python lists (synchronises)."""
+        self.wait()
         kp = self.kp_yx.cpu().numpy(); cnt = self.kp_count.cpu().numpy()
         K = kp.shape[1]
         mi = self.match_idx.cpu().numpy(); md = self.match_dist.cpu().numpy()
@@ -45,8 +53,10 @@ class PairPipeline:
     """config: the `prediction:` block of the reference yaml
     (configs/config_image_pair_dataset_prediction.yaml:40-53)."""
 
-    def __init__(self, net, config, capacity=None, nms_rounds=8):
+    def __init__(self, net, config, capacity=None, nms_rounds=8, overlap_post=True):
         self.net = net
+        self.overlap_post = overlap_post
+        self._post_stream = None
         self.nms = config.get('nms', 4)
         self.thr = config.get('detection_threshold', 0.015)
         self.topk = config.get('topk', 0)
@@ -74,6 +84,10 @@ class PairPipeline:
         return torch.stack((optical, thermal), dim=1).reshape(2 * P, *optical.shape[1:])
 
     def run_interleaved(self, images, valid_mask=None, is_optical=None):
+        """One batch: forward on the caller's stream, then NMS / top-k / sampling / matching on a side
+        stream (`overlap_post=True`): those kernels are small and latency-bound, so they run in the
+        shadow of the NEXT batch's convolutions instead of serialising behind this one.  The returned
+        tensors belong to the side stream: `PairResults.wait()` (or a device synchronise) orders them."""
         dev = images.device
         B, _, H, W = images.shape
         if B % 2:
@@ -81,6 +95,24 @@ class PairPipeline:
         if is_optical is None:
             is_optical = (torch.arange(B) % 2 == 0).reshape(B, 1)
         out = self.net({'image': images, 'is_optical': is_optical})
+        main = torch.cuda.current_stream(dev)
+        if self.overlap_post:
+            if self._post_stream is None or self._post_stream.device != dev:
+                self._post_stream = torch.cuda.Stream(device=dev)
+            post = self._post_stream
+            post.wait_stream(main)
+            for t in (out['prob'], out['desc'], valid_mask):
+                if t is not None:
+                    t.record_stream(post)
+        else:
+            post = main
+        with torch.cuda.stream(post):
+            res = self._post(out, valid_mask, dev, B, H, W)
+            res.done = torch.cuda.Event()
+            res.done.record(post)
+        return res
+
+    def _post(self, out, valid_mask, dev, B, H, W):
         prob = out['prob']
         if self.nms > 0:
             K = self.capacity or (self.topk if self.topk > 0 else 4096)
@@ -112,11 +144,18 @@ class PairPipeline:
             ones = torch.ones_like(optical, dtype=torch.bool)
             mask = self.interleave(mask_optical if mask_optical is not None else ones,
                                    mask_thermal if mask_thermal is not None else ones)
-        return self.run_interleaved(images, mask)
+        # convenience entry: results are ordered behind the caller's stream (run_interleaved() is the
+        # high-throughput entry that leaves them on the side stream)
+        return self.run_interleaved(images, mask).wait()
 
     def check_converged(self, device=None):
         """Synchronises; raises if the fixed number of asynchronous NMS rounds was not enough."""
-        n = U.nms_unresolved(device)
+        if self._post_stream is not None:
+            self._post_stream.synchronize()
+            with torch.cuda.stream(self._post_stream):
+                n = U.nms_unresolved(device)
+        else:
+            n = U.nms_unresolved(device)
         if n:
             raise RuntimeError('box_nms: %d candidates undecided after %d rounds; raise nms_rounds'
                                % (n, self.nms_rounds))

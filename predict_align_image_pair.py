@@ -92,7 +92,7 @@ def main(argv=None):
                 data = utils.data_to_device(data, device)
                 res = pipe(data['optical']['image'], data['thermal']['image'],
                            data['optical']['valid_mask'], data['thermal']['valid_mask'])
-                K = res.kp_yx.shape[1]
+                K = res.kp_yx.shape[1]          # (pipe(...) already ordered the results behind this stream)
                 cnt = res.kp_count.clamp(max=K).cpu().numpy()
                 n_opt += cnt[0::2].tolist(); n_th += cnt[1::2].tolist()
                 n_match += res.match_count.cpu().numpy().tolist()
