@@ -103,8 +103,10 @@ def main():
         sys.exit('bench.py needs an MI355X; torch.cuda.is_available() is False')
     torch.cuda.set_device(local_rank)
     device = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ      # under torchrun: RCCL even for world 1
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=device)
 
     import multipoint_amd.models as models
@@ -127,7 +129,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize(device)
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -146,7 +148,7 @@ def main():
     prof = net.profile_read()
     net.profile(False)
     t = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
@@ -161,7 +163,7 @@ def main():
         metrics = gather_pair_metrics(rec).cpu().numpy()
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -228,7 +230,7 @@ def main():
     else:
         out['cpu_baseline'] = None
     print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
