@@ -19,7 +19,8 @@ SOURCES = ['conv_mfma.hip', 'conv_first.hip', 'heads_post.hip', 'nms.hip', 'keyp
 HEADERS = [os.path.join(CSRC, 'mp_common.h'),
            os.path.join(HERE, '..', 'include', 'multipoint_hip.h')]
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
-FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function'] + \
+    os.environ.get('MP_HIPCC_FLAGS', '').split()          # e.g. -DMP_TIMING (developer instrumentation)
 
 
 def _stale(target, deps):

@@ -19,6 +19,20 @@
 // overlap (the fp32 MFMA takes 64 cycles per issue, everything else hides behind it).
 #include "mp_common.h"
 
+#ifdef MP_TIMING
+// developer instrumentation: per-workgroup s_memtime stamps (wave 0) of the first 8192 workgroups
+__device__ unsigned long long g_timing[8192 * 8];
+__device__ int g_timing_h = 480;          // only launches whose input height matches are stamped
+#define MP_STAMP(i) do { if (tid == 0 && blockIdx.x < 8192 && p.H == g_timing_h) g_timing[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int mp_debug_select_height(int h) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_timing_h), &h, sizeof(int)); }
+extern "C" int mp_debug_read_timing(unsigned long long* host, int n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_timing), sizeof(unsigned long long) * n);
+}
+#else
+#define MP_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int CK = 32;        // input channels per LDS chunk
@@ -51,11 +65,23 @@ __device__ __forceinline__ int reflect_clamp(int v, int n)
 // -> BN, reference encoder modules 0-3) of the image: instead of reading a 64-channel tensor from HBM
 // (78.6 MB written + re-read per 480x640 image) the (tile+halo) x 32-channel chunk is COMPUTED from a
 // (tile + 2-pixel ring) image patch held in LDS, on the VALU, in the shadow of the MFMAs.
-template <int TAPS, int MBW, bool POOL, bool FUSE1>
+// ReLU as an integer max (finite inputs): one v_max_i32, no NaN-canonicalising v_max_f32 in front of it.
+// Every VALU instruction outside the MFMA loop matters: fp32 MFMA and VALU share one pipe and a wave that
+// is not streaming MFMAs advances only one instruction per MFMA slot of its neighbour (tools/conv_timing.py).
+__device__ __forceinline__ float relu_f(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
+__device__ __forceinline__ float max4_f(float a, float b, float c, float d)
+{
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4" : "=&v"(r) : "v"(a), "v"(b), "v"(c), "v"(d));
+    return r;
+}
+
+template <int TAPS, int MBW, bool POOL, bool FUSE1, bool BNF>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
 {
     using G = Geo<TAPS, MBW>;
     static_assert(!FUSE1 || TAPS == 9, "first-layer fusion is a 3x3 feature");
+    constexpr bool RELU = (TAPS == 9);      // the 1x1 head convolutions have no ReLU (p.relu == 0)
     constexpr int ITW = G::TW + 4, ITH = G::TH + 4;          // image patch of the fused first layer
     constexpr int FUSE_FLOATS = FUSE1 ? (ITH * ITW + 9 * 64 + 3 * 64) : 0;
     // SWAP: weights as the MFMA A operand -> lane = pixel, register quad = 4 consecutive channels
@@ -71,6 +97,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5;
     const int li = lane & 31;
+    MP_STAMP(0);
 
     // ---- workgroup -> (image, tile, channel slice); XCD-aware bijective remap so that
     //      consecutive logical ids (neighbouring tiles, same slice set) share one XCD's L2 ----
@@ -99,7 +126,22 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     }
 
     // ---- per-thread staging offsets (element offsets from in_base, -1 = store zeros) ----
+    // interior tiles (every halo pixel inside the image: ~87 % of the tiles at 480x640) take a lean path:
+    // no reflect / clamp / zero logic here and no zero-select at the LDS writes.
+    bool interior = false;
+    if constexpr (TAPS == 9)
+        interior = (y0 >= 1) && (y0 + G::TH < p.H) && (x0 >= 1) && (x0 + G::TW < p.W);
     int goff[G::NITER];
+    if (interior) {
+        const int base = ((y0 - 1) * p.W + (x0 - 1)) * p.in_cstride + (tid & 7) * 4;
+#pragma unroll
+        for (int j = 0; j < G::NITER; ++j) {
+            const int lp = (tid + j * 256) >> 3;
+            const int ly = lp / G::LW, lx = lp - ly * G::LW;
+            goff[j] = (tid + j * 256 < G::NF4) ? base + (ly * p.W + lx) * (FUSE1 ? 0 : p.in_cstride) : 0;
+            if constexpr (FUSE1) goff[j] = (ly + 1) * (G::TW + 4) + (lx + 1);       // window centre in the image patch
+        }
+    } else {
 #pragma unroll
     for (int j = 0; j < G::NITER; ++j) {
         const int f = tid + j * 256;
@@ -129,6 +171,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
             }
         }
         goff[j] = off;
+    }
     }
 
     // ---- A-fragment LDS base of this lane (M-block 2*wave, tap (0,0), k-group 0) ----
@@ -181,8 +224,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float v = a[e] + b4[e];
-            if (p.bn_first) v = fmaxf(v * s4[e] + t4[e], 0.f);
-            else v = fmaxf(v, 0.f) * s4[e] + t4[e];
+            if (BNF) v = relu_f(v * s4[e] + t4[e]);
+            else v = relu_f(v) * s4[e] + t4[e];
             a[e] = v;
         }
         return a;
@@ -216,16 +259,27 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     constexpr int S0 = (TAPS == 9) ? 6 : 0;               // first step that issues a staging load
     constexpr int PER_STEP = (TAPS == 9) ? 1 : 2;         // staging loads per step
 
+    MP_STAMP(1);
     for (int c = 0; c < nchunks; ++c) {
+        MP_STAMP(2 + 2 * (c & 1) + 1);                     // 3 / 5: chunk c-1 steps done (c > 0)
         if (c > 0) __syncthreads();                        // chunk c-1 fully consumed
+        if (interior) {
 #pragma unroll
-        for (int j = 0; j < G::NITER; ++j) {
-            const int f = tid + j * 256;
-            if (f < G::NF4)      // padding slots (zero pad / beyond the image) are zeroed here, at the consumer
-                *reinterpret_cast<f32x4*>(&lds[(f >> 3) * PS + (f & 7) * 4]) =
-                    (goff[j] >= 0) ? stg[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < G::NITER; ++j) {
+                const int f = tid + j * 256;
+                if (f < G::NF4) *reinterpret_cast<f32x4*>(&lds[(f >> 3) * PS + (f & 7) * 4]) = stg[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < G::NITER; ++j) {
+                const int f = tid + j * 256;
+                if (f < G::NF4)      // padding slots (zero pad / beyond the image) are zeroed here, at the consumer
+                    *reinterpret_cast<f32x4*>(&lds[(f >> 3) * PS + (f & 7) * 4]) =
+                        (goff[j] >= 0) ? stg[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
         __syncthreads();
+        MP_STAMP(2 + 2 * (c & 1));                         // 2 / 4: chunk c steps start
 
         const f32x4* wc = wp + (long long)c * (G::STEPS * 128);
         const bool more = c + 1 < nchunks;
@@ -274,6 +328,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
         }
     }
 
+    MP_STAMP(6);
     // ---------------- epilogue: bias -> (ReLU, BN) | (BN, ReLU) -> [2x2 max] -> store --------
     if constexpr (POOL) {
         // lane = channel (li), register r = pixel (r&3) + 8*(r>>2) + 4*half of the M-block
@@ -286,11 +341,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
         }
         auto act = [&](float v, int nb) -> float {
             v += bia[nb];
-            if (p.bn_first) {
+            if (BNF) {
                 v = v * scl[nb] + sft[nb];
-                if (p.relu) v = fmaxf(v, 0.f);
+                if (RELU) v = relu_f(v);
             } else {
-                if (p.relu) v = fmaxf(v, 0.f);
+                if (RELU) v = relu_f(v);
                 v = v * scl[nb] + sft[nb];
             }
             return v;
@@ -308,8 +363,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
                         const long long o = (((long long)img * Ho + oy) * Wo + ox) * p.out_cstride + p.out_coff;
 #pragma unroll
                         for (int nb = 0; nb < 2; ++nb) {
-                            const float v = fmaxf(fmaxf(act(acc[0][nb][r], nb), act(acc[0][nb][r + 1], nb)),
-                                                  fmaxf(act(acc[1][nb][r], nb), act(acc[1][nb][r + 1], nb)));
+                            const float v = max4_f(act(acc[0][nb][r], nb), act(acc[0][nb][r + 1], nb),
+                                                   act(acc[1][nb][r], nb), act(acc[1][nb][r + 1], nb));
                             if (ch[nb] < p.cout) p.out[o + ch[nb]] = v;
                         }
                     }
@@ -328,15 +383,15 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
                             const long long o = (((long long)img * Ho + oy) * Wo + ox) * p.out_cstride + p.out_coff;
 #pragma unroll
                             for (int nb = 0; nb < 2; ++nb) {
-                                const float v = fmaxf(
-                                    fmaxf(act(acc[mb][nb][r], nb), act(acc[mb][nb][r + 1], nb)),
-                                    fmaxf(act(acc[mb][nb][r + RDOWN], nb), act(acc[mb][nb][r + RDOWN + 1], nb)));
+                                const float v = max4_f(act(acc[mb][nb][r], nb), act(acc[mb][nb][r + 1], nb),
+                                                       act(acc[mb][nb][r + RDOWN], nb), act(acc[mb][nb][r + RDOWN + 1], nb));
                                 if (ch[nb] < p.cout) p.out[o + ch[nb]] = v;
                             }
                         }
                     }
             }
         }
+        MP_STAMP(7);
         return;
     }
     // non-pooled variants
@@ -348,11 +403,11 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float x = a[rg * 4 + e] + b4[e];
-            if (p.bn_first) {
+            if (BNF) {
                 x = x * s4[e] + t4[e];
-                if (p.relu) x = fmaxf(x, 0.f);
+                if (RELU) x = relu_f(x);
             } else {
-                if (p.relu) x = fmaxf(x, 0.f);
+                if (RELU) x = relu_f(x);
                 x = x * s4[e] + t4[e];
             }
             v[e] = x;
@@ -405,7 +460,10 @@ void launch_t(const ConvParams& p, hipStream_t s)
     else ntiles = (p.total_px + 255) / 256;
     const long long nblk = ntiles * p.nslices;
     if (nblk <= 0) return;
-    hipLaunchKernelGGL((conv_mfma_kernel<TAPS, MBW, POOL, FUSE1>), dim3((unsigned)nblk), dim3(256), 0, s, p);
+    if (p.bn_first)
+        hipLaunchKernelGGL((conv_mfma_kernel<TAPS, MBW, POOL, FUSE1, true>), dim3((unsigned)nblk), dim3(256), 0, s, p);
+    else
+        hipLaunchKernelGGL((conv_mfma_kernel<TAPS, MBW, POOL, FUSE1, false>), dim3((unsigned)nblk), dim3(256), 0, s, p);
 }
 
 }  // namespace
