@@ -167,7 +167,7 @@ def main():
             dist.destroy_process_group()
         return
 
-    # roofline of the dominant kernel: conv_mfma_kernel<9,32,true,true> = encoder conv1 (1->64, computed on the
+    # roofline of the dominant kernel: conv_mfma_kernel<9,32,true,true,false> = encoder conv1 (1->64, computed on the
     # VALU inside the tile loader) fused into conv2 (64->64 @480x640, MFMA) + bias/ReLU/BN + 2x2 max-pool: one
     # launch per step, 44 % of all FLOPs and of the time.  Timed with hipEvents on the launch stream inside
     # the timed region; algorithmic FLOPs = conv1 + conv2 = 2*9*(1*64 + 64*64)*H*W per image.
@@ -181,11 +181,11 @@ def main():
         ach = flop / (ms * 1e-3) / 1e12
         roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(),
-                'kernel': 'conv_mfma_kernel<9,32,true,true> (encoder conv1 fused into conv2 64->64 @480x640 + '
-                          'bias/ReLU/BN + 2x2 max-pool)' if 'enc.conv1+2' in by_name else 'conv_mfma_kernel<9,32,true,false> (enc.conv2)',
+                'kernel': 'conv_mfma_kernel<9,32,true,true,false> (encoder conv1 fused into conv2 64->64 @480x640 + '
+                          'bias/ReLU/BN + 2x2 max-pool)' if 'enc.conv1+2' in by_name else 'conv_mfma_kernel<9,32,true,false,false> (enc.conv2)',
                 'launches_per_step': 1, 'ms_per_launch': round(ms, 4), 'flop_per_launch': flop,
                 'note': 'timed while the previous batch\'s NMS/top-k/sampling/matching kernels run concurrently on the '
-                        'pipeline\'s side stream; the same launch alone takes 11.7 ms (0.80 of peak, tools/bench_layers.py)'}
+                        'pipeline\'s side stream; the same launch alone takes 10.9 ms (0.86 of peak, tools/bench_layers.py)'}
     conv_ms = sum(float(np.mean([m for m, _ in v])) for k, v in by_name.items())
     conv_flop = sum(v[0][1] for v in by_name.values())
     layers = {k: round(float(np.mean([m for m, _ in v])), 4) for k, v in by_name.items()}

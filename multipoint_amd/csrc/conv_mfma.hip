@@ -19,11 +19,14 @@
 // overlap (the fp32 MFMA takes 64 cycles per issue, everything else hides behind it).
 #include "mp_common.h"
 
+#include <algorithm>
+#include <type_traits>
+
 #ifdef MP_TIMING
 // developer instrumentation: per-workgroup s_memtime stamps (wave 0) of the first 8192 workgroups
-__device__ unsigned long long g_timing[8192 * 8];
+__device__ unsigned long long g_timing[8192 * 16];
 __device__ int g_timing_h = 480;          // only launches whose input height matches are stamped
-#define MP_STAMP(i) do { if (tid == 0 && blockIdx.x < 8192 && p.H == g_timing_h) g_timing[blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define MP_STAMP(i) do { if (tid == 0 && blockIdx.x < 8192 && p.H == g_timing_h) g_timing[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int mp_debug_select_height(int h) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_timing_h), &h, sizeof(int)); }
 extern "C" int mp_debug_read_timing(unsigned long long* host, int n)
 {
@@ -31,6 +34,11 @@ extern "C" int mp_debug_read_timing(unsigned long long* host, int n)
 }
 #else
 #define MP_STAMP(i) do { } while (0)
+#endif
+#if defined(MP_TIMING) && MP_TIMING == 2      // prologue-focused stamps (reuse slots 4..6 of the first chunk)
+#define MP_STAMP_P(i) MP_STAMP(i)
+#else
+#define MP_STAMP_P(i) do { } while (0)
 #endif
 
 namespace {
@@ -107,16 +115,20 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
         const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, pos = bid >> 3;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
     }
-    const int slice = logical % p.nslices;
-    int tile = logical / p.nslices;
+    // exact division by multiply-high with host-computed magic numbers: stays on the scalar unit (a
+    // runtime integer division costs ~20 VALU instructions, and VALU shares the pipe with fp32 MFMA)
+    auto udiv = [](unsigned n, unsigned magic, unsigned d) -> unsigned { return d == 1 ? n : __umulhi(n, magic); };
+    int tile = (int)udiv((unsigned)logical, p.magic_slices, (unsigned)p.nslices);
+    const int slice = logical - tile * p.nslices;
 
     int img = 0, y0 = 0, x0 = 0;
     long long px0 = 0;
     const float* in_base;      // wave-uniform base: image (3x3) or first pixel of the tile (1x1)
     if constexpr (TAPS == 9) {
-        const int tx = tile % p.tiles_x; tile /= p.tiles_x;
-        const int ty = tile % p.tiles_y;
-        const int bi = tile / p.tiles_y;
+        const int trow = (int)udiv((unsigned)tile, p.magic_tx, (unsigned)p.tiles_x);
+        const int tx = tile - trow * p.tiles_x;
+        const int bi = (int)udiv((unsigned)trow, p.magic_ty, (unsigned)p.tiles_y);
+        const int ty = trow - bi * p.tiles_y;
         img = p.img_list ? p.img_list[bi] : bi;
         y0 = ty * G::TH; x0 = tx * G::TW;
         in_base = p.in + (long long)img * p.H * p.W * p.in_cstride + p.in_coff;
@@ -128,6 +140,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     // ---- per-thread staging offsets (element offsets from in_base, -1 = store zeros) ----
     // interior tiles (every halo pixel inside the image: ~87 % of the tiles at 480x640) take a lean path:
     // no reflect / clamp / zero logic here and no zero-select at the LDS writes.
+    MP_STAMP_P(8);       // block decode done (kernel arguments loaded)
+#if defined(MP_TIMING) && MP_TIMING == 3
+    {   // calibration: 256 dependent VALU adds between stamps 8 and 9 (how fast does this wave issue?)
+        MP_STAMP(8);
+        int xx = tid;
+#pragma unroll
+        for (int i = 0; i < 256; ++i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(xx) : "v"(tid));
+        MP_STAMP(9);
+        if (xx == 0x7fffffff) p.out[0] = 0.f;
+    }
+#endif
     bool interior = false;
     if constexpr (TAPS == 9)
         interior = (y0 >= 1) && (y0 + G::TH < p.H) && (x0 >= 1) && (x0 + G::TW < p.W);
@@ -175,6 +198,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     }
 
     // ---- A-fragment LDS base of this lane (M-block 2*wave, tap (0,0), k-group 0) ----
+    MP_STAMP_P(9);       // staging offsets done
     const int a_base = (((2 * wave) * G::MBH + li / MBW) * G::LW + (li % MBW)) * PS + half * 4;
     constexpr int A_MB = G::MBH * G::LW * PS;     // second M-block of the wave
 
@@ -183,13 +207,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     const f32x4* wp = reinterpret_cast<const f32x4*>(p.wpack) +
                       ((long long)slice * nchunks) * (G::STEPS * 128) + lane;
 
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    f32x16 acc[2][2];        // not zero-initialised: the first MFMA of the tile takes a literal-zero C operand
 
     // -------- operand pipelines --------------------------------------------------------------
     // B (weights): one linear stream over (chunk, step) straight from L2 into VGPRs, fetched two
@@ -260,8 +278,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     constexpr int PER_STEP = (TAPS == 9) ? 1 : 2;         // staging loads per step
 
     MP_STAMP(1);
-    for (int c = 0; c < nchunks; ++c) {
-        MP_STAMP(2 + 2 * (c & 1) + 1);                     // 3 / 5: chunk c-1 steps done (c > 0)
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto mma = [](float a, float b, const f32x16& cc) -> f32x16 {
+        return SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, cc, 0, 0, 0)
+                    : __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, cc, 0, 0, 0);
+    };
+    auto chunk_body = [&](const int c, auto first_tag) {
+        constexpr bool FIRST = decltype(first_tag)::value;
+        if (c > 0) MP_STAMP(5);                            // chunk 0 steps done
         if (c > 0) __syncthreads();                        // chunk c-1 fully consumed
         if (interior) {
 #pragma unroll
@@ -278,6 +302,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
                         (goff[j] >= 0) ? stg[j] : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
+        if (c == 0) MP_STAMP(3);                           // first chunk landed and written to LDS
         __syncthreads();
         MP_STAMP(2 + 2 * (c & 1));                         // 2 / 4: chunk c steps start
 
@@ -315,18 +340,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                acc[0][0] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s % RB][0][e], af[s & 1][0][e], acc[0][0], 0, 0, 0)
-                                 : __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][0][e], bf[s % RB][0][e], acc[0][0], 0, 0, 0);
-                acc[0][1] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s % RB][1][e], af[s & 1][0][e], acc[0][1], 0, 0, 0)
-                                 : __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][0][e], bf[s % RB][1][e], acc[0][1], 0, 0, 0);
-                acc[1][0] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s % RB][0][e], af[s & 1][1][e], acc[1][0], 0, 0, 0)
-                                 : __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][1][e], bf[s % RB][0][e], acc[1][0], 0, 0, 0);
-                acc[1][1] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(bf[s % RB][1][e], af[s & 1][1][e], acc[1][1], 0, 0, 0)
-                                 : __builtin_amdgcn_mfma_f32_32x32x2f32(af[s & 1][1][e], bf[s % RB][1][e], acc[1][1], 0, 0, 0);
+                acc[0][0] = mma(af[s & 1][0][e], bf[s % RB][0][e], (FIRST && s == 0 && e == 0) ? zero16 : acc[0][0]);
+                acc[0][1] = mma(af[s & 1][0][e], bf[s % RB][1][e], (FIRST && s == 0 && e == 0) ? zero16 : acc[0][1]);
+                acc[1][0] = mma(af[s & 1][1][e], bf[s % RB][0][e], (FIRST && s == 0 && e == 0) ? zero16 : acc[1][0]);
+                acc[1][1] = mma(af[s & 1][1][e], bf[s % RB][1][e], (FIRST && s == 0 && e == 0) ? zero16 : acc[1][1]);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-    }
+    };
+    chunk_body(0, std::true_type{});                     // peeled: its first MFMAs start from C = 0
+    for (int c = 1; c < nchunks; ++c) chunk_body(c, std::false_type{});
 
     MP_STAMP(6);
     // ---------------- epilogue: bias -> (ReLU, BN) | (BN, ReLU) -> [2x2 max] -> store --------
@@ -460,10 +483,17 @@ void launch_t(const ConvParams& p, hipStream_t s)
     else ntiles = (p.total_px + 255) / 256;
     const long long nblk = ntiles * p.nslices;
     if (nblk <= 0) return;
+    ConvParams q = p;
+    // magic = floor(2^32 / d) + 1 gives floor(n / d) == umulhi(n, magic) for all n with n * d < 2^32
+    auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ull / (unsigned)d) + 1ull); };
+    q.magic_slices = magic(p.nslices); q.magic_tx = magic(p.tiles_x); q.magic_ty = magic(p.tiles_y);
+    const long long dmax = std::max(std::max(p.nslices, p.tiles_x), p.tiles_y);
+    if (nblk * dmax >= 0x100000000ll) return;          // caller checks hipGetLastError/sizes; unreachable for sane shapes
+    const ConvParams& pp = q;
     if (p.bn_first)
-        hipLaunchKernelGGL((conv_mfma_kernel<TAPS, MBW, POOL, FUSE1, true>), dim3((unsigned)nblk), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_mfma_kernel<TAPS, MBW, POOL, FUSE1, true>), dim3((unsigned)nblk), dim3(256), 0, s, pp);
     else
-        hipLaunchKernelGGL((conv_mfma_kernel<TAPS, MBW, POOL, FUSE1, false>), dim3((unsigned)nblk), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((conv_mfma_kernel<TAPS, MBW, POOL, FUSE1, false>), dim3((unsigned)nblk), dim3(256), 0, s, pp);
 }
 
 }  // namespace

@@ -36,6 +36,7 @@ struct ConvParams {
     int bn_first;         // 0: conv -> ReLU -> BN (reference default), 1: conv -> BN -> ReLU
     int relu;             // 0: no ReLU (final 1x1 convs)
     long long total_px;   // TAPS==1 (flat) mode: number of pixels
+    unsigned magic_slices, magic_tx, magic_ty;   // multiply-high division constants (filled in by the launcher)
 };
 
 // first layer (Cin = 1, direct VALU conv, HBM-write bound)
