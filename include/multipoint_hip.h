@@ -53,6 +53,10 @@ typedef struct mp_model_config {
     int batchnorm;              /* 1: BatchNorm2d after every 3x3 conv (MultiPoint), 0: none (MagicLeap) */
     int key_layout;             /* 0: MultiPoint nn.Sequential keys, 1: SuperPointMagicLeap keys */
     int softmax_mode;           /* 0: nn.Softmax2d, 1: MagicLeap generate_heatmap arithmetic */
+    /* MultiPoint.py:21,99-103: forward under torch.cuda.amp.autocast.  1: fp16 activations and weights on the
+     * fp16 MFMA (fp32 accumulate), BatchNorm / softmax / descriptor normalisation in fp32; inputs and outputs
+     * of mp_forward stay fp32. */
+    int mixed_precision;
 } mp_model_config;
 
 /* one entry of the reference state_dict (torch.save(net.state_dict()), train.py:161-173), host fp32 */

@@ -20,7 +20,7 @@ class ModelConfig(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ('multispectral', 'descriptor_head', 'descriptor_size',
                                      'normalize_descriptors', 'final_batchnorm', 'reflection_pad',
                                      'bn_first', 'double_convolution', 'channel_version', 'batchnorm',
-                                     'key_layout', 'softmax_mode')]
+                                     'key_layout', 'softmax_mode', 'mixed_precision')]
 
 
 class Tensor(ctypes.Structure):

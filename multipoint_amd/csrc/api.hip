@@ -23,12 +23,15 @@ struct DevBuf {
 struct ConvLayer {            // one MFMA conv launch
     const char* name = "";
     float *wpack = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
+    _Float16* wpack_h = nullptr;  // mixed_precision: fp16 fragments (conv_f16.hip) and the fp16-rounded bias
+    float* bias_h = nullptr;
     int cin = 0, cout = 0, taps = 9, nslices = 0;
     bool pool = false, relu = true;
 };
 
 struct FirstLayer {
     float *w = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
+    float *w_h = nullptr, *bias_h = nullptr;      // mixed_precision: fp16-representable copies
 };
 
 struct Encoder {
@@ -110,6 +113,56 @@ void free_weights(mp_handle* h)
     h->loaded = false;
 }
 
+// IEEE binary16 <-> binary32 on the host, round-to-nearest-even (what tensor.half() does)
+uint16_t f2h_bits(float f)
+{
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    x &= 0x7fffffffu;
+    if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0u));
+    if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);          // >= 65520 rounds to inf
+    if (x < 0x38800000u) {                                             // below 2^-14: fp16 subnormal
+        if (x < 0x33000000u) return (uint16_t)sign;                    // below 2^-25: zero
+        const int e = (int)(x >> 23);
+        const uint32_t m = (x & 0x7fffffu) | 0x800000u;
+        const int shift = 126 - e;
+        uint32_t r = m >> shift;
+        const uint32_t rem = m & ((1u << shift) - 1u), halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (r & 1u))) ++r;
+        return (uint16_t)(sign | r);
+    }
+    uint32_t r = (((x >> 23) - 112u) << 10) | ((x & 0x7fffffu) >> 13);
+    const uint32_t rem = x & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (r & 1u))) ++r;
+    return (uint16_t)(sign | r);
+}
+
+float h2f_bits(uint16_t h)
+{
+    const uint32_t sign = (uint32_t)(h & 0x8000u) << 16;
+    const uint32_t e = (h >> 10) & 0x1fu, m = h & 0x3ffu;
+    uint32_t x;
+    if (e == 0) {
+        if (m == 0) { x = sign; }
+        else {
+            int sh = 0;
+            uint32_t mm = m;
+            while (!(mm & 0x400u)) { mm <<= 1; ++sh; }
+            x = sign | ((uint32_t)(113 - sh) << 23) | ((mm & 0x3ffu) << 13);
+        }
+    } else if (e == 31) {
+        x = sign | 0x7f800000u | (m << 13);
+    } else {
+        x = sign | ((e + 112u) << 23) | (m << 13);
+    }
+    float f;
+    std::memcpy(&f, &x, 4);
+    return f;
+}
+
+float round_half(float f) { return h2f_bits(f2h_bits(f)); }
+
 struct TensorMap {
     std::map<std::string, const mp_tensor*> m;
     std::map<std::string, bool> used;
@@ -177,6 +230,34 @@ void pack_conv_weights(const std::vector<const float*>& srcs, const std::vector<
                             }
 }
 
+// fp16 flavour for conv_f16_kernel: chunks of 64 input channels, steps of 16:
+//   [slice][chunk][step = tap*4 + kgroup][nblock(2)][lane(64)][8]
+//   element e of lane l = half(W[cout = slice*64 + nblock*32 + (l&31)][cin = chunk*64 + kgroup*16 + (l>>5)*8 + e][tap])
+void pack_conv_weights_h(const std::vector<const float*>& srcs, const std::vector<int>& couts, int cin,
+                         int taps, std::vector<uint16_t>& out)
+{
+    int cout = 0;
+    for (int c : couts) cout += c;
+    const int nslices = (cout + 63) / 64, nchunks = cin / 64;
+    // + 5 steps of zero padding: the weight prefetch runs 5 steps past the last slice
+    out.assign((size_t)nslices * nchunks * taps * 4 * 2 * 64 * 8 + 5 * 2 * 64 * 8, 0);
+    size_t o = 0;
+    for (int s = 0; s < nslices; ++s)
+        for (int c = 0; c < nchunks; ++c)
+            for (int tap = 0; tap < taps; ++tap)
+                for (int g = 0; g < 4; ++g)
+                    for (int nb = 0; nb < 2; ++nb)
+                        for (int l = 0; l < 64; ++l)
+                            for (int e = 0; e < 8; ++e, ++o) {
+                                int co = s * 64 + nb * 32 + (l & 31);
+                                const int ci = c * 64 + g * 16 + (l >> 5) * 8 + e;
+                                if (co >= cout) continue;
+                                size_t t = 0;
+                                while (co >= couts[t]) { co -= couts[t]; ++t; }
+                                out[o] = f2h_bits(srcs[t][((size_t)co * cin + ci) * taps + tap]);
+                            }
+}
+
 int build_conv(mp_handle* h, TensorMap& tm, ConvLayer& L, const char* name,
                const std::vector<std::string>& conv_keys, const std::vector<std::string>& bn_keys,
                const std::vector<int>& couts, int cin, int taps, bool pool, bool relu)
@@ -211,6 +292,18 @@ int build_conv(mp_handle* h, TensorMap& tm, ConvLayer& L, const char* name,
     if ((rc = upload(h, bias, &L.bias))) return rc;
     if ((rc = upload(h, scale, &L.scale))) return rc;
     if ((rc = upload(h, shift, &L.shift))) return rc;
+    if (h->cfg.mixed_precision) {
+        std::vector<uint16_t> ph;
+        pack_conv_weights_h(srcs, couts, cin, taps, ph);
+        void* d = nullptr;
+        MP_HIP(hipMalloc(&d, ph.size() * 2));
+        h->weight_allocs.push_back(d);
+        MP_HIP(hipMemcpy(d, ph.data(), ph.size() * 2, hipMemcpyHostToDevice));
+        L.wpack_h = static_cast<_Float16*>(d);
+        std::vector<float> bh(bias);
+        for (float& v : bh) v = round_half(v);
+        if ((rc = upload(h, bh, &L.bias_h))) return rc;
+    }
     return MP_OK;
 }
 
@@ -247,6 +340,12 @@ int build_encoder(mp_handle* h, TensorMap& tm, Encoder& E, const std::string& pr
         if ((rc = upload(h, bias, &E.first.bias))) return rc;
         if ((rc = upload(h, s, &E.first.scale))) return rc;
         if ((rc = upload(h, t, &E.first.shift))) return rc;
+        if (h->cfg.mixed_precision) {
+            for (float& v : wt) v = round_half(v);
+            for (float& v : bias) v = round_half(v);
+            if ((rc = upload(h, wt, &E.first.w_h))) return rc;
+            if ((rc = upload(h, bias, &E.first.bias_h))) return rc;
+        }
     }
     for (int i = 1; i < 8; ++i) {
         int rc = build_conv(h, tm, E.conv[i - 1], kEncNames[i - 1], {conv_key(i)}, {bn_key(i)}, {chan[i + 1]}, chan[i], 9,
@@ -315,6 +414,86 @@ void run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride,
     if (fuse) { p.img = images; p.w1 = fuse->w; p.b1 = fuse->bias; p.s1 = fuse->scale; p.t1 = fuse->shift; }
     launch_conv_mfma(p, L.taps, mbw, L.pool, fuse != nullptr, s);
     prof_end(h, s);
+}
+
+void run_conv_h(mp_handle* h, const ConvLayer& L, const _Float16* in, int in_cstride, int in_coff, _Float16* out,
+                int out_cstride, int out_coff, int B, int H, int W, const int* img_list, hipStream_t s)
+{
+    ConvParamsH p{};
+    p.in = in; p.out = out; p.wpack = L.wpack_h; p.bias = L.bias_h; p.scale = L.scale; p.shift = L.shift;
+    p.img_list = img_list;
+    p.B = B; p.H = H; p.W = W;
+    p.in_cstride = in_cstride; p.in_coff = in_coff; p.cin = L.cin;
+    p.out_cstride = out_cstride; p.out_coff = out_coff; p.cout = L.cout;
+    p.nslices = L.nslices;
+    p.pad_zero = h->cfg.reflection_pad ? 0 : 1;
+    p.bn_first = h->cfg.bn_first;
+    int mbw = 32;
+    if (L.taps == 9) {
+        mbw = pick_mbw(H, W);
+        const int tw = mbw, th = 256 / mbw;
+        p.tiles_x = (W + tw - 1) / tw; p.tiles_y = (H + th - 1) / th;
+    } else {
+        p.total_px = (long long)B * H * W;
+    }
+    prof_begin(h, L.name, 2.0 * L.taps * L.cin * L.cout * (double)B * H * W, s);
+    launch_conv_f16(p, L.taps, mbw, L.pool, s);
+    prof_end(h, s);
+}
+
+// mixed_precision forward: fp16 activations end to end, fp32 softmax / descriptor normalisation
+int forward_f16(mp_handle* h, const float* images, int B, int H, int W, int nsets, const int* counts,
+                const int* const* lptr, float* prob, float* logits, float* desc, hipStream_t s)
+{
+    const int Hc = H / 8, Wc = W / 8;
+    const long long npx = (long long)B * Hc * Wc;
+    const int D = h->cfg.descriptor_size;
+    const int headc = h->cfg.descriptor_head ? 512 : 256;
+    // same carve-up as the fp32 path (sizes in elements), element type fp16
+    const size_t nP = (size_t)B * H * W * 64, nQ = (size_t)B * H * W * 16;
+    const size_t nL = (size_t)npx * 128, nD = (size_t)npx * 128, nR = (size_t)npx * 256;
+    _Float16* P = static_cast<_Float16*>(h->ws.p);
+    _Float16* Q = P + nP;
+    _Float16* Lg = Q + nQ;
+    _Float16* X = Lg + nL;
+    _Float16* R = X + nD;        // raw (un-normalised) descriptors
+    (void)nR;
+    for (int e = 0; e < nsets; ++e) {
+        const int nb = counts[e];
+        if (nb == 0) continue;
+        const Encoder& E = h->enc[e];
+        Conv1ParamsH c1{};
+        c1.in = images; c1.out = P; c1.w = E.first.w_h; c1.bias = E.first.bias_h; c1.scale = E.first.scale;
+        c1.shift = E.first.shift; c1.img_list = lptr[e]; c1.B = nb; c1.H = H; c1.W = W;
+        c1.pad_zero = h->cfg.reflection_pad ? 0 : 1; c1.bn_first = h->cfg.bn_first;
+        prof_begin(h, "enc.conv1", 2.0 * 9 * 64 * (double)nb * H * W, s);
+        launch_conv_first_f16(c1, s);
+        prof_end(h, s);
+        int hh = H, ww = W;
+        _Float16* src = P;
+        _Float16* dst = Q;
+        for (int i = 0; i < 7; ++i) {
+            const ConvLayer& L = E.conv[i];
+            run_conv_h(h, L, src, L.cin, 0, i == 6 ? X : dst, L.cout, 0, nb, hh, ww, lptr[e], s);
+            if (L.pool) { hh /= 2; ww /= 2; }
+            _Float16* t = src; src = dst; dst = t;
+        }
+    }
+    run_conv_h(h, h->heads3, X, 128, 0, P, headc, 0, B, Hc, Wc, nullptr, s);
+    run_conv_h(h, h->det1, P, headc, 0, Lg, 128, 0, B, Hc, Wc, nullptr, s);
+    if (prob || logits) {
+        prof_begin(h, "det.softmax_shuffle", 0.0, s);
+        launch_det_post_f16(Lg, 128, B, Hc, Wc, prob, logits, h->cfg.softmax_mode, s);
+        prof_end(h, s);
+    }
+    if (desc) {
+        run_conv_h(h, h->desc1, P, headc, 256, R, D, 0, B, Hc, Wc, nullptr, s);
+        prof_begin(h, "desc.l2norm", 0.0, s);
+        launch_desc_l2norm_f16(R, desc, npx, D, h->cfg.normalize_descriptors ? 1 : 0, s);
+        prof_end(h, s);
+    }
+    MP_HIP(hipGetLastError());
+    return MP_OK;
 }
 
 bool footprint(float size, float iou, NmsFootprint& fp)
@@ -553,6 +732,7 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
         MP_HIP(hipMemcpyAsync(lists, host.data(), 1024 * 4, hipMemcpyHostToDevice, s));
         lptr[0] = lists; lptr[1] = lists + 512;
     }
+    if (h->cfg.mixed_precision) return forward_f16(h, images, B, H, W, nsets, counts, lptr, prob, logits, desc, s);
     for (int e = 0; e < nsets; ++e) {
         const int nb = counts[e];
         if (nb == 0) continue;

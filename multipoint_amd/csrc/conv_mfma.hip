@@ -23,10 +23,10 @@
 #include <type_traits>
 
 #ifdef MP_TIMING
-// developer instrumentation: per-workgroup s_memtime stamps (wave 0) of the first 8192 workgroups
-__device__ unsigned long long g_timing[8192 * 16];
+// developer instrumentation: per-wave s_memtime stamps of the first 8192 workgroups (slot 15: HW_ID | XCC_ID << 32)
+__device__ unsigned long long g_timing[8192 * 4 * 16];
 __device__ int g_timing_h = 480;          // only launches whose input height matches are stamped
-#define MP_STAMP(i) do { if (tid == 0 && blockIdx.x < 8192 && p.H == g_timing_h) g_timing[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define MP_STAMP(i) do { if ((tid & 63) == 0 && blockIdx.x < 8192 && p.H == g_timing_h) g_timing[(blockIdx.x * 4 + (tid >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
 extern "C" int mp_debug_select_height(int h) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_timing_h), &h, sizeof(int)); }
 extern "C" int mp_debug_read_timing(unsigned long long* host, int n)
 {
@@ -106,6 +106,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     const int half = lane >> 5;
     const int li = lane & 31;
     MP_STAMP(0);
+#ifdef MP_TIMING
+    if ((tid & 63) == 0 && blockIdx.x < 8192 && p.H == g_timing_h) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_timing[(blockIdx.x * 4 + (tid >> 6)) * 16 + 15] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+    }
+#endif
 
     // ---- workgroup -> (image, tile, channel slice); XCD-aware bijective remap so that
     //      consecutive logical ids (neighbouring tiles, same slice set) share one XCD's L2 ----

@@ -11,7 +11,8 @@ namespace {
 
 // One wave = 8 horizontally adjacent coarse cells; lane l: cell l>>3, column j = l&7 of the 8x8
 // block; registers i = 0..7 hold channel 8i+j.  For a fixed i the wave writes 64 contiguous floats.
-__global__ __launch_bounds__(256) void det_post_kernel(const float* __restrict__ logits, int lstride,
+template <typename T>
+__global__ __launch_bounds__(256) void det_post_kernel(const T* __restrict__ logits, int lstride,
                                                       int B, int Hc, int Wc, float* __restrict__ prob,
                                                       float* __restrict__ logits_nchw, int mode)
 {
@@ -27,12 +28,12 @@ __global__ __launch_bounds__(256) void det_post_kernel(const float* __restrict__
     const int w = gx * 8 + cell;
     const bool valid = w < Wc;
     const long long cidx = ((long long)b * Hc + h) * Wc + (valid ? w : Wc - 1);
-    const float* lp = logits + cidx * lstride;
+    const T* lp = logits + cidx * lstride;
 
     float v[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = lp[8 * i + j];
-    const float d = lp[64];
+    for (int i = 0; i < 8; ++i) v[i] = (float)lp[8 * i + j];
+    const float d = (float)lp[64];
 
     if (logits_nchw && valid) {
         const long long plane = (long long)Hc * Wc;
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(256) void det_post_kernel(const float* __restrict__
 }
 
 // rows of D floats; LPP = D/4 lanes per pixel (16, 32 or 64), one float4 per lane.
-__global__ __launch_bounds__(256) void desc_l2norm_kernel(const float* __restrict__ raw,
+template <typename T>
+__global__ __launch_bounds__(256) void desc_l2norm_kernel(const T* __restrict__ raw,
                                                          float* __restrict__ out, long long npx,
                                                          int D, int normalize)
 {
@@ -80,7 +82,15 @@ __global__ __launch_bounds__(256) void desc_l2norm_kernel(const float* __restric
     const bool valid = px < npx;
     const int c = (lane % lpp) * 4;
     f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (valid) v = *reinterpret_cast<const f32x4*>(raw + px * D + c);
+    if (valid) {
+        if constexpr (sizeof(T) == 4) {
+            v = *reinterpret_cast<const f32x4*>(raw + px * D + c);
+        } else {
+            typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+            const h4 hv = *reinterpret_cast<const h4*>(raw + px * D + c);
+            v = f32x4{(float)hv[0], (float)hv[1], (float)hv[2], (float)hv[3]};
+        }
+    }
     if (normalize) {
         float s = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
         for (int off = 1; off < lpp; off <<= 1) s += __shfl_xor(s, off);
@@ -97,7 +107,16 @@ void launch_det_post(const float* logits, int lstride, int B, int Hc, int Wc, fl
 {
     const long long waves = (long long)B * Hc * ((Wc + 7) / 8);
     if (waves <= 0) return;
-    hipLaunchKernelGGL(det_post_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, logits,
+    hipLaunchKernelGGL(det_post_kernel<float>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, logits,
+                       lstride, B, Hc, Wc, prob, logits_nchw, mode);
+}
+
+void launch_det_post_f16(const _Float16* logits, int lstride, int B, int Hc, int Wc, float* prob,
+                         float* logits_nchw, int mode, hipStream_t s)
+{
+    const long long waves = (long long)B * Hc * ((Wc + 7) / 8);
+    if (waves <= 0) return;
+    hipLaunchKernelGGL(det_post_kernel<_Float16>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, logits,
                        lstride, B, Hc, Wc, prob, logits_nchw, mode);
 }
 
@@ -107,6 +126,18 @@ void launch_desc_l2norm(const float* raw, float* out, long long npx, int D, int 
     const int ppw = 64 / (D / 4);
     const long long waves = (npx + ppw - 1) / ppw;
     if (waves <= 0) return;
-    hipLaunchKernelGGL(desc_l2norm_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, raw,
+    hipLaunchKernelGGL(desc_l2norm_kernel<float>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, raw,
+                       out, npx, D, normalize);
+}
+
+// fp16 head output -> fp32 descriptors (F.normalize computes the norm in fp32 under autocast and the
+// division promotes to fp32)
+void launch_desc_l2norm_f16(const _Float16* raw, float* out, long long npx, int D, int normalize,
+                            hipStream_t s)
+{
+    const int ppw = 64 / (D / 4);
+    const long long waves = (npx + ppw - 1) / ppw;
+    if (waves <= 0) return;
+    hipLaunchKernelGGL(desc_l2norm_kernel<_Float16>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, raw,
                        out, npx, D, normalize);
 }

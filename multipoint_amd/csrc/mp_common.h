@@ -53,6 +53,36 @@ struct Conv1Params {
 void launch_conv_mfma(const ConvParams& p, int taps, int mbw, bool pool, bool fuse1, hipStream_t s);
 void launch_conv_first(const Conv1Params& p, hipStream_t s);
 
+// fp16 path (mixed_precision: activations and packed weights fp16, fp32 accumulate; conv_f16.hip).
+// Same tiling as ConvParams; a chunk is 64 input channels, so cin must be a multiple of 64.
+struct ConvParamsH {
+    const _Float16* in;   // [B][H][W][in_cstride]
+    _Float16* out;        // [B][Ho][Wo][out_cstride]
+    const _Float16* wpack;
+    const float* bias;    // fp16-representable values
+    const float* scale;   // fp32 BN terms (BatchNorm runs in fp32 under autocast)
+    const float* shift;
+    const int* img_list;
+    int B, H, W;
+    int in_cstride, in_coff, cin;
+    int out_cstride, out_coff, cout;
+    int nslices, tiles_x, tiles_y;
+    int pad_zero, bn_first;
+    long long total_px;
+    unsigned magic_slices, magic_tx, magic_ty;
+};
+struct Conv1ParamsH {
+    const float* in;      // [B][H][W] fp32 image (rounded to fp16 on load)
+    _Float16* out;        // [B][H][W][64]
+    const float* w;       // [9][64] fp16-representable values
+    const float* bias; const float* scale; const float* shift;
+    const int* img_list;
+    int B, H, W;
+    int pad_zero, bn_first;
+};
+void launch_conv_f16(const ConvParamsH& p, int taps, int mbw, bool pool, hipStream_t s);
+void launch_conv_first_f16(const Conv1ParamsH& p, hipStream_t s);
+
 // ---------------------------------------------------------------------------------------------
 // heads post-processing
 // ---------------------------------------------------------------------------------------------
@@ -60,9 +90,13 @@ void launch_conv_first(const Conv1Params& p, hipStream_t s);
 // depth-to-space 8) and/or logits_nchw [B][65][Hc][Wc]
 void launch_det_post(const float* logits, int lstride, int B, int Hc, int Wc, float* prob,
                      float* logits_nchw, int mode, hipStream_t s);
+void launch_det_post_f16(const _Float16* logits, int lstride, int B, int Hc, int Wc, float* prob,
+                         float* logits_nchw, int mode, hipStream_t s);
 // raw [npx][D] -> out [npx][D] rows divided by max(||row||, 1e-12)   (D multiple of 4, <= 1024)
 void launch_desc_l2norm(const float* raw, float* out, long long npx, int D, int normalize,
                         hipStream_t s);
+void launch_desc_l2norm_f16(const _Float16* raw, float* out, long long npx, int D, int normalize,
+                            hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
 // keypoint extraction

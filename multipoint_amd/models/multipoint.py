@@ -40,9 +40,6 @@ class MultiPoint:
                              '(channels [1,64,64,128,128], MultiPoint.py:38-40)')
         if not self.config['double_convolution']:
             raise ValueError('multipoint_amd supports double_convolution=True only')
-        if self.config['mixed_precision']:
-            raise ValueError('mixed_precision (fp16 MFMA path) is not available yet; the fp32 path '
-                             'is exact fp32')
         self.training = False
         self.device = None
         self._handle = None
@@ -185,7 +182,8 @@ class MultiPoint:
         vals = [int(c[k]) if k in ('descriptor_size', 'channel_version') else int(bool(c[k]))
                 for k in ('multispectral', 'descriptor_head', 'descriptor_size', 'normalize_descriptors',
                           'final_batchnorm', 'reflection_pad', 'bn_first', 'double_convolution', 'channel_version')]
-        vals += [self._abi_extra['batchnorm'], self._abi_extra['key_layout'], self._abi_extra['softmax_mode']]
+        vals += [self._abi_extra['batchnorm'], self._abi_extra['key_layout'], self._abi_extra['softmax_mode'],
+                 int(bool(c['mixed_precision']))]      # MultiPoint.py:99-103: forward under autocast -> fp16 MFMA path
         cfg = _lib.ModelConfig(*vals)
         keep = []
         arr = []

@@ -16,6 +16,10 @@ Pinning status (see tests/test_oracle_vs_reference.py and tests/golden/make_gold
   * box_nms (torchvision.ops.nms / batched_nms) and cv2.BFMatcher: third-party code absent from
     /root/reference and not installable here -> "PARITY UNPINNED" at those two boundaries; the
     published algorithms are restated (oracle/nms_greedy.c, ``bf_match_crosscheck``).
+  * ``mixed_precision: true`` (forward under torch.cuda.amp.autocast, MultiPoint.py:99-103): autocast needs a
+    CUDA device, so the reference cannot produce vectors here -> "PARITY UNPINNED" for this mode; its
+    rounding points are restated in ``_block`` / ``_head`` (fp16 conv in/out with fp32 accumulation, fp32
+    BatchNorm arithmetic with fp16 results, fp32 softmax and normalisation).
 """
 import collections
 import ctypes
@@ -211,8 +215,22 @@ def _pad(x, cfg):
     return F.pad(x, (1, 1, 1, 1), mode='reflect') if cfg['reflection_pad'] else F.pad(x, (1, 1, 1, 1))
 
 
+def _h(t):
+    """Round to fp16 and back (round-to-nearest-even): the value an fp16 tensor would hold."""
+    return t.half().float()
+
+
 def _block(x, sd, cfg, conv_key, bn_key):
     # MultiPoint.py:143-148 + :137-141
+    if cfg.get('mixed_precision'):
+        # MultiPoint.py:99-103: forward under torch.cuda.amp.autocast (CUDA only -- cannot run here; PARITY
+        # UNPINNED for this mode).  Restated autocast semantics: Conv2d casts input, weight and bias to fp16,
+        # accumulates in fp32 and returns fp16; ReLU / pad / max-pool are exact on fp16; BatchNorm2d(eval) on an
+        # fp16 tensor evaluates its affine form in fp32 and returns fp16.  x arrives holding fp16 values.
+        x = _h(F.conv2d(_pad(x, cfg), _h(sd[conv_key + '.weight']), _h(sd[conv_key + '.bias'])))
+        if cfg['bn_first']:
+            return F.relu(_h(_bn_eval(x, sd, bn_key)))
+        return _h(_bn_eval(F.relu(x), sd, bn_key))
     x = F.conv2d(_pad(x, cfg), sd[conv_key + '.weight'], sd[conv_key + '.bias'])
     if cfg['bn_first']:
         return F.relu(_bn_eval(x, sd, bn_key))
@@ -240,6 +258,11 @@ def depth_to_space(x, block_size):
 def _head(x, sd, cfg, name):
     bn_i = 2 if cfg['bn_first'] else 3
     x = _block(x, sd, cfg, name + '.1', '%s.%d' % (name, bn_i))
+    if cfg.get('mixed_precision'):
+        x = _h(F.conv2d(x, _h(sd[name + '.4.weight']), _h(sd[name + '.4.bias'])))
+        if cfg['final_batchnorm']:
+            x = _h(_bn_eval(x, sd, name + '.5'))
+        return x       # fp16 values; softmax / F.normalize below run in fp32 (autocast's fp32 op list)
     x = F.conv2d(x, sd[name + '.4.weight'], sd[name + '.4.bias'])
     if cfg['final_batchnorm']:
         x = _bn_eval(x, sd, name + '.5')
@@ -251,6 +274,8 @@ def forward(sd, image, cfg=None, is_optical=None, return_logits=False):
     image: (B,1,H,W) fp32.  Returns dict(prob (B,1,H,W) | logits (B,65,H/8,W/8), desc (B,D,H/8,W/8))."""
     cfg = full_config(cfg)
     with torch.no_grad():
+        if cfg.get('mixed_precision'):
+            image = _h(image)             # autocast casts the first convolution's input to fp16
         if cfg['multispectral']:
             # MultiPoint.py:107-122: route each image through encoder_optical / encoder_thermal
             B, _, H, W = image.shape

@@ -92,3 +92,18 @@ def test_forward_magicleap(oracle, golden_dir):
     assert np.abs(out['logits'].numpy() - g['logits']).max() <= 1e-5
     assert np.abs(out['desc'].numpy() - g['desc']).max() <= 1e-6
     assert np.abs(out['prob'].numpy() - g['prob']).max() <= 1e-6
+
+
+def test_autocast_restatement_is_fp16_noise_away_from_fp32(oracle):
+    """mixed_precision restatement (PARITY UNPINNED: autocast needs CUDA): every intermediate is an fp16 value, the
+    result stays within fp16 noise of the fp32 forward, descriptors are normalised in fp32."""
+    import torch
+    cfg = dict(oracle.SHIPPED_MODEL_CONFIG); cfg16 = dict(cfg); cfg16['mixed_precision'] = True
+    sd = oracle.make_weights(0, cfg)
+    img = oracle.make_images(9, 2, 64, 64)
+    a, b = oracle.forward(sd, img, cfg), oracle.forward(sd, img, cfg16)
+    assert 0 < (a['prob'] - b['prob']).abs().max().item() < 2e-2
+    assert 0 < (a['desc'] - b['desc']).abs().max().item() < 4e-3
+    assert (b['desc'].pow(2).sum(1).sqrt() - 1).abs().max().item() < 1e-5
+    lg = oracle.forward(sd, img, cfg16, return_logits=True)['logits']
+    assert torch.equal(lg, lg.half().float())

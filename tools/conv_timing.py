@@ -17,13 +17,15 @@ torch.cuda.synchronize()
 # run a forward on an input whose later layers are tiny?  Instead read after a forward restricted by env.
 sel_h = int(os.environ.get('MP_TIMING_H', '480'))     # 480: fused conv1+2, 240: conv3 (no pool) then conv4 (pool; last writer)
 assert lib.mp_debug_select_height(sel_h) == 0
-buf = (ctypes.c_ulonglong * (8192 * 16))()
+NW = 8192 * 4
+buf = (ctypes.c_ulonglong * (NW * 16))()
 net({'image': img}); torch.cuda.synchronize()
-assert lib.mp_debug_read_timing(buf, 8192 * 16) == 0
-t = np.frombuffer(buf, dtype=np.uint64).reshape(8192, 16).astype(np.float64)
+assert lib.mp_debug_read_timing(buf, NW * 16) == 0
+raw = np.frombuffer(buf, dtype=np.uint64).reshape(NW, 16)
+t = raw.astype(np.float64)
 ok = (t[:, 7] > t[:, 0]) & (t[:, 0] > 0)
-t = t[ok]
-print('blocks', len(t))
+t = t[ok]; raw = raw[ok]
+print('waves', len(t))
 d = {'  index+issue (t1-t0)': t[:, 1] - t[:, 0], '  land+ldswrite (t3-t1)': t[:, 3] - t[:, 1], '  barrier (t2-t3)': t[:, 2] - t[:, 3],
      'prologue (t2-t0)': t[:, 2] - t[:, 0], 'chunk0 (t5-t2)': t[:, 5] - t[:, 2], 'boundary (t4-t5)': t[:, 4] - t[:, 5],
      'chunk1 (t6-t4)': t[:, 6] - t[:, 4], 'epilogue (t7-t6)': t[:, 7] - t[:, 6], 'total (t7-t0)': t[:, 7] - t[:, 0]}
@@ -34,3 +36,38 @@ if os.environ.get('MP_TIMING_CAL') == '1':
     d = {'256 dependent v_add (t9-t8)': t[:, 9] - t[:, 8]}
 for k, v in d.items():
     print('%-24s mean %9.0f  p10 %9.0f  p50 %9.0f  p90 %9.0f' % (k, v.mean(), np.percentile(v, 10), np.percentile(v, 50), np.percentile(v, 90)))
+
+
+if os.environ.get('MP_TIMING_SIMD') == '1':
+    # per-SIMD occupancy of the matrix pipe (2-chunk layers): how much of the time are 0 / 1 / 2 of the resident
+    # waves inside their MFMA loops ([t2,t5] and [t4,t6]), and how many waves are resident ([t0,t7])
+    hw = raw[:, 15]
+    key = ((hw >> np.uint64(32)) & np.uint64(15)) * np.uint64(1 << 16) + ((hw >> np.uint64(8)) & np.uint64(0xff)) * np.uint64(4) \
+        + ((hw >> np.uint64(4)) & np.uint64(3))
+    acc_s = np.zeros(4); acc_r = np.zeros(4); nsimd = 0
+    for k in np.unique(key):
+        w = t[key == k]
+        if len(w) < 8:
+            continue
+        starts = np.sort(w[:, 0])
+        lo, hi = starts[2], starts[-3]
+        if hi <= lo:
+            continue
+        ev = []
+        for r in w:
+            ev += [(r[2], 0, 1), (r[5], 0, -1), (r[4], 0, 1), (r[6], 0, -1), (r[0], 1, 1), (r[7], 1, -1)]
+        ev.sort()
+        cnt = [0, 0]; prev = lo
+        for tt, kind, dlt in ev:
+            if tt > lo:
+                x = min(tt, hi)
+                if x > prev:
+                    acc_s[min(cnt[0], 3)] += x - prev; acc_r[min(cnt[1], 3)] += x - prev
+                    prev = x
+            cnt[kind] += dlt
+            if tt >= hi:
+                break
+        nsimd += 1
+    print('SIMDs analysed', nsimd)
+    print('waves in MFMA loop   0: %.1f %%   1: %.1f %%   2: %.1f %%' % tuple(100 * acc_s[:3] / acc_s.sum()))
+    print('waves resident       0: %.1f %%   1: %.1f %%   2: %.1f %%  3+: %.1f %%' % tuple(100 * acc_r / acc_r.sum()))
