@@ -10,6 +10,9 @@ GPU: encoder + detector/descriptor heads (fp32) -> box-NMS (size 4, iou 0.1, thr
 -> bilinear descriptor sampling + L2 norm -> mutual-NN match.  Pairs shard independently over ranks
 (weak scaling, no data-path collective); RCCL only gathers the per-pair metric records.
 
+`--workload c5` switches to BASELINE.json configs[4]'s per-GPU share instead: 8 pairs of 1024x1280 images on the
+fp16 MFMA path (`mixed_precision`), top-k 2000 (a secondary line; the default run is the headline metric).
+
 Prints ONE JSON line on rank 0 (see README / DESIGN.md section "Measurement").
 """
 import argparse
@@ -26,6 +29,7 @@ sys.path.insert(0, ROOT)
 
 GFLOP_PER_IMAGE_480x640 = 51.6317        # SURVEY.md Appendix B (12 convolutions)
 PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
+PEAK_FP16_MFMA_TFLOPS = 2500.0           # MI355X_MICROARCH.md: dense fp16/bf16 MFMA (v_mfma_f32_32x32x16_f16)
 PAIRS_PER_GPU = 32
 H, W = 480, 640
 PRED_CFG = {'nms': 4, 'detection_threshold': 0.015, 'topk': 1000, 'cpu_nms': False,
@@ -52,7 +56,7 @@ def pmc_traffic():
         return None
 
 
-def make_batch(rank, n_pairs, device):
+def make_batch(rank, n_pairs, device, H=H, W=W):
     """Interleaved batch: image 2p = optical, 2p+1 = thermal of global pair id rank*n_pairs + p."""
     from multipoint_amd.datasets import SyntheticPairs
     imgs = np.empty((2 * n_pairs, 1, H, W), dtype=np.float32)
@@ -62,7 +66,7 @@ def make_batch(rank, n_pairs, device):
     return torch.from_numpy(imgs).to(device)
 
 
-def cpu_baseline(sd, cfg, n_pairs=16):
+def cpu_baseline(sd, cfg, n_pairs=16, H=H, W=W, PRED_CFG=PRED_CFG):
     """The oracle (CPU restatement of the reference path, ATen CPU ops) timed on this box's host cores
     on a bounded sample of the same workload.  A reported baseline, not the optimisation target."""
     from oracle import mp_oracle as O
@@ -77,8 +81,10 @@ def cpu_baseline(sd, cfg, n_pairs=16):
                           topk=PRED_CFG['topk'])
     dt = time.perf_counter() - t0
     return {'value': n_pairs / dt, 'unit': 'image-pairs/s', 'cores': torch.get_num_threads(), 'kind': 'port',
-            'sample': '%d pairs 480x640, full path (oracle.process_pairs: ATen-CPU forward, C greedy NMS, '
-                      'numpy sampling + NNMatcher), %.1f s' % (n_pairs, dt)}, res
+            'sample': '%d pairs %dx%d, full path (oracle.process_pairs: ATen-CPU forward%s, C greedy NMS, '
+                      'numpy sampling + NNMatcher), %.1f s' % (n_pairs, H, W, ' with the fp16 rounding points of '
+                                                               'autocast emulated in fp32 arithmetic'
+                                                               if cfg.get('mixed_precision') else '', dt)}, res
 
 
 def main():
@@ -89,7 +95,17 @@ def main():
     ap.add_argument('--pairs-per-gpu', type=int, default=PAIRS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--forward-only', action='store_true', help='configs[1]: encoder+heads only')
+    ap.add_argument('--workload', choices=['c3', 'c5'], default='c3',
+                    help='c3 (default, headline): 480x640 fp32 top-k 1000; c5: 1024x1280 fp16 MFMA path top-k 2000')
     args = ap.parse_args()
+    global H, W
+    PRED = dict(PRED_CFG)
+    c5 = args.workload == 'c5'
+    if c5:
+        H, W = 1024, 1280
+        PRED['topk'] = 2000
+        if args.pairs_per_gpu == PAIRS_PER_GPU:
+            args.pairs_per_gpu = 8                # 64 pairs over 8 GPUs
 
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
     local_rank = int(os.environ.get('LOCAL_RANK', 0))
@@ -115,11 +131,13 @@ def main():
     from oracle import mp_oracle as O          # weights generator + cpu_baseline leg only
 
     cfg = dict(O.SHIPPED_MODEL_CONFIG)
+    if c5:
+        cfg['mixed_precision'] = True
     sd = O.make_weights(0, cfg)
     net = models.MultiPoint(cfg); net.load_state_dict(sd); net.to(device); net.eval()
-    pipe = PairPipeline(net, PRED_CFG, capacity=PRED_CFG['topk'], nms_rounds=8)
+    pipe = PairPipeline(net, PRED, capacity=PRED['topk'], nms_rounds=8)
     P = args.pairs_per_gpu
-    images = make_batch(rank, P, device)
+    images = make_batch(rank, P, device, H, W)
     flags = (torch.arange(2 * P) % 2 == 0).reshape(-1, 1)
 
     def step():
@@ -179,7 +197,14 @@ def main():
     if dom:
         ms = float(np.mean([m for m, _ in dom])); flop = dom[0][1]
         ach = flop / (ms * 1e-3) / 1e12
-        roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+        if c5:
+            roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(ach / PEAK_FP16_MFMA_TFLOPS, 4), 'traffic': None,
+                    'kernel': 'conv_f16_kernel<9,32,true,false> (enc.conv2 64->64 @1024x1280 on v_mfma_f32_32x32x16_f16 '
+                              '+ bias/ReLU/BN + 2x2 max-pool)',
+                    'launches_per_step': 1, 'ms_per_launch': round(ms, 4), 'flop_per_launch': flop}
+        else:
+          roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(),
                 'kernel': 'conv_mfma_kernel<9,32,true,true,false> (encoder conv1 fused into conv2 64->64 @480x640 + '
                           'bias/ReLU/BN + 2x2 max-pool)' if 'enc.conv1+2' in by_name else 'conv_mfma_kernel<9,32,true,false,false> (enc.conv2)',
@@ -193,20 +218,24 @@ def main():
     total_pairs = P * world * args.steps
     value = total_pairs / dt
     gflop_pair = 2 * conv_flops_per_image(H, W) / 1e9
+    peak = PEAK_FP16_MFMA_TFLOPS if c5 else PEAK_FP32_MFMA_TFLOPS
     out = {
-        'metric': 'image-pairs/sec (detect+desc+match) @ 480x640' if not args.forward_only
-                  else 'image-pairs/sec (encoder+heads forward only) @ 480x640',
+        'metric': ('image-pairs/sec (detect+desc+match) @ %dx%d' % (H, W)) if not args.forward_only
+                  else 'image-pairs/sec (encoder+heads forward only) @ %dx%d' % (H, W),
         'value': round(value, 2), 'unit': 'image-pairs/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
-        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': 'BASELINE configs[2]: %d pairs (=%d images) 480x640 per GPU, full path: fp32 '
+        'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16' if c5 else 'f32', 'data': 'synthetic',
+        'config': {'workload': ('BASELINE configs[4] (per-GPU share): %d pairs (=%d images) 1024x1280, fp16 MFMA conv path '
+                                '(fp32 accumulate), box-NMS size 4 + top-k 2000, bilinear desc sampling, mutual-NN match'
+                                % (P, 2 * P)) if c5 else
+                               'BASELINE configs[2]: %d pairs (=%d images) 480x640 per GPU, full path: fp32 '
                                'encoder+heads, box-NMS size 4 + top-k 1000, bilinear desc sampling, mutual-NN match'
                                % (P, 2 * P) if not args.forward_only else
                                'BASELINE configs[1]: %d pairs 480x640 per GPU, forward only' % P,
-                   'pairs_per_gpu': P, 'height': H, 'width': W, 'topk': PRED_CFG['topk'], 'nms': PRED_CFG['nms'],
+                   'pairs_per_gpu': P, 'height': H, 'width': W, 'topk': PRED['topk'], 'nms': PRED['nms'],
                    'weights': 'seeded synthetic state_dict (reference key layout)', 'parallelism': 'dp%d' % world},
         'roofline': roof,
-        'conv_mfma_frac_whole_path': round(value / world * gflop_pair / 1e3 / PEAK_FP32_MFMA_TFLOPS, 4),
+        'conv_mfma_frac_whole_path': round(value / world * gflop_pair / 1e3 / peak, 4),
         'forward_tflops': round(conv_flop / (conv_ms * 1e-3) / 1e12, 2) if conv_ms > 0 else None,
         'layer_ms': layers,
     }
@@ -215,7 +244,7 @@ def main():
                                'mean_kp_thermal': float(metrics[:, 2].mean()),
                                'mean_matches': float(metrics[:, 3].mean())}
     if world == 1 and not args.no_cpu_baseline:
-        cb, cres = cpu_baseline(sd, cfg)
+        cb, cres = cpu_baseline(sd, cfg, 2 if c5 else 16, H, W, PRED)
         out['cpu_baseline'] = cb
         if not args.forward_only:
             # parity in the same run: GPU vs CPU descriptors on the keypoints both found
