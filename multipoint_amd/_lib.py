@@ -10,7 +10,8 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmultipoint_hip.so')
+# MP_LIB selects another build of the library (developer tools: the -DMP_TIMING instrumented variant)
+LIB_PATH = os.environ.get('MP_LIB') or os.path.join(_HERE, 'libmultipoint_hip.so')
 
 MP_OK = 0
 c_void_p, c_int, c_float, c_ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong

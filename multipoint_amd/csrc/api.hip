@@ -61,6 +61,7 @@ struct mp_handle {
     DevBuf nms_state;               // 64 round counters + tile flags
     int* nms_total = nullptr;       // device: undecided candidates summed over all calls since the last read
     int last_nms_rounds = 0;
+    void* dummy = nullptr;          // scratch line for masked-off store lanes of the fp16 kernels
     bool fuse_first = true;         // fuse the Cin=1 block into the second convolution (MP_NO_FUSE=1 disables)
     int* pinned = nullptr;          // small pinned host scratch (img lists, counters)
     bool prof = false;
@@ -428,6 +429,7 @@ void run_conv_h(mp_handle* h, const ConvLayer& L, const _Float16* in, int in_cst
     p.nslices = L.nslices;
     p.pad_zero = h->cfg.reflection_pad ? 0 : 1;
     p.bn_first = h->cfg.bn_first;
+    p.dummy = static_cast<_Float16*>(h->dummy);
     int mbw = 32;
     if (L.taps == 9) {
         mbw = pick_mbw(H, W);
@@ -452,6 +454,7 @@ int forward_f16(mp_handle* h, const float* images, int B, int H, int W, int nset
     // same carve-up as the fp32 path (sizes in elements), element type fp16
     const size_t nP = (size_t)B * H * W * 64, nQ = (size_t)B * H * W * 16;
     const size_t nL = (size_t)npx * 128, nD = (size_t)npx * 128, nR = (size_t)npx * 256;
+    if (!h->dummy) MP_HIP(hipMalloc(&h->dummy, 4096));
     _Float16* P = static_cast<_Float16*>(h->ws.p);
     _Float16* Q = P + nP;
     _Float16* Lg = Q + nQ;
@@ -618,6 +621,7 @@ void mp_destroy(mp_handle* h)
     if (h->ws3.p) (void)hipFree(h->ws3.p);
     if (h->nms_state.p) (void)hipFree(h->nms_state.p);
     if (h->nms_total) (void)hipFree(h->nms_total);
+    if (h->dummy) (void)hipFree(h->dummy);
     if (h->pinned) (void)hipHostFree(h->pinned);
     for (auto& e : h->prof_entries) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     delete h;

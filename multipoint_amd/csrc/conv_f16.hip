@@ -11,6 +11,23 @@
 #include "mp_common.h"
 
 #include <algorithm>
+#include <type_traits>
+
+#ifdef MP_TIMING
+// developer instrumentation: per-workgroup cycle sums per phase (wave 0), see tools/conv_timing_f16.py
+__device__ unsigned long long g_timing_h[512 * 8];
+__device__ int g_timing_h_sel = 1024;       // only launches whose input height matches are recorded
+extern "C" int mp_debug_select_height_f16(int h) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_timing_h_sel), &h, sizeof(int)); }
+extern "C" int mp_debug_read_timing_f16(unsigned long long* host, int n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_timing_h), sizeof(unsigned long long) * n);
+}
+#define MPH_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define MPH_ADD(slot, a, b) do { tsum[slot] += (b) - (a); } while (0)      // wave-uniform register accumulators
+#else
+#define MPH_T(var) do { } while (0)
+#define MPH_ADD(slot, a, b) do { } while (0)
+#endif
 
 namespace {
 
@@ -59,6 +76,24 @@ __device__ __forceinline__ float act_h(float acc, float bias, float scale, float
     return v;
 }
 
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// the same on a pair, written so that hipcc emits packed instructions (v_pk_add_f32, v_cvt_pk_f16_f32,
+// v_pk_max_f16, v_pk_fma_f32): ReLU commutes with the rounding, so it runs on the packed halves
+template <bool RELU, bool BNF>
+__device__ __forceinline__ h2 act_h2(float a0, float a1, f32x2 bias, f32x2 scale, f32x2 shift)
+{
+    const f32x2 x = f32x2{a0, a1} + bias;
+    h2 h = __builtin_convertvector(x, h2);
+    const h2 zero = {0, 0};
+    if (RELU && !BNF) h = __builtin_elementwise_max(h, zero);
+    const f32x2 y = __builtin_convertvector(h, f32x2) * scale + shift;
+    h2 o = __builtin_convertvector(y, h2);
+    if (RELU && BNF) o = __builtin_elementwise_max(o, zero);
+    return o;
+}
+
 template <int TAPS, int MBW, bool POOL, bool BNF>
 __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvParamsH p)
 {
@@ -66,6 +101,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvParamsH p)
     constexpr bool RELU = (TAPS == 9);
     constexpr bool SWAP = !POOL;      // weights as the MFMA A operand -> lane = pixel, register quad = 4 channels
     __shared__ __attribute__((aligned(16))) _Float16 lds[G::NPIX * PSH];
+    // bias | BN scale | BN shift of the current 64-channel slice: fetched from global memory only when the slice
+    // changes (a global load in every epilogue costs its L2 latency per item)
+    __shared__ __attribute__((aligned(16))) float prm[3 * 64];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -73,84 +111,107 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvParamsH p)
     const int half = lane >> 5;
     const int li = lane & 31;
 
-    int logical;
-    {
-        const int nblk = gridDim.x, bid = blockIdx.x;
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, pos = bid >> 3;
-        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
-    }
+    // ---- persistent workgroup: walks work items (tile, slice) of its XCD's contiguous eighth of the item space,
+    //      gridDim.x/8 items apart, and fetches the NEXT item's activation tile while multiplying the current one
+    //      (an fp16 tile is only ~4.6 k cycles of MFMA: without the prefetch the HBM latency of every tile is exposed)
+    const int per_xcd = (p.nitems + 7) >> 3;
+    const int stride = gridDim.x >> 3;                     // gridDim.x is a multiple of 8
+    const int xcd = blockIdx.x & 7;
+    const int item_end = min((xcd + 1) * per_xcd, p.nitems);
+    int item = xcd * per_xcd + (blockIdx.x >> 3);
+
     auto udiv = [](unsigned n, unsigned magic, unsigned d) -> unsigned { return d == 1 ? n : __umulhi(n, magic); };
-    const int tile = (int)udiv((unsigned)logical, p.magic_slices, (unsigned)p.nslices);
-    const int slice = logical - tile * p.nslices;
-
-    int img = 0, y0 = 0, x0 = 0;
-    long long px0 = 0;
-    const _Float16* in_base;
-    if constexpr (TAPS == 9) {
-        const int trow = (int)udiv((unsigned)tile, p.magic_tx, (unsigned)p.tiles_x);
-        const int tx = tile - trow * p.tiles_x;
-        const int bi = (int)udiv((unsigned)trow, p.magic_ty, (unsigned)p.tiles_y);
-        const int ty = trow - bi * p.tiles_y;
-        img = p.img_list ? p.img_list[bi] : bi;
-        y0 = ty * G::TH; x0 = tx * G::TW;
-        in_base = p.in + (long long)img * p.H * p.W * p.in_cstride + p.in_coff;
-    } else {
-        px0 = (long long)tile * 256;
-        in_base = p.in + px0 * p.in_cstride + p.in_coff;
-    }
-
-    // per-thread staging offsets in halfs from in_base (-1: padding slot, zero-filled at the LDS write)
-    int goff[G::NITER];
-#pragma unroll
-    for (int j = 0; j < G::NITER; ++j) {
-        const int f = tid + j * 256;
-        const int lp = f >> 3, c8 = f & 7;
-        int off = -1;
-        if (f < G::NV) {
-            if constexpr (TAPS == 9) {
-                const int ly = lp / G::LW, lx = lp - ly * G::LW;
-                int gy = y0 + ly - 1, gx = x0 + lx - 1;
-                bool zero = false;
-                if (p.pad_zero) {
-                    zero = (gy < 0) | (gy >= p.H) | (gx < 0) | (gx >= p.W);
-                    gy = min(max(gy, 0), p.H - 1); gx = min(max(gx, 0), p.W - 1);
-                } else {
-                    gy = reflect_clamp_h(gy, p.H); gx = reflect_clamp_h(gx, p.W);
-                }
-                if (!zero) off = (gy * p.W + gx) * p.in_cstride + c8 * 8;
-            } else {
-                if (px0 + lp < p.total_px) off = lp * p.in_cstride + c8 * 8;
-            }
+    struct Where { int slice, img, y0, x0; long long px0; const _Float16* in_base; };
+    auto decode = [&](int it) __attribute__((always_inline)) -> Where {
+        Where w{};
+        const int tile = (int)udiv((unsigned)it, p.magic_slices, (unsigned)p.nslices);
+        w.slice = it - tile * p.nslices;
+        if constexpr (TAPS == 9) {
+            const int trow = (int)udiv((unsigned)tile, p.magic_tx, (unsigned)p.tiles_x);
+            const int tx = tile - trow * p.tiles_x;
+            const int bi = (int)udiv((unsigned)trow, p.magic_ty, (unsigned)p.tiles_y);
+            const int ty = trow - bi * p.tiles_y;
+            w.img = p.img_list ? p.img_list[bi] : bi;
+            w.y0 = ty * G::TH; w.x0 = tx * G::TW;
+            w.in_base = p.in + (long long)w.img * p.H * p.W * p.in_cstride + p.in_coff;
+        } else {
+            w.px0 = (long long)tile * 256;
+            w.in_base = p.in + w.px0 * p.in_cstride + p.in_coff;
         }
-        goff[j] = off;
-    }
+        return w;
+    };
+    // per-thread staging offsets in halfs.  Interior items (every halo pixel inside the image; all pixels valid in
+    // flat mode): offsets relative to the item's first halo pixel, IDENTICAL for every such item, so they are
+    // computed once and only the wave-uniform base pointer moves (no VALU per item: a wave that is not streaming
+    // MFMAs issues its vector instructions very slowly next to one that is).  Boundary items: absolute offsets from
+    // in_base with -1 marking padding slots that are zero-filled at the LDS write.
+    int goff[G::NITER];
+    bool goff_rel = false;          // goff currently holds the item-invariant relative offsets
+    bool cur_pad = false;           // the LDS image being written has padding slots
+    auto is_interior = [&](const Where& w) __attribute__((always_inline)) -> bool {
+        if constexpr (TAPS == 9) return (w.y0 >= 1) && (w.y0 + G::TH < p.H) && (w.x0 >= 1) && (w.x0 + G::TW < p.W);
+        else return w.px0 + 256 <= p.total_px;
+    };
+    // returns the base pointer the staging loads of item w add goff to
+    auto offsets = [&](const Where& w) __attribute__((always_inline)) -> const _Float16* {
+        if (is_interior(w)) {
+            if (!goff_rel) {
+#pragma unroll
+                for (int j = 0; j < G::NITER; ++j) {
+                    const int f = tid + j * 256;
+                    const int lp = f >> 3;
+                    int off = 0;
+                    if (f < G::NV) {
+                        if constexpr (TAPS == 9) {
+                            const int ly = lp / G::LW, lx = lp - ly * G::LW;
+                            off = (ly * p.W + lx) * p.in_cstride + (f & 7) * 8;
+                        } else {
+                            off = lp * p.in_cstride + (f & 7) * 8;
+                        }
+                    }
+                    goff[j] = off;
+                }
+                goff_rel = true;
+            }
+            if constexpr (TAPS == 9) return w.in_base + (long long)((w.y0 - 1) * p.W + (w.x0 - 1)) * p.in_cstride;
+            else return w.in_base;
+        }
+        goff_rel = false;
+#pragma unroll
+        for (int j = 0; j < G::NITER; ++j) {
+            const int f = tid + j * 256;
+            const int lp = f >> 3, c8 = f & 7;
+            int off = -1;
+            if (f < G::NV) {
+                if constexpr (TAPS == 9) {
+                    const int ly = lp / G::LW, lx = lp - ly * G::LW;
+                    int gy = w.y0 + ly - 1, gx = w.x0 + lx - 1;
+                    bool zero = false;
+                    if (p.pad_zero) {
+                        zero = (gy < 0) | (gy >= p.H) | (gx < 0) | (gx >= p.W);
+                        gy = min(max(gy, 0), p.H - 1); gx = min(max(gx, 0), p.W - 1);
+                    } else {
+                        gy = reflect_clamp_h(gy, p.H); gx = reflect_clamp_h(gx, p.W);
+                    }
+                    if (!zero) off = (gy * p.W + gx) * p.in_cstride + c8 * 8;
+                } else {
+                    if (w.px0 + lp < p.total_px) off = lp * p.in_cstride + c8 * 8;
+                }
+            }
+            goff[j] = off;
+        }
+        return w.in_base;
+    };
 
     const int a_base = (((2 * wave) * G::MBH + li / MBW) * G::LW + (li % MBW)) * PSH + half * 8;
     constexpr int A_MB = G::MBH * G::LW * PSH;
-
     const int nchunks = p.cin / CKH;
-    // B fragments: [slice][chunk][step][nb][lane][8 halfs]
-    const h8* wp = reinterpret_cast<const h8*>(p.wpack) + ((long long)slice * nchunks) * (G::STEPS * 128) + lane;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     constexpr int RB = (G::STEPS % 6 == 0) ? 6 : 4;      // weight ring (divides STEPS: stays aligned across chunks)
     constexpr int PF = RB - 1;                           // steps of weight prefetch
     constexpr int RA = 3;                                // activation-fragment ring (restarted per chunk)
     static_assert(G::STEPS % RB == 0, "weight ring must stay aligned across chunks");
     h8 af[RA][2], bf[RB][2], stg[G::NITER];
-#pragma unroll
-    for (int s = 0; s < PF; ++s) { bf[s][0] = wp[s * 128]; bf[s][1] = wp[s * 128 + 64]; }
-#pragma unroll
-    for (int j = 0; j < G::NITER; ++j)
-        stg[j] = *reinterpret_cast<const h8*>(in_base + (goff[j] >= 0 ? goff[j] : 0));
-
     constexpr int S0 = (TAPS == 9) ? 4 : 0;               // first step that issues a staging load
     constexpr int PER_STEP = (TAPS == 9) ? 1 : 2;
     auto a_off = [](int s) -> int {
@@ -163,136 +224,259 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvParamsH p)
                     : __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, cc, 0, 0, 0);
     };
 
-    for (int c = 0; c < nchunks; ++c) {
-        if (c > 0) __syncthreads();                        // chunk c-1 fully consumed
+    if (item >= item_end) return;
+    Where cur = decode(item);
+    const _Float16* src = offsets(cur);                    // staging base of the item being loaded
+    cur_pad = !goff_rel;
 #pragma unroll
-        for (int j = 0; j < G::NITER; ++j) {
-            const int f = tid + j * 256;
-            if (f < G::NV) {
-                h8 v = stg[j];
-                if (goff[j] < 0) v = h8{0, 0, 0, 0, 0, 0, 0, 0};
-                *reinterpret_cast<h8*>(&lds[(f >> 3) * PSH + (f & 7) * 8]) = v;
-            }
-        }
-        __syncthreads();
+    for (int j = 0; j < G::NITER; ++j)
+        stg[j] = *reinterpret_cast<const h8*>(src + (goff[j] >= 0 ? goff[j] : 0));
 
-        const h8* wc = wp + (long long)c * (G::STEPS * 128);
-        const bool more = c + 1 < nchunks;
-        const _Float16* in_next = in_base + (more ? (c + 1) * CKH : 0);   // dummy (re-reads chunk 0) on the last chunk
+    auto lds_write = [&]() __attribute__((always_inline)) {
+        if (!cur_pad) {
 #pragma unroll
-        for (int s = 0; s < RA - 1; ++s) {
-            af[s][0] = *reinterpret_cast<const h8*>(&lds[a_base + a_off(s)]);
-            af[s][1] = *reinterpret_cast<const h8*>(&lds[a_base + A_MB + a_off(s)]);
-        }
-#pragma unroll
-        for (int s = 0; s < G::STEPS; ++s) {
-            bf[(s + PF) % RB][0] = wc[(s + PF) * 128];
-            bf[(s + PF) % RB][1] = wc[(s + PF) * 128 + 64];
-            if (s + RA - 1 < G::STEPS) {
-                const int sn = s + RA - 1;
-                af[sn % RA][0] = *reinterpret_cast<const h8*>(&lds[a_base + a_off(sn)]);
-                af[sn % RA][1] = *reinterpret_cast<const h8*>(&lds[a_base + A_MB + a_off(sn)]);
-            }
-#pragma unroll
-            for (int u = 0; u < PER_STEP; ++u) {
-                const int j = (s - S0) * PER_STEP + u;
-                if (s >= S0 && j < G::NITER)      // unconditional load: keeps the compiler's vmcnt counting exact
-                    stg[j] = *reinterpret_cast<const h8*>(in_next + (goff[j] >= 0 ? goff[j] : 0));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            acc[0][0] = mma(af[s % RA][0], bf[s % RB][0], acc[0][0]);
-            acc[0][1] = mma(af[s % RA][0], bf[s % RB][1], acc[0][1]);
-            acc[1][0] = mma(af[s % RA][1], bf[s % RB][0], acc[1][0]);
-            acc[1][1] = mma(af[s % RA][1], bf[s % RB][1], acc[1][1]);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    }
-
-    // ---------------- epilogue ----------------
-    if constexpr (POOL) {
-        // lane = channel (li), register r = pixel (r&3) + 8*(r>>2) + 4*half of the M-block
-        float bia[2], scl[2], sft[2];
-        int ch[2];
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
-            ch[nb] = slice * 64 + nb * 32 + li;
-            bia[nb] = p.bias[ch[nb]]; scl[nb] = p.scale[ch[nb]]; sft[nb] = p.shift[ch[nb]];
-        }
-        const int Ho = p.H >> 1, Wo = p.W >> 1;
-        auto pooled = [&](float a, float b, float c, float d, int nb) -> _Float16 {
-            const float v = fmaxf(fmaxf(act_h<RELU, BNF>(a, bia[nb], scl[nb], sft[nb]), act_h<RELU, BNF>(b, bia[nb], scl[nb], sft[nb])),
-                                  fmaxf(act_h<RELU, BNF>(c, bia[nb], scl[nb], sft[nb]), act_h<RELU, BNF>(d, bia[nb], scl[nb], sft[nb])));
-            return (_Float16)v;
-        };
-        if constexpr (MBW == 32) {
-#pragma unroll
-            for (int r = 0; r < 16; r += 2) {
-                const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-                const int oy = (y0 + 2 * wave) >> 1, ox = (x0 + i) >> 1;
-                if (oy < Ho && ox < Wo) {
-                    const long long o = (((long long)img * Ho + oy) * Wo + ox) * p.out_cstride + p.out_coff;
-#pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
-                        if (ch[nb] < p.cout)
-                            p.out[o + ch[nb]] = pooled(acc[0][nb][r], acc[0][nb][r + 1], acc[1][nb][r], acc[1][nb][r + 1], nb);
-                }
+            for (int j = 0; j < G::NITER; ++j) {
+                const int f = tid + j * 256;
+                if (f < G::NV) *reinterpret_cast<h8*>(&lds[(f >> 3) * PSH + (f & 7) * 8]) = stg[j];
             }
         } else {
-            constexpr int RDOWN = (MBW == 16) ? 8 : 4;
 #pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int r = 0; r < 16; r += 2) {
-                    if ((r & RDOWN) != 0) continue;
-                    const int i = (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const int oy = (y0 + (2 * wave + mb) * G::MBH + i / MBW) >> 1;
-                    const int ox = (x0 + i % MBW) >> 1;
-                    if (oy < Ho && ox < Wo) {
-                        const long long o = (((long long)img * Ho + oy) * Wo + ox) * p.out_cstride + p.out_coff;
-#pragma unroll
-                        for (int nb = 0; nb < 2; ++nb)
-                            if (ch[nb] < p.cout)
-                                p.out[o + ch[nb]] = pooled(acc[mb][nb][r], acc[mb][nb][r + 1], acc[mb][nb][r + RDOWN],
-                                                           acc[mb][nb][r + RDOWN + 1], nb);
-                    }
+            for (int j = 0; j < G::NITER; ++j) {
+                const int f = tid + j * 256;
+                if (f < G::NV) {
+                    h8 v = stg[j];
+                    if (goff[j] < 0) v = h8{0, 0, 0, 0, 0, 0, 0, 0};
+                    *reinterpret_cast<h8*>(&lds[(f >> 3) * PSH + (f & 7) * 8]) = v;
                 }
-        }
-        return;
-    }
-    // non-pooled: lane = pixel, register r = channel (r&3) + 8*(r>>2) + 4*half of the N-block -> 8-byte stores
-    auto store4 = [&](_Float16* dst, int ch0, const h4& v) {
-        if (ch0 + 3 < p.cout) {
-            *reinterpret_cast<h4*>(dst + ch0) = v;
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (ch0 + e < p.cout) dst[ch0 + e] = v[e];
+            }
         }
     };
-#pragma unroll
-    for (int nb = 0; nb < 2; ++nb)
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-            const int ch0 = slice * 64 + nb * 32 + rg * 8 + half * 4;
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(p.bias + ch0);
-            const f32x4 s4 = *reinterpret_cast<const f32x4*>(p.scale + ch0);
-            const f32x4 t4 = *reinterpret_cast<const f32x4*>(p.shift + ch0);
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb) {
-                h4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = (_Float16)act_h<RELU, BNF>(acc[mb][nb][rg * 4 + e], b4[e], s4[e], t4[e]);
-                if constexpr (TAPS == 1) {
-                    const long long gp = px0 + (2 * wave + mb) * 32 + li;
-                    if (gp < p.total_px) store4(p.out + gp * p.out_cstride + p.out_coff, ch0, v);
-                } else {
-                    const int oy = y0 + (2 * wave + mb) * G::MBH + li / MBW;
-                    const int ox = x0 + li % MBW;
-                    if (oy < p.H && ox < p.W)
-                        store4(p.out + (((long long)img * p.H + oy) * p.W + ox) * p.out_cstride + p.out_coff, ch0, v);
-                }
-            }
+    lds_write();
+    auto load_prm = [&](int slice) __attribute__((always_inline)) {
+        if (tid < 64) {
+            prm[tid] = p.bias[slice * 64 + tid]; prm[64 + tid] = p.scale[slice * 64 + tid]; prm[128 + tid] = p.shift[slice * 64 + tid];
         }
+    };
+    load_prm(cur.slice);
+    // weights: [slice][chunk][step][nb][lane][8 halfs]; ONE linear stream per item, and the tail of an item's
+    // prefetch already reads the head of the next item's stream, so it is never restarted after this point
+    const h8* wp = reinterpret_cast<const h8*>(p.wpack) + ((long long)cur.slice * nchunks) * (G::STEPS * 128) + lane;
+#pragma unroll
+    for (int s = 0; s < PF; ++s) { bf[s][0] = wp[s * 128]; bf[s][1] = wp[s * 128 + 64]; }
+    __syncthreads();
+
+#ifdef MP_TIMING
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool t_on = (p.H == g_timing_h_sel);      // read once: a global load inside the loop would add a vmcnt(0) wait
+#endif
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (;;) {
+        MPH_T(t_item);
+        f32x16 acc[2][2];      // not zero-initialised: the first MFMAs of the item take a literal-zero C operand
+        const int item_next = item + stride;
+        const bool has_next = item_next < item_end;
+        Where nxt = cur;
+        const h8* wnext = wp;
+        const _Float16* cur_src = src;
+        bool nxt_pad = cur_pad;
+
+        auto chunk_body = [&](const int c, auto first_tag) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            // source of the staging loads issued during this chunk: the next chunk of this item, or chunk 0 of the
+            // next item (whose offsets replace goff: the LDS image of the current chunk is already written)
+            const bool last = c + 1 == nchunks;
+            const _Float16* in_next;
+            if (!last) {
+                in_next = cur_src + (c + 1) * CKH;
+            } else {
+                if (has_next) {
+                    nxt = decode(item_next);
+                    src = offsets(nxt);
+                    nxt_pad = !goff_rel;
+                    wnext = reinterpret_cast<const h8*>(p.wpack) + ((long long)nxt.slice * nchunks) * (G::STEPS * 128) + lane;
+                }
+                in_next = src;                                  // !has_next: dummy re-read of the current tile
+            }
+            const h8* wc = wp + (long long)c * (G::STEPS * 128);
+            const h8* wt = last ? wnext : wc + G::STEPS * 128;   // where the prefetch continues after this chunk
+            MPH_T(t_steps0);
+            if (c == 0) MPH_ADD(0, t_item, t_steps0);          // item start -> first step (decode, offsets)
+#pragma unroll
+            for (int s = 0; s < RA - 1; ++s) {
+                af[s][0] = *reinterpret_cast<const h8*>(&lds[a_base + a_off(s)]);
+                af[s][1] = *reinterpret_cast<const h8*>(&lds[a_base + A_MB + a_off(s)]);
+            }
+#pragma unroll
+            for (int s = 0; s < G::STEPS; ++s) {
+                if (s + PF < G::STEPS) {
+                    bf[(s + PF) % RB][0] = wc[(s + PF) * 128];
+                    bf[(s + PF) % RB][1] = wc[(s + PF) * 128 + 64];
+                } else {
+                    bf[(s + PF) % RB][0] = wt[(s + PF - G::STEPS) * 128];
+                    bf[(s + PF) % RB][1] = wt[(s + PF - G::STEPS) * 128 + 64];
+                }
+                if (s + RA - 1 < G::STEPS) {
+                    const int sn = s + RA - 1;
+                    af[sn % RA][0] = *reinterpret_cast<const h8*>(&lds[a_base + a_off(sn)]);
+                    af[sn % RA][1] = *reinterpret_cast<const h8*>(&lds[a_base + A_MB + a_off(sn)]);
+                }
+#pragma unroll
+                for (int u = 0; u < PER_STEP; ++u) {
+                    const int j = (s - S0) * PER_STEP + u;
+                    if (s >= S0 && j < G::NITER)      // unconditional load: keeps the compiler's vmcnt counting exact
+                        stg[j] = *reinterpret_cast<const h8*>(in_next + (goff[j] >= 0 ? goff[j] : 0));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0][0] = mma(af[s % RA][0], bf[s % RB][0], (FIRST && s == 0) ? zero16 : acc[0][0]);
+                acc[0][1] = mma(af[s % RA][0], bf[s % RB][1], (FIRST && s == 0) ? zero16 : acc[0][1]);
+                acc[1][0] = mma(af[s % RA][1], bf[s % RB][0], (FIRST && s == 0) ? zero16 : acc[1][0]);
+                acc[1][1] = mma(af[s % RA][1], bf[s % RB][1], (FIRST && s == 0) ? zero16 : acc[1][1]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            MPH_T(t_steps1);
+            MPH_ADD(1, t_steps0, t_steps1);                    // the MFMA steps of a chunk
+            __syncthreads();                                   // this chunk's LDS image fully consumed
+            MPH_T(t_bar);
+            MPH_ADD(2, t_steps1, t_bar);                       // barrier skew
+            if (last) cur_pad = nxt_pad;
+            if (!last || has_next) lds_write();                // staged registers are free again before the epilogue
+            MPH_T(t_ldsw);
+            MPH_ADD(3, t_bar, t_ldsw);                         // staging data landed + LDS write
+            if (!last) __syncthreads();
+        };
+        chunk_body(0, std::true_type{});
+        for (int c = 1; c < nchunks; ++c) chunk_body(c, std::false_type{});
+        MPH_T(t_epi0);
+
+        // ---------------- epilogue of item `cur` ----------------
+        const int slice = cur.slice, img = cur.img, y0 = cur.y0, x0 = cur.x0;
+        const long long px0 = cur.px0;
+        // Addressing: wave-uniform 64-bit base (scalar unit) + one per-lane 32-bit offset computed once per item + uniform
+        // per-store increments.  `full` items (tile entirely inside the output) store unconditionally; partial tiles
+        // send masked lanes to a dummy line so that BOTH paths issue the same number of stores and hipcc's vmcnt
+        // counting stays exact (a guarded store would make the next item's first operand wait cover every store).
+        if constexpr (POOL) {
+            // lane = channel (li), register r = pixel (r&3) + 8*(r>>2) + 4*half of the M-block; registers r, r+1
+            // are horizontally adjacent pixels -> one packed pair
+            f32x2 bia[2], scl[2], sft[2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const float b = prm[nb * 32 + li], sc = prm[64 + nb * 32 + li], sh = prm[128 + nb * 32 + li];
+                bia[nb] = f32x2{b, b}; scl[nb] = f32x2{sc, sc}; sft[nb] = f32x2{sh, sh};
+            }
+            const int Ho = p.H >> 1, Wo = p.W >> 1;
+            const int cs = p.out_cstride;
+            auto pooled = [&](float a0, float a1, float b0, float b1, int nb) __attribute__((always_inline)) -> _Float16 {
+                const h2 m = __builtin_elementwise_max(act_h2<RELU, BNF>(a0, a1, bia[nb], scl[nb], sft[nb]),
+                                                       act_h2<RELU, BNF>(b0, b1, bia[nb], scl[nb], sft[nb]));
+                return m[0] > m[1] ? m[0] : m[1];
+            };
+            const bool full = (y0 + G::TH <= p.H) && (x0 + G::TW <= p.W) && (slice * 64 + 64 <= p.cout);
+            const int lane_off = 2 * half * cs + li;
+            _Float16* const obase = p.out + ((long long)img * Ho * Wo) * cs + p.out_coff + slice * 64;
+            // MBW == 32: rows 2*wave (mb 0) and 2*wave+1 (mb 1) pool together; otherwise both rows of a window are
+            // registers r and r+RDOWN of one M-block
+            constexpr int RDOWN = (MBW == 32) ? 0 : (MBW == 16) ? 8 : 4;
+            constexpr int NMB = (MBW == 32) ? 1 : 2;
+            auto store_all = [&](auto full_tag) __attribute__((always_inline)) {
+                constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+                for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        if (RDOWN != 0 && (r & RDOWN) != 0) continue;
+                        const int iu = (r & 3) + 8 * (r >> 2);                       // lane-independent part of the pixel index
+                        const int oy = (MBW == 32) ? (y0 + 2 * wave) >> 1 : (y0 + (2 * wave + mb) * G::MBH + iu / MBW) >> 1;
+                        const int oxu = (x0 + iu % MBW) >> 1;                        // + 2*half per lane
+                        _Float16* const rowp = obase + ((long long)oy * Wo + oxu) * cs;
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) {
+                            const _Float16 v = (MBW == 32)
+                                ? pooled(acc[0][nb][r], acc[0][nb][r + 1], acc[1][nb][r], acc[1][nb][r + 1], nb)
+                                : pooled(acc[mb][nb][r], acc[mb][nb][r + 1], acc[mb][nb][r + RDOWN], acc[mb][nb][r + RDOWN + 1], nb);
+                            if constexpr (FULL) {
+                                rowp[nb * 32 + lane_off] = v;
+                            } else {
+                                const bool ok = (oy < Ho) & (oxu + 2 * half < Wo) & (slice * 64 + nb * 32 + li < p.cout);
+                                _Float16* dst = ok ? rowp + nb * 32 + lane_off : p.dummy + lane;
+                                *dst = v;
+                            }
+                        }
+                    }
+            };
+            if (full) store_all(std::true_type{}); else store_all(std::false_type{});
+        } else {
+            // non-pooled: lane = pixel, register r = channel (r&3) + 8*(r>>2) + 4*half of the N-block -> 8-byte stores
+            const int cs = p.out_cstride;
+            int lane_off;
+            _Float16* obase;
+            bool full;
+            if constexpr (TAPS == 1) {
+                lane_off = li * cs + half * 4;
+                obase = p.out + px0 * cs + p.out_coff + slice * 64;
+                full = (px0 + 256 <= p.total_px) && (slice * 64 + 64 <= p.cout);
+            } else {
+                lane_off = ((li / MBW) * p.W + li % MBW) * cs + half * 4;
+                obase = p.out + (((long long)img * p.H + y0) * p.W + x0) * cs + p.out_coff + slice * 64;
+                full = (y0 + G::TH <= p.H) && (x0 + G::TW <= p.W) && (slice * 64 + 64 <= p.cout);
+            }
+            auto store_all = [&](auto full_tag) __attribute__((always_inline)) {
+                constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int cl = nb * 32 + rg * 8 + half * 4;
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(&prm[cl]);
+                        const f32x4 s4 = *reinterpret_cast<const f32x4*>(&prm[64 + cl]);
+                        const f32x4 t4 = *reinterpret_cast<const f32x4*>(&prm[128 + cl]);
+#pragma unroll
+                        for (int mb = 0; mb < 2; ++mb) {
+                            const h2 lo = act_h2<RELU, BNF>(acc[mb][nb][rg * 4], acc[mb][nb][rg * 4 + 1], f32x2{b4[0], b4[1]},
+                                                            f32x2{s4[0], s4[1]}, f32x2{t4[0], t4[1]});
+                            const h2 hi = act_h2<RELU, BNF>(acc[mb][nb][rg * 4 + 2], acc[mb][nb][rg * 4 + 3], f32x2{b4[2], b4[3]},
+                                                            f32x2{s4[2], s4[3]}, f32x2{t4[2], t4[3]});
+                            const h4 v = h4{lo[0], lo[1], hi[0], hi[1]};
+                            // M-block (2*wave+mb): rows (2*wave+mb)*MBH.. of the tile, or 32 consecutive pixels in flat mode
+                            _Float16* const mp = (TAPS == 1) ? obase + (long long)((2 * wave + mb) * 32) * cs
+                                                             : obase + (long long)((2 * wave + mb) * G::MBH) * p.W * cs;
+                            _Float16* const dst = mp + nb * 32 + rg * 8 + lane_off;
+                            if constexpr (FULL) {
+                                *reinterpret_cast<h4*>(dst) = v;
+                            } else {
+                                bool okp;
+                                if constexpr (TAPS == 1) okp = px0 + (2 * wave + mb) * 32 + li < p.total_px;
+                                else okp = (y0 + (2 * wave + mb) * G::MBH + li / MBW < p.H) & (x0 + li % MBW < p.W);
+                                const int ch0 = slice * 64 + cl;
+                                if (ch0 + 3 < p.cout || !okp) {
+                                    *reinterpret_cast<h4*>(okp ? dst : p.dummy + lane * 4) = v;
+                                } else {                     // partial channel quad (cout = 65: the 1x1 detector head only)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e)
+                                        if (ch0 + e < p.cout) dst[e] = v[e];
+                                }
+                            }
+                        }
+                    }
+            };
+            if (full) store_all(std::true_type{}); else store_all(std::false_type{});
+        }
+        MPH_T(t_epi1);
+        MPH_ADD(4, t_epi0, t_epi1);                            // epilogue
+#ifdef MP_TIMING
+        tsum[7] += 1;
+        if (!has_next && tid == 0 && t_on)
+            for (int i = 0; i < 8; ++i) g_timing_h[blockIdx.x * 8 + i] = tsum[i];
+#endif
+        if (!has_next) return;
+        __syncthreads();                                       // next item's LDS image complete, every epilogue done
+        if (nxt.slice != cur.slice) load_prm(nxt.slice);       // (rare) visible to the next epilogue via the post-steps barrier
+        MPH_T(t_bar2);
+        MPH_ADD(5, t_epi1, t_bar2);
+        item = item_next;
+        cur = nxt;
+        wp = wnext;
+    }
 }
 
 template <int TAPS, int MBW, bool POOL>
@@ -301,13 +485,16 @@ void launch_h(const ConvParamsH& p, hipStream_t s)
     long long ntiles;
     if (TAPS == 9) ntiles = (long long)p.B * p.tiles_x * p.tiles_y;
     else ntiles = (p.total_px + 255) / 256;
-    const long long nblk = ntiles * p.nslices;
-    if (nblk <= 0) return;
+    const long long nitems = ntiles * p.nslices;
+    if (nitems <= 0) return;
     ConvParamsH q = p;
     auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ull / (unsigned)d) + 1ull); };
     q.magic_slices = magic(p.nslices); q.magic_tx = magic(p.tiles_x); q.magic_ty = magic(p.tiles_y);
     const long long dmax = std::max(std::max(p.nslices, p.tiles_x), p.tiles_y);
-    if (nblk * dmax >= 0x100000000ll) return;
+    if (nitems * dmax >= 0x100000000ll) return;
+    q.nitems = (int)nitems;
+    // persistent workgroups: two per CU (256 CUs), a multiple of the 8 XCDs
+    const long long nblk = std::min<long long>(512, ((nitems + 7) / 8) * 8);
     const ConvParamsH& pp = q;
     if (p.bn_first)
         hipLaunchKernelGGL((conv_f16_kernel<TAPS, MBW, POOL, true>), dim3((unsigned)nblk), dim3(256), 0, s, pp);

@@ -70,6 +70,8 @@ struct ConvParamsH {
     int pad_zero, bn_first;
     long long total_px;
     unsigned magic_slices, magic_tx, magic_ty;
+    int nitems;           // work items (tile, slice) of the launch (filled in by the launcher)
+    _Float16* dummy;      // >= 1 KiB scratch line that masked-off store lanes write to
 };
 struct Conv1ParamsH {
     const float* in;      // [B][H][W] fp32 image (rounded to fp16 on load)

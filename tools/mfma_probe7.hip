@@ -8,7 +8,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // LOADS: partner issues 2 ds_read_b128 + 2 global_load_dwordx4 per 16 MFMAs and feeds them to the MFMAs
-template <int LOADS, int SEPARATE, int PRIO = 0, int REVERSE = 0>
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+template <int LOADS, int SEPARATE, int PRIO = 0, int REVERSE = 0, int F16 = 0>
 __global__ __launch_bounds__(256, 2) void probe(const float* __restrict__ wsrc, float* out, unsigned long long* cyc,
                                                 int* arrival, int stream_iters)
 {
@@ -49,8 +50,15 @@ __global__ __launch_bounds__(256, 2) void probe(const float* __restrict__ wsrc, 
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t >> 1][kk], bv[t & 1][kk], acc[t], 0, 0, 0);
+                    for (int t = 0; t < 4; ++t) {
+                        if (F16) {
+                            h8v ah, bh;
+                            __builtin_memcpy(&ah, &av[t >> 1], 16); __builtin_memcpy(&bh, &bv[t & 1], 16);
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+                        } else {
+                            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t >> 1][kk], bv[t & 1][kk], acc[t], 0, 0, 0);
+                        }
+                    }
                 if (LOADS) { av[0] = an[0]; av[1] = an[1]; bv[0] = bn[0]; bv[1] = bn[1]; }
             }
         }
@@ -70,11 +78,11 @@ __global__ __launch_bounds__(256, 2) void probe(const float* __restrict__ wsrc, 
     if (x == 123456789) out[tid] = 1.f;
 }
 
-template <int LOADS, int SEPARATE, int PRIO = 0, int REVERSE = 0>
+template <int LOADS, int SEPARATE, int PRIO = 0, int REVERSE = 0, int F16 = 0>
 void run(const float* w, float* out, unsigned long long* cyc, int* arrival, const char* what)
 {
     hipMemset(cyc, 0, 512 * 4 * 8); hipMemset(arrival, 0, 4096 * 4);
-    probe<LOADS, SEPARATE, PRIO, REVERSE><<<512, 256>>>(w, out, cyc, arrival, 2000);
+    probe<LOADS, SEPARATE, PRIO, REVERSE, F16><<<512, 256>>>(w, out, cyc, arrival, 2000);
     hipDeviceSynchronize();
     static unsigned long long h[2048];
     hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
@@ -97,5 +105,7 @@ int main()
     run<0, 1, 2>(w, out, cyc, arrival, "MFMA only, STREAM wave s_setprio 3");
     run<0, 1, 0, 1>(w, out, cyc, arrival, "MFMA only, timed wave is the OLDER workgroup");
     run<1, 1, 0, 1>(w, out, cyc, arrival, "MFMA + loads, timed wave is the OLDER workgroup");
+    run<0, 1, 0, 0, 1>(w, out, cyc, arrival, "f16 MFMA only (32x32x16), partner workgroup");
+    run<1, 1, 0, 0, 1>(w, out, cyc, arrival, "f16 MFMA + loads, partner workgroup");
     return 0;
 }
