@@ -35,6 +35,14 @@ extern "C" int mp_debug_read_timing(unsigned long long* host, int n)
 #else
 #define MP_STAMP(i) do { } while (0)
 #endif
+#ifdef MP_TIMING
+// persistent kernel: wave-uniform per-phase cycle sums, written once per workgroup to g_timing[blockIdx*8 + i]
+#define MPP_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define MPP_ADD(slot, a, b) do { tsum[slot] += (b) - (a); } while (0)
+#else
+#define MPP_T(var) do { } while (0)
+#define MPP_ADD(slot, a, b) do { } while (0)
+#endif
 #if defined(MP_TIMING) && MP_TIMING == 2      // prologue-focused stamps (reuse slots 4..6 of the first chunk)
 #define MP_STAMP_P(i) MP_STAMP(i)
 #else
@@ -483,6 +491,383 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Persistent variant (all non-fused layers with enough work items): two workgroups per CU walk the (tile, slice)
+// items of their XCD's contiguous eighth of the item space.  What it buys over one-workgroup-per-tile:
+//   * the next item's first chunk is fetched during the current item's last chunk, so a tile's HBM/L2 latency and
+//     its whole prologue disappear from the timeline (in the per-tile kernel a wave in its prologue crawls at one
+//     vector instruction per MFMA of its SIMD neighbour: 33-58 k cycles per tile, tools/conv_timing.py);
+//   * interior items share ONE set of item-invariant staging offsets -- only the scalar base pointer moves, i.e.
+//     no per-item vector address arithmetic at all (every VALU instruction costs fp32-MFMA pipe cycles);
+//   * the weight stream runs on from one item into the next, bias/scale/shift sit in LDS, and the staged registers
+//     are written to LDS BEFORE the epilogue, so the epilogue runs with them dead (no extra register pressure).
+// The inner step loop is the per-tile kernel's, unchanged.
+template <int TAPS, int MBW, bool POOL, bool BNF>
+__global__ __launch_bounds__(256, 2) void conv_mfma_persist_kernel(const ConvParams p)
+{
+    using G = Geo<TAPS, MBW>;
+    constexpr bool RELU = (TAPS == 9);
+    constexpr bool SWAP = !POOL;
+    __shared__ __attribute__((aligned(16))) float lds[G::NPIX * PS];
+    __shared__ __attribute__((aligned(16))) float prm[3 * 64];      // bias | scale | shift of the current slice
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5;
+    const int li = lane & 31;
+
+    const int per_xcd = (p.nitems + 7) >> 3;
+    const int stride = gridDim.x >> 3;                     // gridDim.x is a multiple of 8
+    const int xcd = blockIdx.x & 7;
+    const int item_end = min((xcd + 1) * per_xcd, p.nitems);
+    int item = xcd * per_xcd + (blockIdx.x >> 3);
+
+    auto udiv = [](unsigned n, unsigned magic, unsigned d) -> unsigned { return d == 1 ? n : __umulhi(n, magic); };
+    struct Where { int slice, img, y0, x0; long long px0; const float* in_base; };
+    auto decode = [&](int it) __attribute__((always_inline)) -> Where {
+        Where w{};
+        const int tile = (int)udiv((unsigned)it, p.magic_slices, (unsigned)p.nslices);
+        w.slice = it - tile * p.nslices;
+        if constexpr (TAPS == 9) {
+            const int trow = (int)udiv((unsigned)tile, p.magic_tx, (unsigned)p.tiles_x);
+            const int tx = tile - trow * p.tiles_x;
+            const int bi = (int)udiv((unsigned)trow, p.magic_ty, (unsigned)p.tiles_y);
+            const int ty = trow - bi * p.tiles_y;
+            w.img = p.img_list ? p.img_list[bi] : bi;
+            w.y0 = ty * G::TH; w.x0 = tx * G::TW;
+            w.in_base = p.in + (long long)w.img * p.H * p.W * p.in_cstride + p.in_coff;
+        } else {
+            w.px0 = (long long)tile * 256;
+            w.in_base = p.in + w.px0 * p.in_cstride + p.in_coff;
+        }
+        return w;
+    };
+    int goff[G::NITER];
+    bool goff_rel = false;          // goff holds the item-invariant relative offsets of interior items
+    bool cur_pad = false;           // the LDS image being written has padding slots
+    auto is_interior = [&](const Where& w) __attribute__((always_inline)) -> bool {
+        if constexpr (TAPS == 9) return (w.y0 >= 1) && (w.y0 + G::TH < p.H) && (w.x0 >= 1) && (w.x0 + G::TW < p.W);
+        else return w.px0 + 256 <= p.total_px;
+    };
+    auto offsets = [&](const Where& w) __attribute__((always_inline)) -> const float* {
+        if (is_interior(w)) {
+            if (!goff_rel) {
+#pragma unroll
+                for (int j = 0; j < G::NITER; ++j) {
+                    const int f = tid + j * 256;
+                    const int lp = f >> 3;
+                    int off = 0;
+                    if (f < G::NF4) {
+                        if constexpr (TAPS == 9) {
+                            const int ly = lp / G::LW, lx = lp - ly * G::LW;
+                            off = (ly * p.W + lx) * p.in_cstride + (f & 7) * 4;
+                        } else {
+                            off = lp * p.in_cstride + (f & 7) * 4;
+                        }
+                    }
+                    goff[j] = off;
+                }
+                goff_rel = true;
+            }
+            if constexpr (TAPS == 9) return w.in_base + (long long)((w.y0 - 1) * p.W + (w.x0 - 1)) * p.in_cstride;
+            else return w.in_base;
+        }
+        goff_rel = false;
+#pragma unroll
+        for (int j = 0; j < G::NITER; ++j) {
+            const int f = tid + j * 256;
+            const int lp = f >> 3, c4 = f & 7;
+            int off = -1;
+            if (f < G::NF4) {
+                if constexpr (TAPS == 9) {
+                    const int ly = lp / G::LW, lx = lp - ly * G::LW;
+                    int gy = w.y0 + ly - 1, gx = w.x0 + lx - 1;
+                    bool zero = false;
+                    if (p.pad_zero) {
+                        zero = (gy < 0) | (gy >= p.H) | (gx < 0) | (gx >= p.W);
+                        gy = min(max(gy, 0), p.H - 1); gx = min(max(gx, 0), p.W - 1);
+                    } else {
+                        gy = reflect_clamp(gy, p.H); gx = reflect_clamp(gx, p.W);
+                    }
+                    if (!zero) off = (gy * p.W + gx) * p.in_cstride + c4 * 4;
+                } else {
+                    if (w.px0 + lp < p.total_px) off = lp * p.in_cstride + c4 * 4;
+                }
+            }
+            goff[j] = off;
+        }
+        return w.in_base;
+    };
+
+    const int a_base = (((2 * wave) * G::MBH + li / MBW) * G::LW + (li % MBW)) * PS + half * 4;
+    constexpr int A_MB = G::MBH * G::LW * PS;
+    const int nchunks = p.cin / CK;
+    constexpr int RB = (G::STEPS % 3 == 0) ? 3 : 4;
+    static_assert(G::STEPS % RB == 0 && G::STEPS % 2 == 0, "operand rings must stay aligned across chunks");
+    f32x4 af[2][2], bf[RB][2], stg[G::NITER];
+    constexpr int S0 = (TAPS == 9) ? 6 : 0;
+    constexpr int PER_STEP = (TAPS == 9) ? 1 : 2;
+    auto mma = [](float a, float b, const f32x16& cc) -> f32x16 {
+        return SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, cc, 0, 0, 0)
+                    : __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, cc, 0, 0, 0);
+    };
+
+    if (item >= item_end) return;
+    Where cur = decode(item);
+    const float* src = offsets(cur);
+    cur_pad = !goff_rel;
+#pragma unroll
+    for (int j = 0; j < G::NITER; ++j)
+        stg[j] = *reinterpret_cast<const f32x4*>(src + (goff[j] >= 0 ? goff[j] : 0));
+    auto lds_write = [&]() __attribute__((always_inline)) {
+        if (!cur_pad) {
+#pragma unroll
+            for (int j = 0; j < G::NITER; ++j) {
+                const int f = tid + j * 256;
+                if (f < G::NF4) *reinterpret_cast<f32x4*>(&lds[(f >> 3) * PS + (f & 7) * 4]) = stg[j];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < G::NITER; ++j) {
+                const int f = tid + j * 256;
+                if (f < G::NF4)
+                    *reinterpret_cast<f32x4*>(&lds[(f >> 3) * PS + (f & 7) * 4]) =
+                        (goff[j] >= 0) ? stg[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto load_prm = [&](int slice) __attribute__((always_inline)) {
+        if (tid < 64) {
+            prm[tid] = p.bias[slice * 64 + tid]; prm[64 + tid] = p.scale[slice * 64 + tid]; prm[128 + tid] = p.shift[slice * 64 + tid];
+        }
+    };
+    lds_write();
+    load_prm(cur.slice);
+    const f32x4* wp = reinterpret_cast<const f32x4*>(p.wpack) + ((long long)cur.slice * nchunks) * (G::STEPS * 128) + lane;
+    bf[0][0] = wp[0];   bf[0][1] = wp[64];
+    bf[1][0] = wp[128]; bf[1][1] = wp[128 + 64];
+    __syncthreads();
+
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#ifdef MP_TIMING
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool t_on = (p.H == g_timing_h);
+#endif
+    for (;;) {
+        MPP_T(t_item);
+        f32x16 acc[2][2];
+        const int item_next = item + stride;
+        const bool has_next = item_next < item_end;
+        Where nxt = cur;
+        const f32x4* wnext = wp;
+        const float* cur_src = src;
+        bool nxt_pad = cur_pad;
+
+        auto chunk_body = [&](const int c, auto first_tag) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            const bool last = c + 1 == nchunks;
+            const float* in_next;
+            if (!last) {
+                in_next = cur_src + (c + 1) * CK;
+            } else {
+                if (has_next) {
+                    nxt = decode(item_next);
+                    src = offsets(nxt);
+                    nxt_pad = !goff_rel;
+                    wnext = reinterpret_cast<const f32x4*>(p.wpack) + ((long long)nxt.slice * nchunks) * (G::STEPS * 128) + lane;
+                }
+                in_next = src;                                  // !has_next: dummy re-read of the current tile
+            }
+            const f32x4* wc = wp + (long long)c * (G::STEPS * 128);
+            const f32x4* wt = last ? wnext : wc + G::STEPS * 128;      // where the weight prefetch continues
+            MPP_T(t_s0);
+            if (c == 0) MPP_ADD(0, t_item, t_s0);
+            af[0][0] = *reinterpret_cast<const f32x4*>(&lds[a_base]);
+            af[0][1] = *reinterpret_cast<const f32x4*>(&lds[a_base + A_MB]);
+#pragma unroll
+            for (int s = 0; s < G::STEPS; ++s) {
+                if (s + 2 < G::STEPS) {
+                    bf[(s + 2) % RB][0] = wc[(s + 2) * 128];
+                    bf[(s + 2) % RB][1] = wc[(s + 2) * 128 + 64];
+                } else {
+                    bf[(s + 2) % RB][0] = wt[(s + 2 - G::STEPS) * 128];
+                    bf[(s + 2) % RB][1] = wt[(s + 2 - G::STEPS) * 128 + 64];
+                }
+                if (s + 1 < G::STEPS) {
+                    const int sn = s + 1;
+                    const int tap = sn >> 2, gg = sn & 3;
+                    const int kh = (TAPS == 9) ? tap / 3 : 0, kw = (TAPS == 9) ? tap % 3 : 0;
+                    const int aoff = (kh * G::LW + kw) * PS + gg * 8;
+                    af[sn & 1][0] = *reinterpret_cast<const f32x4*>(&lds[a_base + aoff]);
+                    af[sn & 1][1] = *reinterpret_cast<const f32x4*>(&lds[a_base + A_MB + aoff]);
+                }
+#pragma unroll
+                for (int u = 0; u < PER_STEP; ++u) {
+                    const int j = (s - S0) * PER_STEP + u;
+                    if (s >= S0 && j < G::NITER)
+                        stg[j] = *reinterpret_cast<const f32x4*>(in_next + (goff[j] >= 0 ? goff[j] : 0));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[0][0] = mma(af[s & 1][0][e], bf[s % RB][0][e], (FIRST && s == 0 && e == 0) ? zero16 : acc[0][0]);
+                    acc[0][1] = mma(af[s & 1][0][e], bf[s % RB][1][e], (FIRST && s == 0 && e == 0) ? zero16 : acc[0][1]);
+                    acc[1][0] = mma(af[s & 1][1][e], bf[s % RB][0][e], (FIRST && s == 0 && e == 0) ? zero16 : acc[1][0]);
+                    acc[1][1] = mma(af[s & 1][1][e], bf[s % RB][1][e], (FIRST && s == 0 && e == 0) ? zero16 : acc[1][1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            MPP_T(t_s1);
+            MPP_ADD(1, t_s0, t_s1);
+            __syncthreads();                                   // this chunk's LDS image fully consumed
+            MPP_T(t_b);
+            MPP_ADD(2, t_s1, t_b);
+            if (last) cur_pad = nxt_pad;
+            if (!last || has_next) lds_write();                // staged registers are dead again before the epilogue
+            MPP_T(t_w);
+            MPP_ADD(3, t_b, t_w);
+            if (!last) __syncthreads();
+            MPP_T(t_b2);
+            MPP_ADD(6, t_w, t_b2);
+        };
+        chunk_body(0, std::true_type{});
+        for (int c = 1; c < nchunks; ++c) chunk_body(c, std::false_type{});
+
+        MPP_T(t_e0);
+        // ---------------- epilogue of item `cur`: wave-uniform 64-bit base + one per-lane offset ----------------
+        const int slice = cur.slice, img = cur.img, y0 = cur.y0, x0 = cur.x0;
+        const long long px0 = cur.px0;
+        const int cs = p.out_cstride;
+        if constexpr (POOL) {
+            // lane = channel (li), register r = pixel (r&3) + 8*(r>>2) + 4*half of the M-block
+            float bia[2], scl[2], sft[2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) { bia[nb] = prm[nb * 32 + li]; scl[nb] = prm[64 + nb * 32 + li]; sft[nb] = prm[128 + nb * 32 + li]; }
+            auto act = [&](float v, int nb) __attribute__((always_inline)) -> float {
+                v += bia[nb];
+                if (BNF) {
+                    v = v * scl[nb] + sft[nb];
+                    if (RELU) v = relu_f(v);
+                } else {
+                    if (RELU) v = relu_f(v);
+                    v = v * scl[nb] + sft[nb];
+                }
+                return v;
+            };
+            const int Ho = p.H >> 1, Wo = p.W >> 1;
+            const bool full = (y0 + G::TH <= p.H) && (x0 + G::TW <= p.W) && (slice * 64 + 64 <= p.cout);
+            const int lane_off = 2 * half * cs + li;
+            float* const obase = p.out + ((long long)img * Ho * Wo) * cs + p.out_coff + slice * 64;
+            constexpr int RDOWN = (MBW == 32) ? 0 : (MBW == 16) ? 8 : 4;
+            constexpr int NMB = (MBW == 32) ? 1 : 2;
+            auto store_all = [&](auto full_tag) __attribute__((always_inline)) {
+                constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+                for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        if (RDOWN != 0 && (r & RDOWN) != 0) continue;
+                        const int iu = (r & 3) + 8 * (r >> 2);
+                        const int oy = (MBW == 32) ? (y0 + 2 * wave) >> 1 : (y0 + (2 * wave + mb) * G::MBH + iu / MBW) >> 1;
+                        const int oxu = (x0 + iu % MBW) >> 1;
+                        float* const rowp = obase + ((long long)oy * Wo + oxu) * cs;
+#pragma unroll
+                        for (int nb = 0; nb < 2; ++nb) {
+                            const float v = (MBW == 32)
+                                ? max4_f(act(acc[0][nb][r], nb), act(acc[0][nb][r + 1], nb), act(acc[1][nb][r], nb), act(acc[1][nb][r + 1], nb))
+                                : max4_f(act(acc[mb][nb][r], nb), act(acc[mb][nb][r + 1], nb), act(acc[mb][nb][r + RDOWN], nb),
+                                         act(acc[mb][nb][r + RDOWN + 1], nb));
+                            if constexpr (FULL) {
+                                rowp[nb * 32 + lane_off] = v;
+                            } else {
+                                if ((oy < Ho) & (oxu + 2 * half < Wo) & (slice * 64 + nb * 32 + li < p.cout)) rowp[nb * 32 + lane_off] = v;
+                            }
+                        }
+                    }
+            };
+            if (full) store_all(std::true_type{}); else store_all(std::false_type{});
+        } else {
+            int lane_off;
+            float* obase;
+            bool full;
+            if constexpr (TAPS == 1) {
+                lane_off = li * cs + half * 4;
+                obase = p.out + px0 * cs + p.out_coff + slice * 64;
+                full = (px0 + 256 <= p.total_px) && (slice * 64 + 64 <= p.cout);
+            } else {
+                lane_off = ((li / MBW) * p.W + li % MBW) * cs + half * 4;
+                obase = p.out + (((long long)img * p.H + y0) * p.W + x0) * cs + p.out_coff + slice * 64;
+                full = (y0 + G::TH <= p.H) && (x0 + G::TW <= p.W) && (slice * 64 + 64 <= p.cout);
+            }
+            auto store_all = [&](auto full_tag) __attribute__((always_inline)) {
+                constexpr bool FULL = decltype(full_tag)::value;
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                    for (int rg = 0; rg < 4; ++rg) {
+                        const int cl = nb * 32 + rg * 8 + half * 4;
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(&prm[cl]);
+                        const f32x4 s4 = *reinterpret_cast<const f32x4*>(&prm[64 + cl]);
+                        const f32x4 t4 = *reinterpret_cast<const f32x4*>(&prm[128 + cl]);
+#pragma unroll
+                        for (int mb = 0; mb < 2; ++mb) {
+                            f32x4 v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                float x = acc[mb][nb][rg * 4 + e] + b4[e];
+                                if (BNF) {
+                                    x = x * s4[e] + t4[e];
+                                    if (RELU) x = relu_f(x);
+                                } else {
+                                    if (RELU) x = relu_f(x);
+                                    x = x * s4[e] + t4[e];
+                                }
+                                v[e] = x;
+                            }
+                            float* const mp = (TAPS == 1) ? obase + (long long)((2 * wave + mb) * 32) * cs
+                                                          : obase + (long long)((2 * wave + mb) * G::MBH) * p.W * cs;
+                            float* const dst = mp + nb * 32 + rg * 8 + lane_off;
+                            if constexpr (FULL) {
+                                *reinterpret_cast<f32x4*>(dst) = v;
+                            } else {
+                                bool okp;
+                                if constexpr (TAPS == 1) okp = px0 + (2 * wave + mb) * 32 + li < p.total_px;
+                                else okp = (y0 + (2 * wave + mb) * G::MBH + li / MBW < p.H) & (x0 + li % MBW < p.W);
+                                const int ch0 = slice * 64 + cl;
+                                if (okp) {
+                                    if (ch0 + 3 < p.cout) {
+                                        *reinterpret_cast<f32x4*>(dst) = v;
+                                    } else {
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e)
+                                            if (ch0 + e < p.cout) dst[e] = v[e];
+                                    }
+                                }
+                            }
+                        }
+                    }
+            };
+            if (full) store_all(std::true_type{}); else store_all(std::false_type{});
+        }
+        MPP_T(t_e1);
+        MPP_ADD(4, t_e0, t_e1);
+#ifdef MP_TIMING
+        tsum[7] += 1;
+        if (!has_next && tid == 0 && t_on)
+            for (int i = 0; i < 8; ++i) g_timing[blockIdx.x * 8 + i] = tsum[i];
+#endif
+        if (!has_next) return;
+        __syncthreads();                                       // next item's LDS image complete, every epilogue done
+        MPP_T(t_b3);
+        MPP_ADD(5, t_e1, t_b3);
+        if (nxt.slice != cur.slice) load_prm(nxt.slice);       // (rare) visible to the next epilogue via the post-steps barrier
+        item = item_next;
+        cur = nxt;
+        wp = wnext;
+    }
+}
+
 template <int TAPS, int MBW, bool POOL, bool FUSE1>
 void launch_t(const ConvParams& p, hipStream_t s)
 {
@@ -497,7 +882,18 @@ void launch_t(const ConvParams& p, hipStream_t s)
     q.magic_slices = magic(p.nslices); q.magic_tx = magic(p.tiles_x); q.magic_ty = magic(p.tiles_y);
     const long long dmax = std::max(std::max(p.nslices, p.tiles_x), p.tiles_y);
     if (nblk * dmax >= 0x100000000ll) return;          // caller checks hipGetLastError/sizes; unreachable for sane shapes
+    q.nitems = (int)nblk;
     const ConvParams& pp = q;
+    if constexpr (!FUSE1) {
+        // persistent workgroups (two per CU) when every workgroup gets enough items for the tail not to matter
+        if (p.persist && nblk >= 512 * 8) {
+            if (p.bn_first)
+                hipLaunchKernelGGL((conv_mfma_persist_kernel<TAPS, MBW, POOL, true>), dim3(512), dim3(256), 0, s, pp);
+            else
+                hipLaunchKernelGGL((conv_mfma_persist_kernel<TAPS, MBW, POOL, false>), dim3(512), dim3(256), 0, s, pp);
+            return;
+        }
+    }
     if (p.bn_first)
         hipLaunchKernelGGL((conv_mfma_kernel<TAPS, MBW, POOL, FUSE1, true>), dim3((unsigned)nblk), dim3(256), 0, s, pp);
     else
