@@ -20,6 +20,7 @@
 #include "mp_common.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #ifdef MP_TIMING
@@ -503,12 +504,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
 //     are written to LDS BEFORE the epilogue, so the epilogue runs with them dead (no extra register pressure).
 // The inner step loop is the per-tile kernel's, unchanged.
 template <int TAPS, int MBW, bool POOL, bool BNF>
-__global__ __launch_bounds__(256, 2) void conv_mfma_persist_kernel(const ConvParams p)
+__global__ __launch_bounds__(256, 1) void conv_mfma_persist_kernel(const ConvParams p)
 {
     using G = Geo<TAPS, MBW>;
     constexpr bool RELU = (TAPS == 9);
     constexpr bool SWAP = !POOL;
-    __shared__ __attribute__((aligned(16))) float lds[G::NPIX * PS];
+    // ONE workgroup per CU (a second MFMA stream per SIMD only gets in the first one's way), which
+    // leaves room for a double-buffered LDS image: chunk c+1 is written into the other buffer while chunk c is being
+    // multiplied (each staged vector 8 steps after its load was issued), so a chunk boundary is ONE barrier
+    static_assert(TAPS == 9, "the persistent kernel handles the 3x3 layers");
+    constexpr int BUF = G::NPIX * PS;
+    __shared__ __attribute__((aligned(16))) float lds[2 * BUF];
     __shared__ __attribute__((aligned(16))) float prm[3 * 64];      // bias | scale | shift of the current slice
 
     const int tid = threadIdx.x;
@@ -603,11 +609,17 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_persist_kernel(const ConvPar
     const int a_base = (((2 * wave) * G::MBH + li / MBW) * G::LW + (li % MBW)) * PS + half * 4;
     constexpr int A_MB = G::MBH * G::LW * PS;
     const int nchunks = p.cin / CK;
-    constexpr int RB = (G::STEPS % 3 == 0) ? 3 : 4;
+    // Weight prefetch distance.  Vector memory loads return IN ORDER, so the wait for a weight fragment also waits
+    // for every older load -- including the HBM staging loads of the next image issued in between.  With the
+    // per-tile kernel's 2-step distance (2 k cycles) each chunk stalls for the rest of the HBM latency; one
+    // workgroup per CU has the registers for a ring of 9 (8 steps = 8 k cycles ahead).
+    constexpr int RB = 9, PF = 8;
     static_assert(G::STEPS % RB == 0 && G::STEPS % 2 == 0, "operand rings must stay aligned across chunks");
-    f32x4 af[2][2], bf[RB][2], stg[G::NITER];
-    constexpr int S0 = (TAPS == 9) ? 6 : 0;
-    constexpr int PER_STEP = (TAPS == 9) ? 1 : 2;
+    f32x4 af2[3][2], bf[RB][2], stg[G::NITER];
+    constexpr int S0 = 6;            // first step that issues a staging load (one per step)
+    constexpr int SD = 8;            // a staged vector is written to LDS this many steps after its load
+    static_assert(S0 + SD + G::NITER <= G::STEPS, "staging must finish inside the chunk");
+    int bufsel = 0;
     auto mma = [](float a, float b, const f32x16& cc) -> f32x16 {
         return SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(b, a, cc, 0, 0, 0)
                     : __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, cc, 0, 0, 0);
@@ -620,21 +632,13 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_persist_kernel(const ConvPar
 #pragma unroll
     for (int j = 0; j < G::NITER; ++j)
         stg[j] = *reinterpret_cast<const f32x4*>(src + (goff[j] >= 0 ? goff[j] : 0));
-    auto lds_write = [&]() __attribute__((always_inline)) {
-        if (!cur_pad) {
-#pragma unroll
-            for (int j = 0; j < G::NITER; ++j) {
-                const int f = tid + j * 256;
-                if (f < G::NF4) *reinterpret_cast<f32x4*>(&lds[(f >> 3) * PS + (f & 7) * 4]) = stg[j];
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < G::NITER; ++j) {
-                const int f = tid + j * 256;
-                if (f < G::NF4)
-                    *reinterpret_cast<f32x4*>(&lds[(f >> 3) * PS + (f & 7) * 4]) =
-                        (goff[j] >= 0) ? stg[j] : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
+    // staged vector j -> LDS image `buf` (padding slots of boundary items are zeroed here, at the consumer)
+    auto lds_put = [&](int j, float* buf, bool pad) __attribute__((always_inline)) {
+        const int f = tid + j * 256;
+        if (f < G::NF4) {
+            f32x4 v = stg[j];
+            if (pad && goff[j] < 0) v = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(&buf[(f >> 3) * PS + (f & 7) * 4]) = v;
         }
     };
     auto load_prm = [&](int slice) __attribute__((always_inline)) {
@@ -642,11 +646,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_persist_kernel(const ConvPar
             prm[tid] = p.bias[slice * 64 + tid]; prm[64 + tid] = p.scale[slice * 64 + tid]; prm[128 + tid] = p.shift[slice * 64 + tid];
         }
     };
-    lds_write();
+#pragma unroll
+    for (int j = 0; j < G::NITER; ++j) lds_put(j, lds, cur_pad);
     load_prm(cur.slice);
     const f32x4* wp = reinterpret_cast<const f32x4*>(p.wpack) + ((long long)cur.slice * nchunks) * (G::STEPS * 128) + lane;
-    bf[0][0] = wp[0];   bf[0][1] = wp[64];
-    bf[1][0] = wp[128]; bf[1][1] = wp[128 + 64];
+#pragma unroll
+    for (int s = 0; s < PF; ++s) { bf[s][0] = wp[s * 128]; bf[s][1] = wp[s * 128 + 64]; }
     __syncthreads();
 
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -681,55 +686,59 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_persist_kernel(const ConvPar
             }
             const f32x4* wc = wp + (long long)c * (G::STEPS * 128);
             const f32x4* wt = last ? wnext : wc + G::STEPS * 128;      // where the weight prefetch continues
+            const bool stage_pad = last ? nxt_pad : cur_pad;           // padding flags of the image being staged
+            const float* const rbuf = lds + bufsel * BUF;               // image of this chunk
+            float* const wbuf = lds + (bufsel ^ 1) * BUF;               // image being built for the next chunk / item
             MPP_T(t_s0);
             if (c == 0) MPP_ADD(0, t_item, t_s0);
-            af[0][0] = *reinterpret_cast<const f32x4*>(&lds[a_base]);
-            af[0][1] = *reinterpret_cast<const f32x4*>(&lds[a_base + A_MB]);
+            af2[0][0] = *reinterpret_cast<const f32x4*>(&rbuf[a_base]);
+            af2[0][1] = *reinterpret_cast<const f32x4*>(&rbuf[a_base + A_MB]);
+            af2[1][0] = *reinterpret_cast<const f32x4*>(&rbuf[a_base + 8]);          // step 1 = tap 0, channel group 1
+            af2[1][1] = *reinterpret_cast<const f32x4*>(&rbuf[a_base + A_MB + 8]);
 #pragma unroll
             for (int s = 0; s < G::STEPS; ++s) {
-                if (s + 2 < G::STEPS) {
-                    bf[(s + 2) % RB][0] = wc[(s + 2) * 128];
-                    bf[(s + 2) % RB][1] = wc[(s + 2) * 128 + 64];
-                } else {
-                    bf[(s + 2) % RB][0] = wt[(s + 2 - G::STEPS) * 128];
-                    bf[(s + 2) % RB][1] = wt[(s + 2 - G::STEPS) * 128 + 64];
-                }
-                if (s + 1 < G::STEPS) {
-                    const int sn = s + 1;
-                    const int tap = sn >> 2, gg = sn & 3;
-                    const int kh = (TAPS == 9) ? tap / 3 : 0, kw = (TAPS == 9) ? tap % 3 : 0;
-                    const int aoff = (kh * G::LW + kw) * PS + gg * 8;
-                    af[sn & 1][0] = *reinterpret_cast<const f32x4*>(&lds[a_base + aoff]);
-                    af[sn & 1][1] = *reinterpret_cast<const f32x4*>(&lds[a_base + A_MB + aoff]);
-                }
-#pragma unroll
-                for (int u = 0; u < PER_STEP; ++u) {
-                    const int j = (s - S0) * PER_STEP + u;
-                    if (s >= S0 && j < G::NITER)
-                        stg[j] = *reinterpret_cast<const f32x4*>(in_next + (goff[j] >= 0 ? goff[j] : 0));
-                }
-                __builtin_amdgcn_sched_barrier(0);
+                // One wave per SIMD: nothing else fills the matrix pipe while this wave issues its memory instructions,
+                // so they are spread over the step -- each group sits in the 64-cycle shadow of the MFMA before it.
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    acc[0][0] = mma(af[s & 1][0][e], bf[s % RB][0][e], (FIRST && s == 0 && e == 0) ? zero16 : acc[0][0]);
-                    acc[0][1] = mma(af[s & 1][0][e], bf[s % RB][1][e], (FIRST && s == 0 && e == 0) ? zero16 : acc[0][1]);
-                    acc[1][0] = mma(af[s & 1][1][e], bf[s % RB][0][e], (FIRST && s == 0 && e == 0) ? zero16 : acc[1][0]);
-                    acc[1][1] = mma(af[s & 1][1][e], bf[s % RB][1][e], (FIRST && s == 0 && e == 0) ? zero16 : acc[1][1]);
+                    acc[0][0] = mma(af2[s % 3][0][e], bf[s % RB][0][e], (FIRST && s == 0 && e == 0) ? zero16 : acc[0][0]);
+                    acc[0][1] = mma(af2[s % 3][0][e], bf[s % RB][1][e], (FIRST && s == 0 && e == 0) ? zero16 : acc[0][1]);
+                    acc[1][0] = mma(af2[s % 3][1][e], bf[s % RB][0][e], (FIRST && s == 0 && e == 0) ? zero16 : acc[1][0]);
+                    acc[1][1] = mma(af2[s % 3][1][e], bf[s % RB][1][e], (FIRST && s == 0 && e == 0) ? zero16 : acc[1][1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (e == 0) {                          // weights PF steps ahead (ring slot consumed in step s-1)
+                        if (s + PF < G::STEPS) {
+                            bf[(s + PF) % RB][0] = wc[(s + PF) * 128];
+                            bf[(s + PF) % RB][1] = wc[(s + PF) * 128 + 64];
+                        } else {
+                            bf[(s + PF) % RB][0] = wt[(s + PF - G::STEPS) * 128];
+                            bf[(s + PF) % RB][1] = wt[(s + PF - G::STEPS) * 128 + 64];
+                        }
+                    } else if (e == 1) {                   // activation fragments of step s+2 (slot consumed in step s ... see RA)
+                        if (s + 2 < G::STEPS) {
+                            const int sn = s + 2;
+                            const int tap = sn >> 2, gg = sn & 3;
+                            const int kh = tap / 3, kw = tap % 3;
+                            const int aoff = (kh * G::LW + kw) * PS + gg * 8;
+                            af2[sn % 3][0] = *reinterpret_cast<const f32x4*>(&rbuf[a_base + aoff]);
+                            af2[sn % 3][1] = *reinterpret_cast<const f32x4*>(&rbuf[a_base + A_MB + aoff]);
+                        }
+                    } else if (e == 2) {
+                        if (s >= S0 && s - S0 < G::NITER)          // unconditional load (exact vmcnt counting)
+                            stg[s - S0] = *reinterpret_cast<const f32x4*>(in_next + (goff[s - S0] >= 0 ? goff[s - S0] : 0));
+                    } else {
+                        if (s >= S0 + SD && s - S0 - SD < G::NITER) lds_put(s - S0 - SD, wbuf, stage_pad);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
-                __builtin_amdgcn_sched_barrier(0);
             }
             MPP_T(t_s1);
             MPP_ADD(1, t_s0, t_s1);
-            __syncthreads();                                   // this chunk's LDS image fully consumed
+            bufsel ^= 1;
+            if (last) cur_pad = nxt_pad;
+            __syncthreads();                                   // next image complete, this one fully consumed
             MPP_T(t_b);
             MPP_ADD(2, t_s1, t_b);
-            if (last) cur_pad = nxt_pad;
-            if (!last || has_next) lds_write();                // staged registers are dead again before the epilogue
-            MPP_T(t_w);
-            MPP_ADD(3, t_b, t_w);
-            if (!last) __syncthreads();
-            MPP_T(t_b2);
-            MPP_ADD(6, t_w, t_b2);
         };
         chunk_body(0, std::true_type{});
         for (int c = 1; c < nchunks; ++c) chunk_body(c, std::false_type{});
@@ -858,10 +867,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_persist_kernel(const ConvPar
             for (int i = 0; i < 8; ++i) g_timing[blockIdx.x * 8 + i] = tsum[i];
 #endif
         if (!has_next) return;
-        __syncthreads();                                       // next item's LDS image complete, every epilogue done
-        MPP_T(t_b3);
-        MPP_ADD(5, t_e1, t_b3);
-        if (nxt.slice != cur.slice) load_prm(nxt.slice);       // (rare) visible to the next epilogue via the post-steps barrier
+        if (nxt.slice != cur.slice) {                          // (rare) every wave must be past its epilogue reads of prm
+            __syncthreads();
+            load_prm(nxt.slice);                               // visible to the next epilogue via the chunk barriers
+        }
         item = item_next;
         cur = nxt;
         wp = wnext;
@@ -885,13 +894,15 @@ void launch_t(const ConvParams& p, hipStream_t s)
     q.nitems = (int)nblk;
     const ConvParams& pp = q;
     if constexpr (!FUSE1) {
-        // persistent workgroups (two per CU) when every workgroup gets enough items for the tail not to matter
-        if (p.persist && nblk >= 512 * 8) {
-            if (p.bn_first)
-                hipLaunchKernelGGL((conv_mfma_persist_kernel<TAPS, MBW, POOL, true>), dim3(512), dim3(256), 0, s, pp);
-            else
-                hipLaunchKernelGGL((conv_mfma_persist_kernel<TAPS, MBW, POOL, false>), dim3(512), dim3(256), 0, s, pp);
-            return;
+        if constexpr (TAPS == 9) {
+            // persistent workgroups, ONE per CU, when every workgroup gets enough items for the tail not to matter
+            if (p.persist && nblk >= 256 * 8) {
+                if (p.bn_first)
+                    hipLaunchKernelGGL((conv_mfma_persist_kernel<TAPS, MBW, POOL, true>), dim3(256), dim3(256), 0, s, pp);
+                else
+                    hipLaunchKernelGGL((conv_mfma_persist_kernel<TAPS, MBW, POOL, false>), dim3(256), dim3(256), 0, s, pp);
+                return;
+            }
         }
     }
     if (p.bn_first)

@@ -24,7 +24,7 @@ assert lib.mp_debug_read_timing(buf, 512 * 8) == 0
 t = np.frombuffer(buf, dtype=np.uint64).reshape(512, 8).astype(np.float64)
 t = t[(t[:, 7] > 0) & (t[:, 7] < 1e6)]
 n = t[:, 7]
-names = ['item start -> first step', 'MFMA steps (all chunks)', 'barrier after steps', 'LDS write', 'epilogue', 'barrier before next item', 'barrier after LDS write']
+names = ['item start -> first step', 'MFMA steps (all chunks)', 'chunk-end barrier', '(unused)', 'epilogue', '(unused)', '(unused)']
 tot = 0
 for i, nm in enumerate(names):
     v = t[:, i] / n
@@ -37,5 +37,5 @@ if layer in prof:
     print('%s: %.3f ms in this (instrumented) run, %.0f ticks per workgroup -> %.3f GHz shader clock during the kernel' % (layer, prof[layer], ticks, ticks / prof[layer] * 1e-6))
     nch = {240: 2, 120: 4}.get(sel, 0)
     if nch:
-        need = n.mean() * nch * 576 * 64 * 2
-        print('MFMA cycles needed per SIMD (2 waves) %.0f = %.1f %% of the ticks' % (need, 100 * need / ticks))
+        need = n.mean() * nch * 576 * 64
+        print('MFMA cycles needed per SIMD (1 wave) %.0f = %.1f %% of the ticks' % (need, 100 * need / ticks))
