@@ -129,6 +129,20 @@ int mp_match_mutual_nn(mp_handle* h, const float* descA, const int* countA, cons
                        int D, float threshold, int* match_idx, float* match_dist, int* match_count,
                        void* stream);
 
+/* replaces the per-sample arithmetic of utils.compute_descriptor_metrics (multipoint/utils/evaluation.py:287-328) on
+ * the device-resident lists the calls above produced, for P pairs stored interleaved (image slot 2p = optical,
+ * 2p+1 = thermal):
+ *   kp_yx [2P][K][2], kp_count [2P]; match_idx [P][K]: thermal index matched to optical keypoint i, or -1
+ *   homography  device double [2P][9], row-major 3x3 acting on (x, y, 1): slot 2p = ground-truth optical->thermal
+ *               homography h_t * inv(h_o) (evaluation.py:259), slot 2p+1 = its inverse (:288)
+ *   metrics [P][8] int32: n_gt_optical, n_gt_thermal (:297-298), num_matched_optical, num_matched_thermal (:301-311),
+ *               N_optical, N_thermal (warped keypoints inside the H x W image, :315-316), number of matches, 0
+ *   tp [2P][K] uint8: tp[2p][i] = match of optical keypoint i is correct; tp[2p+1][j] = match of thermal keypoint j
+ *               (the same mutual pair seen from the other side) is correct; 0 for unmatched keypoints */
+int mp_pair_metrics(mp_handle* h, const int* kp_yx, const int* kp_count, const int* match_idx, const double* homography,
+                    int P, int K, int H, int W, float threshold_keypoints, int* metrics, unsigned char* tp,
+                    void* stream);
+
 /* per-launch timing of mp_forward with hipEvents on the caller's stream (bench.py roofline leg).
  * mp_profile_read synchronises; names[i] points to static strings. */
 int mp_profile_enable(mp_handle* h, int enable);

@@ -58,6 +58,7 @@ struct mp_handle {
     DevBuf ws;                      // forward workspace
     DevBuf ws2;                     // NMS work map + kept lists
     DevBuf ws3;                     // matching arg-min arrays
+    DevBuf ws4;                     // pair metrics: warped keypoints + inverse match map
     DevBuf nms_state;               // 64 round counters + tile flags
     int* nms_total = nullptr;       // device: undecided candidates summed over all calls since the last read
     int last_nms_rounds = 0;
@@ -622,6 +623,7 @@ void mp_destroy(mp_handle* h)
     if (h->ws.p) (void)hipFree(h->ws.p);
     if (h->ws2.p) (void)hipFree(h->ws2.p);
     if (h->ws3.p) (void)hipFree(h->ws3.p);
+    if (h->ws4.p) (void)hipFree(h->ws4.p);
     if (h->nms_state.p) (void)hipFree(h->nms_state.p);
     if (h->nms_total) (void)hipFree(h->nms_total);
     if (h->dummy) (void)hipFree(h->dummy);
@@ -862,6 +864,32 @@ int mp_match_mutual_nn(mp_handle* h, const float* descA, const int* countA, cons
     MP_HIP(hipMemsetAsync(match_count, 0, (size_t)P * 4, s));
     launch_match_impl(descA, countA, descB, countB, pair_stride, count_stride, P, K, D, threshold, rowbest,
                       colbest, match_idx, match_dist, match_count, s);
+    MP_HIP(hipGetLastError());
+    return MP_OK;
+}
+
+int mp_pair_metrics(mp_handle* h, const int* kp_yx, const int* kp_count, const int* match_idx, const double* homography,
+                    int P, int K, int H, int W, float threshold_keypoints, int* metrics, unsigned char* tp,
+                    void* stream)
+{
+    if (!h) return MP_EINVAL;
+    if (!kp_yx || !kp_count || !match_idx || !homography || !metrics || !tp)
+        return fail(h, MP_EINVAL, "mp_pair_metrics: NULL tensor");
+    if (P <= 0 || K <= 0 || H <= 0 || W <= 0) return fail(h, MP_EINVAL, "mp_pair_metrics: P, K, H, W must be positive");
+    if (!(threshold_keypoints >= 0.f)) return fail(h, MP_EINVAL, "mp_pair_metrics: threshold must be non-negative");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MP_HIP(hipSetDevice(h->device));
+    // scratch: warped [2P][K][2] double | inv_idx [P][K] int
+    const size_t nw = (size_t)2 * P * K * 2 * sizeof(double), ni = (size_t)P * K * sizeof(int);
+    int rc;
+    if ((rc = ensure(h, h->ws4, nw + ni))) return rc;
+    double* warped = static_cast<double*>(h->ws4.p);
+    int* inv_idx = reinterpret_cast<int*>(static_cast<char*>(h->ws4.p) + nw);
+    MP_HIP(hipMemsetAsync(inv_idx, 0xff, ni, s));
+    MP_HIP(hipMemsetAsync(tp, 0, (size_t)2 * P * K, s));
+    MP_HIP(hipMemsetAsync(metrics, 0, (size_t)P * 8 * sizeof(int), s));
+    launch_pair_metrics(kp_yx, kp_count, match_idx, homography, P, K, H, W, threshold_keypoints, warped, inv_idx, tp,
+                        metrics, s);
     MP_HIP(hipGetLastError());
     return MP_OK;
 }

@@ -136,3 +136,10 @@ void launch_match_impl(const float* dA, const int* nA, const float* dB, const in
                        long long pair_stride, int count_stride, int P, int K, int D, float thr,
                        unsigned long long* rowbest, unsigned long long* colbest, int* match_idx,
                        float* match_dist, int* match_count, hipStream_t s);
+
+// GPU-resident pair metrics (evaluation.py:287-328): hom [2P][9] double (slot 2p: optical->thermal ground-truth
+// homography, 2p+1: its inverse), warped [2P][K][2] double scratch, inv_idx [P][K] scratch (pre-set to -1),
+// tp [2P][K] (pre-set to 0), metrics [P][8] (pre-set to 0): n_gt_o, n_gt_t, matched_o, matched_t, N_o, N_t, n_matches
+void launch_pair_metrics(const int* kp_yx, const int* kp_count, const int* match_idx, const double* hom, int P, int K,
+                         int H, int W, float thr, double* warped, int* inv_idx, unsigned char* tp, int* metrics,
+                         hipStream_t s);

@@ -1,0 +1,130 @@
+"""Host-side mirror of the descriptor-metric driver of the reference (multipoint/utils/evaluation.py:209-439,
+`compute_descriptor_metrics`, the `-e` mode of predict_align_image_pair.py:69-73): forward, NMS/top-k, descriptor
+sampling and mutual-NN matching run through PairPipeline, and the per-sample arithmetic (keypoint warping by the
+ground-truth homography, the N x M correctness test, true positives of the matches, matching score) runs on the GPU
+behind mp_pair_metrics.  Only the final precision/recall bookkeeping over the concatenated match lists is numpy, as
+in the reference (:360-419).
+
+Not accelerated (and not computed): the RANSAC homography estimate `cv2.findHomography` and the 4-corner error
+derived from it (:330-356) -- `pts_dist`, `average_h_error` and `h_correctness` are returned as None."""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+def div0(a, b):
+    # evaluation.py:202-207
+    with np.errstate(divide='ignore', invalid='ignore'):
+        c = np.true_divide(a, b)
+        idx = ~np.isfinite(c)
+        c[idx] = np.where(a[idx] == 0, 1, 0)
+    return c
+
+
+def compute_mAP(precision, recall):
+    # evaluation.py:99-103
+    return np.sum(precision[1:] * (recall[1:] - recall[:-1]))
+
+
+def ground_truth_homographies(h_optical, h_thermal):
+    """evaluation.py:259,288: gt = h_t @ inv(h_o) and its inverse, fp32 like the reference's torch ops.
+    h_* : (P,3,3) tensors/arrays.  Returns a (2P,9) float64 tensor: slot 2p = gt, 2p+1 = inv(gt)."""
+    ho = torch.as_tensor(h_optical, dtype=torch.float32).cpu()
+    ht = torch.as_tensor(h_thermal, dtype=torch.float32).cpu()
+    gt = torch.matmul(ht, torch.linalg.inv(ho))
+    gti = torch.linalg.inv(gt)
+    return torch.stack([gt, gti], dim=1).reshape(-1, 9).to(torch.float64)
+
+
+def pair_metrics(res, homography, threshold_keypoints):
+    """GPU arithmetic of evaluation.py:287-328 for the pairs of a PairResults.
+    homography: (2P,9) float64 from ground_truth_homographies().
+    Returns (metrics [P,8] int32 device tensor, tp [2P,K] uint8 device tensor); see include/multipoint_hip.h."""
+    res.wait()
+    dev = res.kp_yx.device
+    P = res.num_pairs
+    K = res.kp_yx.shape[1]
+    hom = torch.as_tensor(homography, dtype=torch.float64).reshape(2 * P, 9).to(dev).contiguous()
+    metrics = torch.empty((P, 8), dtype=torch.int32, device=dev)
+    tp = torch.empty((2 * P, K), dtype=torch.uint8, device=dev)
+    h = _lib.get_handle(dev)
+    with torch.cuda.device(dev):
+        h.check(h.lib.mp_pair_metrics(h.ptr, _lib.ptr(res.kp_yx.contiguous()), _lib.ptr(res.kp_count.contiguous()),
+                                      _lib.ptr(res.match_idx.contiguous()), _lib.ptr(hom), P, K, int(res.H), int(res.W),
+                                      float(threshold_keypoints), _lib.ptr(metrics), _lib.ptr(tp),
+                                      _lib.stream_ptr(dev)))
+    return metrics, tp
+
+
+def compute_descriptor_metrics(net, dataloader, device, config, threshold_keypoints, threshold_warp=None):
+    """Same signature and result keys as the reference function (evaluation.py:209); see the module docstring for
+    what is left out."""
+    from ..pipeline import PairPipeline
+    from .utils import data_to_device
+    pipe = PairPipeline(net, config)
+    tp_o, tp_t, dist_o, dist_t, ms_o, ms_t = [], [], [], [], [], []
+    n_gt_o = n_gt_t = 0
+    for data in dataloader:
+        data = data_to_device(data, device)
+        opt, th = data['optical'], data['thermal']
+        B = opt['image'].shape[0]
+        eye = torch.eye(3, dtype=torch.float32).repeat(B, 1, 1)
+        ho = opt.get('homography', eye)
+        ht = th.get('homography', eye)
+        res = pipe(opt['image'], th['image'], opt.get('valid_mask'), th.get('valid_mask'))
+        metrics, tp = pair_metrics(res, ground_truth_homographies(ho, ht), threshold_keypoints)
+        pipe.check_converged()
+        m = metrics.cpu().numpy(); tp = tp.cpu().numpy()
+        midx = res.match_idx.cpu().numpy(); mdist = res.match_dist.cpu().numpy()
+        cnt = res.kp_count.cpu().numpy()
+        K = midx.shape[1]
+        for p in range(B):
+            no = min(int(cnt[2 * p]), K)
+            q = np.nonzero(midx[p, :no] >= 0)[0]
+            # matches_optical (query = optical) and matches_thermal (query = thermal) are the same mutual pairs
+            # (evaluation.py:273-282); their order does not matter, everything is re-sorted by distance below
+            tp_o.append(tp[2 * p, q].astype(bool)); dist_o.append(mdist[p, q])
+            tp_t.append(tp[2 * p + 1, midx[p, q]].astype(bool)); dist_t.append(mdist[p, q])
+            n_gt_o += int(m[p, 0]); n_gt_t += int(m[p, 1])
+            ms_o.append(float(m[p, 2]) / m[p, 4] if m[p, 4] > 0 else 0.0)
+            ms_t.append(float(m[p, 3]) / m[p, 5] if m[p, 5] > 0 else 0.0)
+    return summarize_descriptor_metrics(np.concatenate(tp_o) if tp_o else np.zeros(0, bool),
+                                        np.concatenate(dist_o) if dist_o else np.zeros(0, np.float32),
+                                        np.concatenate(tp_t) if tp_t else np.zeros(0, bool),
+                                        np.concatenate(dist_t) if dist_t else np.zeros(0, np.float32),
+                                        n_gt_o, n_gt_t, np.array(ms_o), np.array(ms_t))
+
+
+def summarize_descriptor_metrics(tp_optical, distance_optical, tp_thermal, distance_thermal, n_gt_optical,
+                                 n_gt_thermal, m_score_optical, m_score_thermal):
+    """evaluation.py:360-439 (precision / recall / NN-mAP / M-score bookkeeping), verbatim arithmetic."""
+    sort_o = np.argsort(distance_optical, kind='stable')
+    tp_optical = tp_optical[sort_o]; fp_optical = np.logical_not(tp_optical); distance_optical = distance_optical[sort_o]
+    sort_t = np.argsort(distance_thermal, kind='stable')
+    tp_thermal = tp_thermal[sort_t]; fp_thermal = np.logical_not(tp_thermal); distance_thermal = distance_thermal[sort_t]
+    tpo, tpt = np.cumsum(tp_optical), np.cumsum(tp_thermal)
+    fpo, fpt = np.cumsum(fp_optical), np.cumsum(fp_thermal)
+    recall_optical = div0(tpo, n_gt_optical); recall_thermal = div0(tpt, n_gt_thermal)
+    precision_optical = div0(tpo, tpo + fpo); precision_thermal = div0(tpt, tpt + fpt)
+    recall_optical = np.concatenate([[0], recall_optical, [1]])
+    precision_optical = np.concatenate([[0], precision_optical, [0]])
+    precision_optical = np.maximum.accumulate(precision_optical[::-1])[::-1]
+    recall_thermal = np.concatenate([[0], recall_thermal, [1]])
+    precision_thermal = np.concatenate([[0], precision_thermal, [0]])
+    precision_thermal = np.maximum.accumulate(precision_thermal[::-1])[::-1]
+    nn_map_optical = compute_mAP(precision_optical, recall_optical)
+    nn_map_thermal = compute_mAP(precision_thermal, recall_thermal)
+    m_score = (m_score_optical.mean() + m_score_thermal.mean()) * 0.5 if len(m_score_optical) else 0.0
+    return {
+        'tp_optical': tp_optical, 'tp_thermal': tp_thermal, 'fp_optical': fp_optical, 'fp_thermal': fp_thermal,
+        'distance_optical': distance_optical, 'distance_thermal': distance_thermal,
+        'recall_optical': recall_optical, 'recall_thermal': recall_thermal,
+        'precision_optical': precision_optical, 'precision_thermal': precision_thermal,
+        'nn_map_optical': nn_map_optical, 'nn_map_thermal': nn_map_thermal,
+        'nn_map': (nn_map_optical + nn_map_thermal) * 0.5,
+        'm_score_optical': m_score_optical, 'm_score_thermal': m_score_thermal, 'm_score': m_score,
+        'pts_dist': None, 'average_h_error': None, 'h_correctness': None,
+    }

@@ -553,6 +553,49 @@ def bf_match_crosscheck(desc1, desc2):
 # --------------------------------------------------------------------------------------------
 # whole path on one batch of pairs (evaluation.py:224-285 loop head), used by the CPU baseline
 # --------------------------------------------------------------------------------------------
+def warp_keypoints(keypoints, homography):
+    """multipoint/utils/homographies.py:331-346 with return_type float: cv2.perspectiveTransform on float64 (x,y)
+    points (cv2 is absent -> PARITY UNPINNED; OpenCV's perspectiveTransform_64f arithmetic restated:
+    w = x*m6 + y*m7 + m8; w = 1/w if |w| > eps else 0; x' = (x*m0 + y*m1 + m2)*w; y' = (x*m3 + y*m4 + m5)*w).
+    keypoints (N,2) as (y,x); returns (N,2) float64 as (y,x)."""
+    kp = np.asarray(keypoints, dtype=np.float64)
+    if len(kp) == 0:
+        return kp.reshape(0, 2)
+    m = np.asarray(homography, dtype=np.float64).reshape(9)
+    y, x = kp[:, 0], kp[:, 1]
+    w = x * m[6] + y * m[7] + m[8]
+    w = np.where(np.abs(w) > np.finfo(np.float64).eps, 1.0 / np.where(w == 0, 1.0, w), 0.0)
+    xo = (x * m[0] + y * m[1] + m[2]) * w
+    yo = (x * m[3] + y * m[4] + m[5]) * w
+    return np.stack([yo, xo], axis=1)
+
+
+def descriptor_metrics_pair(kp_optical, kp_thermal, match_query, match_train, h_optical, h_thermal,
+                            threshold_keypoints, H, W):
+    """Per-sample arithmetic of utils.compute_descriptor_metrics (multipoint/utils/evaluation.py:259,287-328).
+    kp_* (N,2) int (y,x); match_query/match_train: mutual matches (optical index, thermal index).
+    Returns dict(n_gt_optical, n_gt_thermal, tp_optical (per match), tp_thermal (per match), N_optical, N_thermal)."""
+    ho = torch.as_tensor(h_optical, dtype=torch.float32); ht = torch.as_tensor(h_thermal, dtype=torch.float32)
+    gt = torch.mm(ht, ho.inverse())                                                   # :259
+    kp_o = torch.as_tensor(np.asarray(kp_optical).reshape(-1, 2), dtype=torch.int64)
+    kp_t = torch.as_tensor(np.asarray(kp_thermal).reshape(-1, 2), dtype=torch.int64)
+    warped_o = warp_keypoints(kp_o.float().numpy(), gt.numpy())                        # :287
+    warped_t = warp_keypoints(kp_t.float().numpy(), gt.inverse().numpy())              # :288
+    dist = torch.from_numpy(warped_o).unsqueeze(1) - kp_t.unsqueeze(0)                 # :291 (float64)
+    correct_o = torch.norm(dist.float(), dim=-1) <= threshold_keypoints                # :292
+    dist = torch.from_numpy(warped_t).unsqueeze(1) - kp_o.unsqueeze(0)
+    correct_t = torch.norm(dist.float(), dim=-1) <= threshold_keypoints
+    q = np.asarray(match_query, dtype=np.int64); t = np.asarray(match_train, dtype=np.int64)
+
+    def inside(pts):                                                                    # filter_points, homographies.py:358-372
+        return int(((pts[:, 0] >= 0) & (pts[:, 1] >= 0) & (pts[:, 0] < H) & (pts[:, 1] < W)).sum()) if len(pts) else 0
+    return dict(n_gt_optical=int(correct_o.sum(1).nonzero().shape[0]) if correct_o.numel() else 0,
+                n_gt_thermal=int(correct_t.sum(1).nonzero().shape[0]) if correct_t.numel() else 0,
+                tp_optical=correct_o[q, t].numpy() if len(q) else np.zeros(0, bool),
+                tp_thermal=correct_t[t, q].numpy() if len(q) else np.zeros(0, bool),
+                N_optical=inside(warped_o), N_thermal=inside(warped_t))
+
+
 def process_pairs(sd, cfg, optical, thermal, nms=4, detection_threshold=0.015, topk=1000,
                   mask_optical=None, mask_thermal=None):
     """optical/thermal: (P,1,H,W) torch fp32.  Returns per-pair dicts with keypoints, descriptors

@@ -2,10 +2,10 @@
 """Drop-in for the hot path of the reference's predict_align_image_pair.py: same flags
 (-y -m -v -i -r -p -e -tk -th -s), same yaml keys, same model_weights/<name>/{params.yaml,<version>.model}
 format, same three timing prints (reference predict_align_image_pair.py:141-143) -- computed on an
-MI355X through libmultipoint_hip.so.  The matplotlib/cv2 visualisation of -p and the metric
-arithmetic of -e (NN-mAP, M-score, RANSAC homography) are outside the accelerated path: -p prints a
-text summary of keypoints/matches (and can save them with --save-npz), -e runs the batched
-detect+describe+match driver over the dataset and reports counts and throughput."""
+MI355X through libmultipoint_hip.so.  -e computes NN-mAP and M-score like the reference
+(utils.compute_descriptor_metrics; per-sample arithmetic on the GPU) but not the RANSAC homography
+correctness (cv2.findHomography is outside the accelerated path).  The matplotlib/cv2 visualisation of
+-p is replaced by a text summary of keypoints/matches (and --save-npz)."""
 import argparse
 import os
 import random
@@ -85,27 +85,19 @@ def main(argv=None):
 
     with torch.no_grad():
         if args.evaluation:
-            pipe = PairPipeline(net, pred, capacity=pred['topk'] if pred['topk'] > 0 else 4096)
-            n_pairs, n_opt, n_th, n_match = 0, [], [], []
+            # reference predict_align_image_pair.py:69-88: utils.compute_descriptor_metrics over the whole loader; the
+            # per-sample arithmetic runs on the GPU (mp_pair_metrics), the RANSAC homography estimate is not computed
             synchronize(); t0 = time.time()
-            for data in loader_dataset:
-                data = utils.data_to_device(data, device)
-                res = pipe(data['optical']['image'], data['thermal']['image'],
-                           data['optical']['valid_mask'], data['thermal']['valid_mask'])
-                K = res.kp_yx.shape[1]          # (pipe(...) already ordered the results behind this stream)
-                cnt = res.kp_count.clamp(max=K).cpu().numpy()
-                n_opt += cnt[0::2].tolist(); n_th += cnt[1::2].tolist()
-                n_match += res.match_count.cpu().numpy().tolist()
-                n_pairs += res.num_pairs
-            pipe.check_converged(device)
+            results = utils.compute_descriptor_metrics(net, loader_dataset, device, pred, args.threshold_keypoints,
+                                                       args.threshold_homography)
             synchronize(); dt = time.time() - t0
-            results = {'n_kp_optical': np.array(n_opt), 'n_kp_thermal': np.array(n_th), 'n_matches': np.array(n_match),
-                       'pairs_per_second': n_pairs / dt, 'config': config,
-                       'threshold_keypoints': args.threshold_keypoints, 'threshold_homography': args.threshold_homography}
-            print('Pairs: {}  ({:.1f} pairs/s)'.format(n_pairs, n_pairs / dt))
-            print('Mean optical keypoints: {}'.format(np.mean(n_opt)))
-            print('Mean thermal keypoints: {}'.format(np.mean(n_th)))
-            print('Mean mutual-NN matches: {}'.format(np.mean(n_match)))
+            print('NN-mAP: {}'.format(results['nn_map']))
+            print('M-Score: {}'.format(results['m_score']))
+            print('Homography Correctness: n/a (cv2.findHomography RANSAC is outside the accelerated path)')
+            print('Matches: {}  ({:.1f} pairs/s)'.format(len(results['tp_optical']), len(dataset) / dt))
+            results['config'] = config
+            results['threshold_keypoints'] = args.threshold_keypoints
+            results['threshold_homography'] = args.threshold_homography
             target_dir = os.path.join(args.model_dir, 'descriptor_evaluation')
             os.makedirs(target_dir, exist_ok=True)
             np.save(os.path.join(target_dir, os.path.split(args.model_dir.strip('/'))[-1] + '_' +

@@ -1,0 +1,89 @@
+"""GPU (MI355X): mp_pair_metrics (the per-sample arithmetic of utils.compute_descriptor_metrics, reference
+multipoint/utils/evaluation.py:259,287-328) against the oracle's restatement -- integer results, bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_homography(rng, H, W, strength):
+    a = np.eye(3)
+    a[:2, :2] += rng.normal(0, 0.05 * strength, (2, 2))
+    a[:2, 2] += rng.normal(0, 6.0 * strength, 2)
+    a[2, :2] += rng.normal(0, 2e-4 * strength, 2)
+    return a.astype(np.float32)
+
+
+def _make_results(rng, P, K, H, W, hs, fill):
+    """Synthetic device-resident lists: thermal keypoints = optical ones pushed through the ground-truth homography
+    plus noise (so that a realistic share of the correctness tests is near the threshold), random mutual matches."""
+    from multipoint_amd.pipeline import PairResults
+    kp = np.zeros((2 * P, K, 2), np.int32); cnt = np.zeros(2 * P, np.int32); midx = -np.ones((P, K), np.int32)
+    for p in range(P):
+        no = int(rng.integers(0, K + 1)) if fill == 'ragged' else K
+        o = np.stack([rng.integers(0, H, no), rng.integers(0, W, no)], 1)
+        gt = hs[p][1].astype(np.float64) @ np.linalg.inv(hs[p][0].astype(np.float64))
+        xy1 = np.concatenate([o[:, ::-1], np.ones((no, 1))], 1) @ gt.T
+        t = (xy1[:, :2] / xy1[:, 2:3])[:, ::-1] + rng.normal(0, 2.5, (no, 2))
+        t = np.round(t).astype(np.int64)
+        keep = rng.random(no) < 0.9
+        t = t[keep]
+        nt = min(len(t), K)
+        t = np.clip(t[:nt], [-3, -3], [H + 2, W + 2])          # a few just outside the image
+        kp[2 * p, :no] = o; kp[2 * p + 1, :nt] = t; cnt[2 * p] = no; cnt[2 * p + 1] = nt
+        # mutual matches: a random partial injection optical -> thermal
+        n_m = min(no, nt)
+        if n_m:
+            qs = rng.permutation(no)[:n_m]; ts = rng.permutation(nt)[:n_m]
+            sel = rng.random(n_m) < 0.6
+            midx[p, qs[sel]] = ts[sel]
+    dev = 'cuda'
+    res = PairResults(torch.from_numpy(kp).to(dev), None, torch.from_numpy(cnt).to(dev), None,
+                      torch.from_numpy(midx).to(dev), torch.zeros((P, K), device=dev), None, H, W)
+    return res, kp, cnt, midx
+
+
+@pytest.mark.parametrize('P,K,H,W,strength,fill', [(3, 300, 240, 320, 1.0, 'ragged'), (2, 1000, 480, 640, 0.3, 'full'),
+                                                   (2, 64, 64, 64, 0.0, 'ragged'), (1, 2000, 1024, 1280, 1.0, 'full')])
+def test_pair_metrics_bit_exact(oracle, P, K, H, W, strength, fill):
+    import multipoint_amd.utils as U
+    rng = np.random.default_rng(K + P)
+    hs = [(_random_homography(rng, H, W, strength), _random_homography(rng, H, W, strength)) for _ in range(P)]
+    res, kp, cnt, midx = _make_results(rng, P, K, H, W, hs, fill)
+    hom = U.ground_truth_homographies(np.stack([h[0] for h in hs]), np.stack([h[1] for h in hs]))
+    thr = 4.0
+    metrics, tp = U.pair_metrics(res, hom, thr)
+    metrics = metrics.cpu().numpy(); tp = tp.cpu().numpy()
+    for p in range(P):
+        no, nt = cnt[2 * p], cnt[2 * p + 1]
+        q = np.nonzero(midx[p, :no] >= 0)[0]; t = midx[p, q]
+        ref = oracle.descriptor_metrics_pair(kp[2 * p, :no], kp[2 * p + 1, :nt], q, t, hs[p][0], hs[p][1], thr, H, W)
+        assert metrics[p, 0] == ref['n_gt_optical'] and metrics[p, 1] == ref['n_gt_thermal']
+        assert metrics[p, 2] == int(ref['tp_optical'].sum()) and metrics[p, 3] == int(ref['tp_thermal'].sum())
+        assert metrics[p, 4] == ref['N_optical'] and metrics[p, 5] == ref['N_thermal']
+        assert metrics[p, 6] == len(q)
+        assert np.array_equal(tp[2 * p, q].astype(bool), ref['tp_optical'])
+        assert np.array_equal(tp[2 * p + 1, t].astype(bool), ref['tp_thermal'])
+        un = np.setdiff1d(np.arange(K), q); assert not tp[2 * p, un].any()
+
+
+def test_compute_descriptor_metrics_end_to_end(oracle):
+    """The reference driver's signature and result keys (evaluation.py:209-439) on a synthetic loader whose thermal
+    image is the optical one: every mutual match of identical images is a true positive."""
+    import multipoint_amd.models as M
+    import multipoint_amd.utils as U
+    cfg = oracle.SHIPPED_MODEL_CONFIG
+    net = M.MultiPoint(dict(cfg)); net.load_state_dict(oracle.make_weights(0, cfg)); net.to('cuda'); net.eval()
+    img = oracle.make_images(5, 2, 120, 160)
+    batch = {'optical': {'image': img, 'valid_mask': torch.ones_like(img, dtype=torch.bool)},
+             'thermal': {'image': img.clone(), 'valid_mask': torch.ones_like(img, dtype=torch.bool)}}
+    pred = {'nms': 4, 'detection_threshold': 0.015, 'topk': 300, 'cpu_nms': False,
+            'matching': {'method': 'bfmatcher', 'method_kwargs': {'crossCheck': True}, 'knn_matches': False}}
+    out = U.compute_descriptor_metrics(net, [batch], torch.device('cuda'), pred, 4.0, 4.0)
+    for k in ('tp_optical', 'fp_optical', 'distance_optical', 'recall_optical', 'precision_optical', 'nn_map_optical',
+              'nn_map_thermal', 'nn_map', 'm_score_optical', 'm_score', 'pts_dist', 'h_correctness'):
+        assert k in out
+    assert len(out['tp_optical']) > 100 and out['tp_optical'].all() and out['tp_thermal'].all()
+    assert abs(out['nn_map'] - 1.0) < 1e-9 and abs(out['m_score'] - 1.0) < 1e-9
+    assert out['h_correctness'] is None

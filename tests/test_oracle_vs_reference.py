@@ -107,3 +107,89 @@ def test_magicleap_vs_reference(oracle, ref):
         assert (r[k] - o[k]).abs().max().item() <= 1e-6
     import multipoint_amd.models as M
     assert [k for k, _, _ in M.SuperPointMagicLeap().state_dict_spec()] == list(sd.keys())
+
+
+def test_descriptor_metrics_against_reference_driver(oracle, ref, monkeypatch):
+    """The REFERENCE's own compute_descriptor_metrics (multipoint/utils/evaluation.py:209-439) run here on CPU, with
+    the absent third-party calls (torchvision nms, cv2 BFMatcher / perspectiveTransform) served by the oracle's
+    restatements -- so this pins the bookkeeping (ground-truth homography, correctness matrices, n_gt, true positives,
+    M-score, precision/recall, NN-mAP) of the oracle + the product's host code, not the third-party arithmetic."""
+    import sys
+    import types
+    models, utils = ref
+    import multipoint.utils.evaluation as ev
+    import multipoint.utils.utils as ru
+    import multipoint.utils.matching as rm
+    import multipoint.utils.homographies as rh
+    cv2 = sys.modules['cv2']
+
+    def nms(boxes, scores, iou):
+        keep = oracle.nms_greedy(boxes.numpy().astype(np.float32), scores.numpy().astype(np.float32), float(iou))
+        return torch.as_tensor(np.asarray(keep), dtype=torch.int64)
+
+    def batched_nms(boxes, scores, idxs, iou):
+        keep = []
+        for i in torch.unique(idxs):
+            sel = torch.nonzero(idxs == i)[:, 0]
+            keep.append(sel[nms(boxes[sel], scores[sel], iou)])
+        keep = torch.cat(keep) if keep else torch.zeros(0, dtype=torch.int64)
+        return keep[torch.argsort(scores[keep], descending=True, stable=True)]
+
+    class BFMatcher:
+        def __init__(self, norm, crossCheck=False):
+            assert crossCheck
+        def match(self, d1, d2):
+            q, t, d = oracle.bf_match_crosscheck(d1, d2)
+            return [cv2.DMatch(int(a), int(b), float(c)) for a, b, c in zip(q, t, d)]
+
+    def perspectiveTransform(pts, h):
+        out = oracle.warp_keypoints(pts[0][:, ::-1], h)          # oracle takes / returns (y, x)
+        return out[None, :, ::-1]
+
+    class KeyPoint:
+        def __init__(self, x, y, size):
+            self.pt = (x, y)
+    monkeypatch.setattr(ru, 'nms', nms, raising=False); monkeypatch.setattr(ru, 'batched_nms', batched_nms, raising=False)
+    for name, val in (('BFMatcher', BFMatcher), ('perspectiveTransform', perspectiveTransform), ('KeyPoint', KeyPoint),
+                      ('findHomography', lambda *a, **k: (None, None)), ('RANSAC', 8), ('NORM_L2', 4)):
+        monkeypatch.setattr(cv2, name, val, raising=False)
+
+    cfg = dict(oracle.SHIPPED_MODEL_CONFIG)
+    sd = oracle.make_weights(31, cfg)
+    net = models.MultiPoint(dict(cfg)).eval(); net.load_state_dict(sd)
+    H, W, B = 96, 128, 3
+    rng = np.random.default_rng(5)
+    opt = oracle.make_images(41, B, H, W)
+    th = (opt + 0.02 * torch.from_numpy(rng.standard_normal(opt.shape).astype(np.float32))).clamp(0, 1)
+    ho = torch.eye(3).repeat(B, 1, 1); ht = torch.eye(3).repeat(B, 1, 1)
+    ht[:, 0, 2] = torch.tensor([0.0, 1.0, -2.0]); ht[1, 0, 0] = 1.01
+    ones = torch.ones((B, 1, H, W), dtype=torch.bool)
+    batch = {'optical': {'image': opt, 'valid_mask': ones, 'homography': ho, 'is_optical': torch.ones(B, 1, dtype=torch.bool)},
+             'thermal': {'image': th, 'valid_mask': ones, 'homography': ht, 'is_optical': torch.zeros(B, 1, dtype=torch.bool)}}
+    pred = {'nms': 4, 'detection_threshold': 0.015, 'topk': 150, 'cpu_nms': True, 'reprojection_threshold': 3,
+            'matching': {'method': 'bfmatcher', 'method_kwargs': {'crossCheck': True}, 'knn_matches': False}}
+    with torch.no_grad():
+        r = ev.compute_descriptor_metrics(net, [batch], torch.device('cpu'), pred, 4.0, 4.0)
+
+    # the same through the oracle (per pair) + the product's host bookkeeping
+    from multipoint_amd.utils.evaluation import summarize_descriptor_metrics
+    pairs = oracle.process_pairs(sd, cfg, opt, th, nms=4, detection_threshold=0.015, topk=150)
+    tp_o, tp_t, dist, ms_o, ms_t, ngo, ngt = [], [], [], [], [], 0, 0
+    for p, rec in enumerate(pairs):
+        m = oracle.descriptor_metrics_pair(rec['kp_optical'], rec['kp_thermal'], rec['match_query'], rec['match_train'],
+                                           ho[p], ht[p], 4.0, H, W)
+        tp_o.append(m['tp_optical']); tp_t.append(m['tp_thermal']); dist.append(rec['match_dist'])
+        ngo += m['n_gt_optical']; ngt += m['n_gt_thermal']
+        ms_o.append(m['tp_optical'].sum() / m['N_optical'] if m['N_optical'] else 0.0)
+        ms_t.append(m['tp_thermal'].sum() / m['N_thermal'] if m['N_thermal'] else 0.0)
+    d = np.concatenate(dist)
+    mine = summarize_descriptor_metrics(np.concatenate(tp_o), d, np.concatenate(tp_t), d, ngo, ngt, np.array(ms_o), np.array(ms_t))
+    assert len(r['tp_optical']) == len(mine['tp_optical']) > 50
+    assert r['tp_optical'].sum() == mine['tp_optical'].sum() and r['tp_thermal'].sum() == mine['tp_thermal'].sum()
+    assert 0 < r['tp_optical'].sum() < len(r['tp_optical'])               # the case exercises true AND false positives
+    # (the driver's BFMatcher stub returns ||a-b||, process_pairs the NNMatcher form sqrt(2-2ab): equal to ~1e-5 near 0)
+    assert np.allclose(np.sort(r['distance_optical']), np.sort(mine['distance_optical']), atol=1e-4)
+    assert np.allclose(r['m_score_optical'], mine['m_score_optical']) and np.allclose(r['m_score_thermal'], mine['m_score_thermal'])
+    assert abs(r['m_score'] - mine['m_score']) < 1e-12
+    assert abs(r['nn_map_optical'] - mine['nn_map_optical']) < 1e-6 and abs(r['nn_map_thermal'] - mine['nn_map_thermal']) < 1e-6
+    assert np.allclose(r['recall_optical'][-2], mine['recall_optical'][-2])
