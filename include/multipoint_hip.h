@@ -143,6 +143,16 @@ int mp_pair_metrics(mp_handle* h, const int* kp_yx, const int* kp_count, const i
                     int P, int K, int H, int W, float threshold_keypoints, int* metrics, unsigned char* tp,
                     void* stream);
 
+/* replaces the per-sample arithmetic of utils.compute_repeatability_multispectral (multipoint/utils/evaluation.py:156-199)
+ * for P pairs stored interleaved (slot 2p = optical, 2p+1 = thermal):
+ *   homography  device double [2P][2][9]: for slot b first the INVERSE of its own homography, then the other image's
+ *               homography (evaluation.py:168-169,173-174); both warps truncate to integers like warp_keypoints' default
+ *   counts [P][4] int32: count1 (warped thermal points with an optical keypoint within distance_thresh), count2 (warped
+ *               optical points near a thermal keypoint), N_thermal, N_optical (warped points inside the H x W frame);
+ *               repeatability = (count1 + count2) / (N_thermal + N_optical)  (:198-199) */
+int mp_repeatability(mp_handle* h, const int* kp_yx, const int* kp_count, const double* homography, int P, int K, int H,
+                     int W, double distance_thresh, int* counts, void* stream);
+
 /* per-launch timing of mp_forward with hipEvents on the caller's stream (bench.py roofline leg).
  * mp_profile_read synchronises; names[i] points to static strings. */
 int mp_profile_enable(mp_handle* h, int enable);

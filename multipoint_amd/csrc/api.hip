@@ -894,6 +894,23 @@ int mp_pair_metrics(mp_handle* h, const int* kp_yx, const int* kp_count, const i
     return MP_OK;
 }
 
+int mp_repeatability(mp_handle* h, const int* kp_yx, const int* kp_count, const double* homography, int P, int K, int H,
+                     int W, double distance_thresh, int* counts, void* stream)
+{
+    if (!h) return MP_EINVAL;
+    if (!kp_yx || !kp_count || !homography || !counts) return fail(h, MP_EINVAL, "mp_repeatability: NULL tensor");
+    if (P <= 0 || K <= 0 || H <= 0 || W <= 0) return fail(h, MP_EINVAL, "mp_repeatability: P, K, H, W must be positive");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MP_HIP(hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure(h, h->ws4, (size_t)2 * P * K * 2 * sizeof(long long)))) return rc;
+    MP_HIP(hipMemsetAsync(counts, 0, (size_t)P * 4 * sizeof(int), s));
+    launch_repeatability(kp_yx, kp_count, homography, P, K, H, W, distance_thresh, static_cast<long long*>(h->ws4.p),
+                         counts, s);
+    MP_HIP(hipGetLastError());
+    return MP_OK;
+}
+
 int mp_profile_enable(mp_handle* h, int enable)
 {
     if (!h) return MP_EINVAL;

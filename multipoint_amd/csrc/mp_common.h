@@ -143,3 +143,7 @@ void launch_match_impl(const float* dA, const int* nA, const float* dB, const in
 void launch_pair_metrics(const int* kp_yx, const int* kp_count, const int* match_idx, const double* hom, int P, int K,
                          int H, int W, float thr, double* warped, int* inv_idx, unsigned char* tp, int* metrics,
                          hipStream_t s);
+// keypoint repeatability (evaluation.py:156-199): hom [2P][2][9] double (slot b: inverse of its own homography, then the
+// other image's homography), warped [2P][K][2] int64 scratch, out [P][4] (pre-set to 0): count1, count2, N_thermal, N_optical
+void launch_repeatability(const int* kp_yx, const int* kp_count, const double* hom, int P, int K, int H, int W, double thr,
+                          long long* warped, int* out, hipStream_t s);

@@ -95,7 +95,82 @@ __global__ __launch_bounds__(256) void invert_kernel(const int* __restrict__ mat
     if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&metrics[p * 8 + 6], __popcll(bal));   // number of matches
 }
 
+// ---- keypoint repeatability (reference multipoint/utils/evaluation.py:156-199) ---------------------------------------
+// warp_keypoints with its default integer return type (homographies.py:331-346): the float64 result of
+// cv2.perspectiveTransform is truncated toward zero (ndarray.astype(int)) after EACH of the two warps
+// (frame -> world by inv(h_own), world -> other frame by h_other), then filter_points keeps in-image points.
+__device__ __forceinline__ void warp_trunc(const double* m, long long& y, long long& x)
+{
+    const double xd = (double)x, yd = (double)y;
+    double w = __dadd_rn(__dadd_rn(__dmul_rn(xd, m[6]), __dmul_rn(yd, m[7])), m[8]);
+    w = (fabs(w) > 2.220446049250313e-16) ? 1.0 / w : 0.0;
+    const double xo = __dmul_rn(__dadd_rn(__dadd_rn(__dmul_rn(xd, m[0]), __dmul_rn(yd, m[1])), m[2]), w);
+    const double yo = __dmul_rn(__dadd_rn(__dadd_rn(__dmul_rn(xd, m[3]), __dmul_rn(yd, m[4])), m[5]), w);
+    x = (long long)xo; y = (long long)yo;
+}
+
+__global__ __launch_bounds__(256) void rep_warp_kernel(const int* __restrict__ kp_yx, const int* __restrict__ kp_count,
+                                                       const double* __restrict__ hom, int K, int H, int W,
+                                                       long long* __restrict__ warped, int* __restrict__ out)
+{
+    const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    const int n = min(kp_count[b], K);
+    int inside = 0;
+    if (k < n) {
+        long long y = kp_yx[((size_t)b * K + k) * 2], x = kp_yx[((size_t)b * K + k) * 2 + 1];
+        warp_trunc(hom + (size_t)b * 18, y, x);
+        warp_trunc(hom + (size_t)b * 18 + 9, y, x);
+        inside = (y >= 0) & (x >= 0) & (y < H) & (x < W);
+        warped[((size_t)b * K + k) * 2] = inside ? y : -1;          // -1: filtered out
+        warped[((size_t)b * K + k) * 2 + 1] = x;
+    }
+    const unsigned long long bal = __ballot(inside);
+    // out[p]: count1, count2, N_thermal, N_optical
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&out[(b >> 1) * 4 + ((b & 1) ? 2 : 3)], __popcll(bal));
+}
+
+// one thread per warped point of slot b; the other image's keypoints are scanned from LDS
+__global__ __launch_bounds__(256) void rep_count_kernel(const int* __restrict__ kp_yx, const int* __restrict__ kp_count,
+                                                        const long long* __restrict__ warped, int K, double thr,
+                                                        int* __restrict__ out)
+{
+    __shared__ int oth[256 * 2];
+    const int b = blockIdx.y, ob = b ^ 1;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    const int n = min(kp_count[b], K), m = min(kp_count[ob], K);
+    long long wy = -1, wx = 0;
+    if (k < n) { wy = warped[((size_t)b * K + k) * 2]; wx = warped[((size_t)b * K + k) * 2 + 1]; }
+    const bool live = wy >= 0;
+    int hit = 0;
+    for (int j0 = 0; j0 < m; j0 += 256) {
+        __syncthreads();
+        if (j0 + threadIdx.x < m) {
+            oth[threadIdx.x * 2] = kp_yx[((size_t)ob * K + j0 + threadIdx.x) * 2];
+            oth[threadIdx.x * 2 + 1] = kp_yx[((size_t)ob * K + j0 + threadIdx.x) * 2 + 1];
+        }
+        __syncthreads();
+        if (live) {
+            const int cnt = min(256, m - j0);
+            for (int j = 0; j < cnt; ++j) {
+                const long long dy = wy - oth[j * 2], dx = wx - oth[j * 2 + 1];
+                hit |= sqrt((double)(dy * dy + dx * dx)) <= thr;          // np.linalg.norm of an int array: float64
+            }
+        }
+    }
+    const unsigned long long bal = __ballot(hit);
+    // warped THERMAL points near an optical keypoint -> count1; warped OPTICAL points near a thermal one -> count2
+    if ((threadIdx.x & 63) == 0 && bal) atomicAdd(&out[(b >> 1) * 4 + ((b & 1) ? 0 : 1)], __popcll(bal));
+}
+
 }  // namespace
+
+void launch_repeatability(const int* kp_yx, const int* kp_count, const double* hom, int P, int K, int H, int W, double thr,
+                          long long* warped, int* out, hipStream_t s)
+{
+    const dim3 g((K + 255) / 256, 2 * P);
+    hipLaunchKernelGGL(rep_warp_kernel, g, dim3(256), 0, s, kp_yx, kp_count, hom, K, H, W, warped, out);
+    hipLaunchKernelGGL(rep_count_kernel, g, dim3(256), 0, s, kp_yx, kp_count, warped, K, thr, out);
+}
 
 void launch_pair_metrics(const int* kp_yx, const int* kp_count, const int* match_idx, const double* hom, int P, int K,
                          int H, int W, float thr, double* warped, int* inv_idx, unsigned char* tp, int* metrics,

@@ -128,3 +128,60 @@ def summarize_descriptor_metrics(tp_optical, distance_optical, tp_thermal, dista
         'm_score_optical': m_score_optical, 'm_score_thermal': m_score_thermal, 'm_score': m_score,
         'pts_dist': None, 'average_h_error': None, 'h_correctness': None,
     }
+
+
+def repeatability_counts(kp_yx, kp_count, h_optical, h_thermal, H, W, distance_thresh):
+    """GPU arithmetic of evaluation.py:156-199 on interleaved keypoint lists (slot 2p optical, 2p+1 thermal).
+    Returns a [P,4] int32 device tensor: count1, count2, N_thermal, N_optical."""
+    dev = kp_yx.device
+    P = kp_yx.shape[0] // 2
+    K = kp_yx.shape[1]
+    ho = torch.as_tensor(h_optical, dtype=torch.float32).cpu().reshape(P, 3, 3)
+    ht = torch.as_tensor(h_thermal, dtype=torch.float32).cpu().reshape(P, 3, 3)
+    hoi, hti = torch.linalg.inv(ho), torch.linalg.inv(ht)          # fp32 like h.squeeze().inverse() (:168,173)
+    hom = torch.stack([torch.stack([hoi, ht], 1), torch.stack([hti, ho], 1)], 1)       # [P][slot][warp][3][3]
+    hom = hom.reshape(2 * P, 18).to(torch.float64).to(dev).contiguous()
+    counts = torch.empty((P, 4), dtype=torch.int32, device=dev)
+    h = _lib.get_handle(dev)
+    with torch.cuda.device(dev):
+        h.check(h.lib.mp_repeatability(h.ptr, _lib.ptr(kp_yx.contiguous()), _lib.ptr(kp_count.contiguous()), _lib.ptr(hom),
+                                       P, K, int(H), int(W), float(distance_thresh), _lib.ptr(counts),
+                                       _lib.stream_ptr(dev)))
+    return counts
+
+
+def compute_repeatability_multispectral(net, dataloader, device, config, distance_thresh=3, verbose=False):
+    """Same signature and return value as the reference (evaluation.py:105-200):
+    (mean repeatability, per-sample list, n_kp_optical, n_kp_thermal).  `config` is the whole yaml dict."""
+    from .utils import box_nms, data_to_device, extract_keypoints
+    pred = config['prediction']
+    thr = pred['detection_threshold']
+    cap = pred['topk'] if pred.get('topk', 0) > 0 else 4096
+    repeatability, n_kp_optical, n_kp_thermal = [], [], []
+    for data in dataloader:
+        B = data['optical']['image'].shape[0]
+        eye = torch.eye(3).repeat(B, 1, 1)
+        ho = data['optical'].get('homography', eye)
+        ht = data['thermal'].get('homography', eye)
+        data = data_to_device(data, device)
+        img = torch.stack([data['optical']['image'], data['thermal']['image']], 1).flatten(0, 1)     # interleaved
+        mask = torch.stack([data['optical']['valid_mask'], data['thermal']['valid_mask']], 1).flatten(0, 1)
+        flags = (torch.arange(2 * B) % 2 == 0).reshape(-1, 1)
+        prob = net({'image': img, 'is_optical': flags})['prob']
+        if pred['nms'] > 0:
+            prob = box_nms(prob, pred['nms'], thr, keep_top_k=pred['topk'], on_cpu=pred.get('cpu_nms', False))
+        # keypoints: nonzero((prob > thr) * mask)  (:156-157) -- the mask is applied AFTER the NMS here
+        prob = prob * mask.to(prob.dtype)
+        kp, _, cnt = extract_keypoints(prob, thr, cap)
+        H, W = prob.shape[2:]
+        c = repeatability_counts(kp, cnt, ho, ht, H, W, distance_thresh).cpu().numpy()
+        cnt = cnt.cpu().numpy()
+        if (cnt > cap).any():
+            raise RuntimeError('more than %d keypoints in an image: set prediction.topk' % cap)
+        for p in range(B):
+            n_kp_optical.append(int(cnt[2 * p])); n_kp_thermal.append(int(cnt[2 * p + 1]))
+            if c[p, 2] + c[p, 3] > 0:
+                repeatability.append((c[p, 0] + c[p, 1]) / (c[p, 2] + c[p, 3]))
+                if verbose:
+                    print('repeatability: %f' % repeatability[-1])
+    return np.mean(repeatability), repeatability, n_kp_optical, n_kp_thermal

@@ -596,6 +596,30 @@ def descriptor_metrics_pair(kp_optical, kp_thermal, match_query, match_train, h_
                 N_optical=inside(warped_o), N_thermal=inside(warped_t))
 
 
+def repeatability_pair(kp_optical, kp_thermal, h_optical, h_thermal, H, W, distance_thresh):
+    """Per-sample arithmetic of utils.compute_repeatability_multispectral (multipoint/utils/evaluation.py:165-199);
+    warp_keypoints here has its default integer return type (truncation after each warp).
+    Returns (count1, count2, N_thermal, N_optical)."""
+    ho = torch.as_tensor(h_optical, dtype=torch.float32); ht = torch.as_tensor(h_thermal, dtype=torch.float32)
+    kp_o = np.asarray(kp_optical, dtype=np.int64).reshape(-1, 2); kp_t = np.asarray(kp_thermal, dtype=np.int64).reshape(-1, 2)
+
+    def warp_int(kp, h):
+        return warp_keypoints(kp, h).astype(int) if len(kp) else kp
+
+    def filt(p):
+        return p[(p[:, 0] >= 0) & (p[:, 1] >= 0) & (p[:, 0] < H) & (p[:, 1] < W)] if len(p) else p
+    w_o = filt(warp_int(warp_int(kp_o, ho.inverse().numpy()), ht.numpy()))           # :168-170
+    w_t = filt(warp_int(warp_int(kp_t, ht.inverse().numpy()), ho.numpy()))           # :173-175
+    count1 = count2 = 0
+    if len(kp_o) and len(w_t):
+        d = np.linalg.norm(w_t[:, None] - kp_o[None], axis=2)                         # :186,191-193
+        count1 = int((d.min(axis=1) <= distance_thresh).sum())
+    if len(kp_t) and len(w_o):
+        d = np.linalg.norm(w_o[:, None] - kp_t[None], axis=2)
+        count2 = int((d.min(axis=1) <= distance_thresh).sum())
+    return count1, count2, len(w_t), len(w_o)
+
+
 def process_pairs(sd, cfg, optical, thermal, nms=4, detection_threshold=0.015, topk=1000,
                   mask_optical=None, mask_thermal=None):
     """optical/thermal: (P,1,H,W) torch fp32.  Returns per-pair dicts with keypoints, descriptors

@@ -1,8 +1,10 @@
 #!/usr/bin/env python3
 """Drop-in for the hot path of the reference's predict_keypoints.py (flags -y -m -v -i -r -p -e -b -t
 -mask -s): forward + box_nms (without the valid-mask multiply, reference predict_keypoints.py:136-156)
-for a single sample or a batch (-b).  Drawing (-p) is replaced by a text summary; the repeatability /
-detector-mAP evaluation (-e) is CPU post-processing outside the accelerated path."""
+for a single sample or a batch (-b).  -e computes the keypoint repeatability of an image-pair dataset like the
+reference (utils.compute_repeatability_multispectral; per-sample arithmetic on the GPU); the single-image detector
+mAP (compute_detector_metrics, needs labelled keypoints) is outside the accelerated path.  Drawing (-p) is replaced
+by a text summary."""
 import argparse
 import os
 import time
@@ -48,8 +50,24 @@ def main(argv=None):
 
     with torch.no_grad():
         if args.evaluation:
-            raise NotImplementedError('repeatability / detector mAP (-e) is CPU post-processing outside the '
-                                      'accelerated hot path; use predict_align_image_pair.py -e for the batched driver')
+            # reference predict_keypoints.py:60-107
+            import random
+            random.seed(args.seed); np.random.seed(args.seed); torch.manual_seed(args.seed)
+            if not dataset.returns_pair():
+                raise NotImplementedError('single-image detector mAP (compute_detector_metrics) is outside the '
+                                          'accelerated hot path')
+            repeatability_mean, repeatability, n_kp_optical, n_kp_thermal = utils.compute_repeatability_multispectral(
+                net, loader_dataset, device, config, distance_thresh=args.threshold)
+            print('Repeatability: {}'.format(repeatability_mean))
+            print('Number of optical keypoints: {}'.format(np.mean(n_kp_optical)))
+            print('Number of thermal keypoints: {}'.format(np.mean(n_kp_thermal)))
+            results = {'repeatability_mean': repeatability_mean, 'repeatability': repeatability,
+                       'n_kp_optical': n_kp_optical, 'n_kp_thermal': n_kp_thermal,
+                       'distance_threshold': args.threshold, 'config': config}
+            target_dir = os.path.join(args.model_dir, 'detector_evaluation')
+            os.makedirs(target_dir, exist_ok=True)
+            np.save(os.path.join(target_dir, os.path.split(args.model_dir.strip('/'))[-1] + '_' +
+                                 time.strftime('%Y-%m-%d_%H-%M-%S', time.gmtime())), results)
         t_start = time.time()
         if args.batch:
             for i in range(args.index + 1):

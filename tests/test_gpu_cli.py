@@ -56,5 +56,10 @@ def test_predict_keypoints_cli(model_dir):
     assert out.returncode == 0, out.stderr[-2000:]
     assert 'optical keypoints per image: [300, 300]' in out.stdout
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'predict_keypoints.py'), '-y', str(model_dir / 'cfg.yaml'),
+                          '-m', str(model_dir / 'multipoint'), '-e'], capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'Repeatability:' in out.stdout and 'Number of optical keypoints: 300.0' in out.stdout
+    assert os.listdir(model_dir / 'multipoint' / 'detector_evaluation')
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'predict_keypoints.py'), '-y', str(model_dir / 'cfg.yaml'),
                           '-m', str(model_dir / 'multipoint'), '-v', 'none'], capture_output=True, text=True, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]

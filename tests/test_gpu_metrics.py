@@ -87,3 +87,31 @@ def test_compute_descriptor_metrics_end_to_end(oracle):
     assert len(out['tp_optical']) > 100 and out['tp_optical'].all() and out['tp_thermal'].all()
     assert abs(out['nn_map'] - 1.0) < 1e-9 and abs(out['m_score'] - 1.0) < 1e-9
     assert out['h_correctness'] is None
+
+
+@pytest.mark.parametrize('P,K,H,W,strength', [(3, 300, 240, 320, 1.0), (2, 1000, 480, 640, 0.3), (2, 64, 64, 64, 0.0)])
+def test_repeatability_counts_bit_exact(oracle, P, K, H, W, strength):
+    import multipoint_amd.utils as U
+    rng = np.random.default_rng(7 * K + P)
+    hs = [(_random_homography(rng, H, W, strength), _random_homography(rng, H, W, strength)) for _ in range(P)]
+    res, kp, cnt, _ = _make_results(rng, P, K, H, W, hs, 'ragged')
+    kp = np.clip(kp, 0, [H - 1, W - 1]).astype(np.int32)                   # detector keypoints are always inside the image
+    for thr in (3, 1.5):
+        c = U.repeatability_counts(torch.from_numpy(kp).cuda(), res.kp_count, np.stack([h[0] for h in hs]),
+                                   np.stack([h[1] for h in hs]), H, W, thr).cpu().numpy()
+        for p in range(P):
+            ref = oracle.repeatability_pair(kp[2 * p, :cnt[2 * p]], kp[2 * p + 1, :cnt[2 * p + 1]], hs[p][0], hs[p][1], H, W, thr)
+            assert tuple(int(v) for v in c[p]) == ref
+
+
+def test_compute_repeatability_end_to_end(oracle):
+    import multipoint_amd.models as M
+    import multipoint_amd.utils as U
+    cfg = oracle.SHIPPED_MODEL_CONFIG
+    net = M.MultiPoint(dict(cfg)); net.load_state_dict(oracle.make_weights(0, cfg)); net.to('cuda'); net.eval()
+    img = oracle.make_images(5, 2, 120, 160)
+    ones = torch.ones_like(img, dtype=torch.bool)
+    batch = {'optical': {'image': img, 'valid_mask': ones}, 'thermal': {'image': img.clone(), 'valid_mask': ones}}
+    config = {'prediction': {'nms': 4, 'detection_threshold': 0.015, 'topk': 300, 'cpu_nms': False}}
+    mean, rep, n_o, n_t = U.compute_repeatability_multispectral(net, [batch], torch.device('cuda'), config, distance_thresh=3)
+    assert mean == 1.0 and len(rep) == 2 and n_o == n_t and all(n > 50 for n in n_o)

@@ -193,3 +193,53 @@ def test_descriptor_metrics_against_reference_driver(oracle, ref, monkeypatch):
     assert abs(r['m_score'] - mine['m_score']) < 1e-12
     assert abs(r['nn_map_optical'] - mine['nn_map_optical']) < 1e-6 and abs(r['nn_map_thermal'] - mine['nn_map_thermal']) < 1e-6
     assert np.allclose(r['recall_optical'][-2], mine['recall_optical'][-2])
+
+
+def test_repeatability_against_reference_driver(oracle, ref, monkeypatch):
+    """The reference's compute_repeatability_multispectral (evaluation.py:105-200) run here with oracle stubs for the
+    absent torchvision / cv2 calls, against oracle.repeatability_pair on the oracle's own keypoints."""
+    import sys
+    models, utils = ref
+    import multipoint.utils.evaluation as ev
+    import multipoint.utils.utils as ru
+    cv2 = sys.modules['cv2']
+
+    def nms(boxes, scores, iou):
+        keep = oracle.nms_greedy(boxes.numpy().astype(np.float32), scores.numpy().astype(np.float32), float(iou))
+        return torch.as_tensor(np.asarray(keep), dtype=torch.int64)
+
+    def batched_nms(boxes, scores, idxs, iou):
+        keep = []
+        for i in torch.unique(idxs):
+            sel = torch.nonzero(idxs == i)[:, 0]
+            keep.append(sel[nms(boxes[sel], scores[sel], iou)])
+        keep = torch.cat(keep) if keep else torch.zeros(0, dtype=torch.int64)
+        return keep[torch.argsort(scores[keep], descending=True, stable=True)]
+    monkeypatch.setattr(ru, 'nms', nms, raising=False); monkeypatch.setattr(ru, 'batched_nms', batched_nms, raising=False)
+    monkeypatch.setattr(cv2, 'perspectiveTransform',
+                        lambda pts, h: oracle.warp_keypoints(pts[0][:, ::-1], h)[None, :, ::-1], raising=False)
+    cfg = dict(oracle.SHIPPED_MODEL_CONFIG)
+    sd = oracle.make_weights(33, cfg)
+    net = models.MultiPoint(dict(cfg)).eval(); net.load_state_dict(sd)
+    H, W, B = 96, 128, 3
+    rng = np.random.default_rng(6)
+    opt = oracle.make_images(43, B, H, W)
+    th = (opt + 0.02 * torch.from_numpy(rng.standard_normal(opt.shape).astype(np.float32))).clamp(0, 1)
+    ho = torch.eye(3).repeat(B, 1, 1); ht = torch.eye(3).repeat(B, 1, 1)
+    ht[:, 0, 2] = torch.tensor([0.0, 2.0, -3.0]); ho[2, 1, 2] = 1.5; ht[1, 0, 0] = 1.02
+    ones = torch.ones((B, 1, H, W), dtype=torch.bool)
+    batch = {'optical': {'image': opt, 'valid_mask': ones, 'homography': ho}, 'thermal': {'image': th, 'valid_mask': ones, 'homography': ht}}
+    config = {'prediction': {'nms': 4, 'detection_threshold': 0.015, 'topk': 120, 'cpu_nms': True}}
+    with torch.no_grad():
+        mean, rep, n_o, n_t = ev.compute_repeatability_multispectral(net, [batch], torch.device('cpu'), config, distance_thresh=3)
+    mine = []
+    for p in range(B):
+        kps = []
+        for img in (opt, th):
+            prob = oracle.forward(sd, img[p:p + 1], cfg)['prob']
+            nmsp = oracle.box_nms(prob.numpy(), 4, 0.015, keep_top_k=120)
+            kps.append(oracle.keypoints_from_map(nmsp[0, 0], 0.015))
+        assert len(kps[0]) == n_o[p] and len(kps[1]) == n_t[p]
+        c1, c2, nt, no = oracle.repeatability_pair(kps[0], kps[1], ho[p], ht[p], H, W, 3)
+        mine.append((c1 + c2) / (nt + no))
+    assert np.allclose(rep, mine, atol=1e-12) and 0.2 < mean < 1.0
