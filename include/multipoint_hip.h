@@ -153,6 +153,18 @@ int mp_pair_metrics(mp_handle* h, const int* kp_yx, const int* kp_count, const i
 int mp_repeatability(mp_handle* h, const int* kp_yx, const int* kp_count, const double* homography, int P, int K, int H,
                      int W, double distance_thresh, int* counts, void* stream);
 
+/* replaces cv2.findHomography(optical_pts, thermal_pts, cv2.RANSAC, ransacReprojThreshold) on the matched keypoints
+ * (predict_align_image_pair.py:205-216, multipoint/utils/evaluation.py:330-349) for P pairs (slot 2p optical, 2p+1
+ * thermal).  Not a bit-level restatement of OpenCV (absent third-party code with its own RNG): max_iters hypotheses
+ * from 4 random matches each (counter-based RNG on `seed`: reproducible), forward reprojection error test, most
+ * inliers wins, normalised-DLT refit over the winner's inliers.
+ *   homography   device double [P][9], row-major, maps optical (x, y, 1) to thermal; all zeros when < 4 matches or
+ *                no hypothesis found 4 inliers (the reference's `H_est is None`)
+ *   inlier_mask  uint8 [P][K] per OPTICAL keypoint (1 = its match is an inlier); n_inliers int32 [P] */
+int mp_find_homography(mp_handle* h, const int* kp_yx, const int* kp_count, const int* match_idx, int P, int K,
+                       double reproj_threshold, int max_iters, unsigned long long seed, double* homography,
+                       unsigned char* inlier_mask, int* n_inliers, void* stream);
+
 /* per-launch timing of mp_forward with hipEvents on the caller's stream (bench.py roofline leg).
  * mp_profile_read synchronises; names[i] points to static strings. */
 int mp_profile_enable(mp_handle* h, int enable);

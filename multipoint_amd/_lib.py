@@ -52,6 +52,8 @@ SIGNATURES = {
                                 c_void_p, c_void_p, c_void_p]),
     'mp_repeatability': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_double,
                                  c_void_p, c_void_p]),
+    'mp_find_homography': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_double, c_int,
+                                   ctypes.c_ulonglong, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mp_profile_enable': (c_int, [c_void_p, c_int]),
     'mp_profile_read': (c_int, [c_void_p, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_float),
                                 ctypes.POINTER(ctypes.c_double), c_int, ctypes.POINTER(c_int)]),

@@ -911,6 +911,29 @@ int mp_repeatability(mp_handle* h, const int* kp_yx, const int* kp_count, const 
     return MP_OK;
 }
 
+int mp_find_homography(mp_handle* h, const int* kp_yx, const int* kp_count, const int* match_idx, int P, int K,
+                       double reproj_threshold, int max_iters, unsigned long long seed, double* homography,
+                       unsigned char* inlier_mask, int* n_inliers, void* stream)
+{
+    if (!h) return MP_EINVAL;
+    if (!kp_yx || !kp_count || !match_idx || !homography || !inlier_mask || !n_inliers)
+        return fail(h, MP_EINVAL, "mp_find_homography: NULL tensor");
+    if (P <= 0 || K <= 0 || K > 3200) return fail(h, MP_EINVAL, "mp_find_homography: need P > 0 and 0 < K <= 3200");
+    if (max_iters <= 0 || max_iters > (1 << 20)) return fail(h, MP_EINVAL, "mp_find_homography: max_iters out of range");
+    if (!(reproj_threshold > 0.0)) return fail(h, MP_EINVAL, "mp_find_homography: threshold must be positive");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MP_HIP(hipSetDevice(h->device));
+    int rc;
+    if ((rc = ensure(h, h->ws4, (size_t)P * sizeof(unsigned long long)))) return rc;
+    unsigned long long* best = static_cast<unsigned long long*>(h->ws4.p);
+    MP_HIP(hipMemsetAsync(best, 0, (size_t)P * sizeof(unsigned long long), s));
+    MP_HIP(hipMemsetAsync(inlier_mask, 0, (size_t)P * K, s));
+    launch_ransac_homography(kp_yx, kp_count, match_idx, P, K, max_iters, reproj_threshold, seed, best, homography,
+                             inlier_mask, n_inliers, s);
+    MP_HIP(hipGetLastError());
+    return MP_OK;
+}
+
 int mp_profile_enable(mp_handle* h, int enable)
 {
     if (!h) return MP_EINVAL;

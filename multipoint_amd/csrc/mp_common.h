@@ -147,3 +147,8 @@ void launch_pair_metrics(const int* kp_yx, const int* kp_count, const int* match
 // other image's homography), warped [2P][K][2] int64 scratch, out [P][4] (pre-set to 0): count1, count2, N_thermal, N_optical
 void launch_repeatability(const int* kp_yx, const int* kp_count, const double* hom, int P, int K, int H, int W, double thr,
                           long long* warped, int* out, hipStream_t s);
+// batched RANSAC homography (predict_align_image_pair.py:205-216): best [P] scratch (pre-set to 0), H_out [P][9] double
+// (x,y) optical -> (x,y) thermal, mask [P][K] uint8 per optical keypoint (pre-set to 0), n_inliers [P]
+void launch_ransac_homography(const int* kp_yx, const int* kp_count, const int* match_idx, int P, int K, int T, double thr,
+                              unsigned long long seed, unsigned long long* best, double* H_out, unsigned char* mask,
+                              int* n_inliers, hipStream_t s);

@@ -5,8 +5,9 @@ ground-truth homography, the N x M correctness test, true positives of the match
 behind mp_pair_metrics.  Only the final precision/recall bookkeeping over the concatenated match lists is numpy, as
 in the reference (:360-419).
 
-Not accelerated (and not computed): the RANSAC homography estimate `cv2.findHomography` and the 4-corner error
-derived from it (:330-356) -- `pts_dist`, `average_h_error` and `h_correctness` are returned as None."""
+The RANSAC homography estimate (:330-349, cv2.findHomography) runs on the GPU as well (mp_find_homography: same
+algorithm family, not OpenCV's RNG, so estimates agree with OpenCV's only to the reprojection tolerance); the
+4-corner error derived from it (:351-356) is four points of numpy per pair."""
 import ctypes
 
 import numpy as np
@@ -59,13 +60,57 @@ def pair_metrics(res, homography, threshold_keypoints):
     return metrics, tp
 
 
+def find_homography(res, reproj_threshold=3.0, max_iters=2000, seed=0):
+    """Batched cv2.findHomography(optical_pts, thermal_pts, cv2.RANSAC, reproj_threshold) for the pairs of a PairResults
+    (predict_align_image_pair.py:205-216).  Returns (H [P,3,3] float64 mapping optical (x,y,1) to thermal -- all zeros
+    where the reference would get None --, inlier mask [P,K] uint8 per optical keypoint, n_inliers [P] int32)."""
+    res.wait()
+    dev = res.kp_yx.device
+    P, K = res.num_pairs, res.kp_yx.shape[1]
+    Hm = torch.empty((P, 3, 3), dtype=torch.float64, device=dev)
+    mask = torch.empty((P, K), dtype=torch.uint8, device=dev)
+    nin = torch.empty((P,), dtype=torch.int32, device=dev)
+    h = _lib.get_handle(dev)
+    with torch.cuda.device(dev):
+        h.check(h.lib.mp_find_homography(h.ptr, _lib.ptr(res.kp_yx.contiguous()), _lib.ptr(res.kp_count.contiguous()),
+                                         _lib.ptr(res.match_idx.contiguous()), P, K, float(reproj_threshold), int(max_iters),
+                                         int(seed), _lib.ptr(Hm), _lib.ptr(mask), _lib.ptr(nin), _lib.stream_ptr(dev)))
+    return Hm, mask, nin
+
+
+def find_homography_points(optical_pts, thermal_pts, reproj_threshold=3.0, max_iters=2000, seed=0, device=None):
+    """cv2.findHomography(optical_pts, thermal_pts, cv2.RANSAC, reproj_threshold) for ONE set of corresponding (x, y)
+    points (integer pixel positions, as keypoints are).  Returns (H 3x3 float64 numpy or None, mask (N,) uint8)."""
+    from ..pipeline import PairResults
+    a = np.asarray(optical_pts).reshape(-1, 2); b = np.asarray(thermal_pts).reshape(-1, 2)
+    n = len(a)
+    if n < 4:
+        return None, np.zeros(n, np.uint8)
+    dev = _lib.require_cuda(device)
+    kp = torch.zeros((2, n, 2), dtype=torch.int32)
+    kp[0] = torch.from_numpy(np.ascontiguousarray(a[:, ::-1]).astype(np.int32)); kp[1] = torch.from_numpy(np.ascontiguousarray(b[:, ::-1]).astype(np.int32))
+    res = PairResults(kp.to(dev), None, torch.tensor([n, n], dtype=torch.int32, device=dev), None,
+                      torch.arange(n, dtype=torch.int32, device=dev).reshape(1, n), None, None, 0, 0)
+    Hm, mask, nin = find_homography(res, reproj_threshold, max_iters, seed)
+    if int(nin[0]) < 4:
+        return None, np.zeros(n, np.uint8)
+    return Hm[0].cpu().numpy(), mask[0].cpu().numpy()
+
+
+def _warp_yx(pts_yx, hmat):
+    """warp_keypoints(..., np.float) for a handful of points (homographies.py:331-346)."""
+    p = np.asarray(pts_yx, dtype=np.float64)
+    m = np.asarray(hmat, dtype=np.float64).reshape(3, 3)
+    xy1 = np.concatenate([p[:, ::-1], np.ones((len(p), 1))], 1) @ m.T
+    return (xy1[:, :2] / xy1[:, 2:3])[:, ::-1]
+
+
 def compute_descriptor_metrics(net, dataloader, device, config, threshold_keypoints, threshold_warp=None):
-    """Same signature and result keys as the reference function (evaluation.py:209); see the module docstring for
-    what is left out."""
+    """Same signature and result keys as the reference function (evaluation.py:209)."""
     from ..pipeline import PairPipeline
     from .utils import data_to_device
     pipe = PairPipeline(net, config)
-    tp_o, tp_t, dist_o, dist_t, ms_o, ms_t = [], [], [], [], [], []
+    tp_o, tp_t, dist_o, dist_t, ms_o, ms_t, pts_dist = [], [], [], [], [], [], []
     n_gt_o = n_gt_t = 0
     for data in dataloader:
         data = data_to_device(data, device)
@@ -75,8 +120,12 @@ def compute_descriptor_metrics(net, dataloader, device, config, threshold_keypoi
         ho = opt.get('homography', eye)
         ht = th.get('homography', eye)
         res = pipe(opt['image'], th['image'], opt.get('valid_mask'), th.get('valid_mask'))
-        metrics, tp = pair_metrics(res, ground_truth_homographies(ho, ht), threshold_keypoints)
+        gth = ground_truth_homographies(ho, ht)
+        metrics, tp = pair_metrics(res, gth, threshold_keypoints)
+        h_est, _, n_in = find_homography(res, config.get('reprojection_threshold', 3))
         pipe.check_converged()
+        h_est = h_est.cpu().numpy(); n_in = n_in.cpu().numpy()
+        H_o, W_o = opt['image'].shape[2:]
         m = metrics.cpu().numpy(); tp = tp.cpu().numpy()
         midx = res.match_idx.cpu().numpy(); mdist = res.match_dist.cpu().numpy()
         cnt = res.kp_count.cpu().numpy()
@@ -91,11 +140,23 @@ def compute_descriptor_metrics(net, dataloader, device, config, threshold_keypoi
             n_gt_o += int(m[p, 0]); n_gt_t += int(m[p, 1])
             ms_o.append(float(m[p, 2]) / m[p, 4] if m[p, 4] > 0 else 0.0)
             ms_t.append(float(m[p, 3]) / m[p, 5] if m[p, 5] > 0 else 0.0)
-    return summarize_descriptor_metrics(np.concatenate(tp_o) if tp_o else np.zeros(0, bool),
+            # homography correctness (:351-356; the reference's corner list, including its (H_o, H_o) last point)
+            if n_in[p] >= 4:
+                pts = np.array([[0, 0], [H_o, 0], [0, W_o], [H_o, H_o]])
+                gt = gth[2 * p].numpy().reshape(3, 3)
+                pts_dist.append(np.linalg.norm(_warp_yx(pts, h_est[p]) - _warp_yx(pts, gt), axis=1).sum() / 4)
+            else:
+                pts_dist.append(999.0)
+    out = summarize_descriptor_metrics(np.concatenate(tp_o) if tp_o else np.zeros(0, bool),
                                         np.concatenate(dist_o) if dist_o else np.zeros(0, np.float32),
                                         np.concatenate(tp_t) if tp_t else np.zeros(0, bool),
                                         np.concatenate(dist_t) if dist_t else np.zeros(0, np.float32),
                                         n_gt_o, n_gt_t, np.array(ms_o), np.array(ms_t))
+    pts_dist = np.array(pts_dist)
+    out['pts_dist'] = pts_dist
+    out['average_h_error'] = pts_dist.mean() if len(pts_dist) else None
+    out['h_correctness'] = (pts_dist < threshold_warp).sum() / len(pts_dist) if len(pts_dist) and threshold_warp is not None else None
+    return out
 
 
 def summarize_descriptor_metrics(tp_optical, distance_optical, tp_thermal, distance_thermal, n_gt_optical,

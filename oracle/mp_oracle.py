@@ -620,6 +620,81 @@ def repeatability_pair(kp_optical, kp_thermal, h_optical, h_thermal, H, W, dista
     return count1, count2, len(w_t), len(w_o)
 
 
+_M64 = (1 << 64) - 1
+
+
+def _mix64(z):
+    z = (z + 0x9e3779b97f4a7c15) & _M64
+    z = ((z ^ (z >> 30)) * 0xbf58476d1ce4e5b9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94d049bb133111eb) & _M64
+    return z ^ (z >> 31)
+
+
+def ransac_homography(pts_optical_xy, pts_thermal_xy, reproj_threshold, max_iters, seed, pair_index):
+    """CPU restatement of the PRODUCT's RANSAC (multipoint_amd/csrc/homography.hip) -- the stand-in for
+    cv2.findHomography(..., cv2.RANSAC, thr) (predict_align_image_pair.py:216; OpenCV absent: PARITY UNPINNED against
+    it).  Same counter-based sampling, exact 4-point solve, forward reprojection test, lowest-index tie-break and
+    normalised-DLT refit, so the GPU result can be checked for the same winner / inlier set and H to rounding.
+    Returns (H 3x3 float64 or None, inlier mask (n,) bool)."""
+    a = np.asarray(pts_optical_xy, dtype=np.float32).astype(np.float64).reshape(-1, 2)
+    b = np.asarray(pts_thermal_xy, dtype=np.float32).astype(np.float64).reshape(-1, 2)
+    n = len(a)
+    if n < 4:
+        return None, np.zeros(n, bool)
+    thr2 = float(reproj_threshold) ** 2
+
+    def inliers(h):
+        w = h[6] * a[:, 0] + h[7] * a[:, 1] + h[8]
+        ok = np.abs(w) >= 1e-12
+        iw = 1.0 / np.where(ok, w, 1.0)
+        du = (h[0] * a[:, 0] + h[1] * a[:, 1] + h[2]) * iw - b[:, 0]
+        dv = (h[3] * a[:, 0] + h[4] * a[:, 1] + h[5]) * iw - b[:, 1]
+        return ok & (du * du + dv * dv <= thr2)
+
+    def hypothesis(t):
+        ctr = _mix64((seed ^ (pair_index << 32) ^ t) & _M64)
+        idx = []
+        while len(idx) < 4:
+            ctr = _mix64(ctr)
+            c = ctr % n
+            if c not in idx:
+                idx.append(c)
+        m = np.zeros((8, 8)); r = np.zeros(8)
+        for k, i in enumerate(idx):
+            x, y = a[i]; u, v = b[i]
+            m[2 * k] = [x, y, 1, 0, 0, 0, -u * x, -u * y]; r[2 * k] = u
+            m[2 * k + 1] = [0, 0, 0, x, y, 1, -v * x, -v * y]; r[2 * k + 1] = v
+        try:
+            if abs(np.linalg.det(m)) < 1e-300 or np.linalg.cond(m) > 1e13:
+                return None
+            return np.append(np.linalg.solve(m, r), 1.0)
+        except np.linalg.LinAlgError:
+            return None
+    best_cnt, best_mask = 0, None
+    for t in range(max_iters):
+        h = hypothesis(t)
+        if h is None:
+            continue
+        mk = inliers(h)
+        if mk.sum() > best_cnt:
+            best_cnt, best_mask = int(mk.sum()), mk
+    if best_cnt < 4:
+        return None, np.zeros(n, bool)
+    pa, pb = a[best_mask], b[best_mask]
+    ca, cb = pa.mean(0), pb.mean(0)
+    sa = np.sqrt(2.0) / max(np.sqrt(((pa - ca) ** 2).sum(1)).mean(), 1e-12)
+    sb = np.sqrt(2.0) / max(np.sqrt(((pb - cb) ** 2).sum(1)).mean(), 1e-12)
+    x, y = ((pa - ca) * sa).T; u, v = ((pb - cb) * sb).T
+    o, z = np.ones_like(x), np.zeros_like(x)
+    A = np.concatenate([np.stack([x, y, o, z, z, z, -u * x, -u * y, -u], 1), np.stack([z, z, z, x, y, o, -v * x, -v * y, -v], 1)])
+    w, vecs = np.linalg.eigh(A.T @ A)
+    hn = vecs[:, 0].reshape(3, 3)
+    t1 = np.array([[sa, 0, -sa * ca[0]], [0, sa, -sa * ca[1]], [0, 0, 1]])
+    t2i = np.array([[1 / sb, 0, cb[0]], [0, 1 / sb, cb[1]], [0, 0, 1]])
+    H = t2i @ hn @ t1
+    return H / H[2, 2], best_mask
+
+
 def process_pairs(sd, cfg, optical, thermal, nms=4, detection_threshold=0.015, topk=1000,
                   mask_optical=None, mask_thermal=None):
     """optical/thermal: (P,1,H,W) torch fp32.  Returns per-pair dicts with keypoints, descriptors

@@ -2,10 +2,10 @@
 """Drop-in for the hot path of the reference's predict_align_image_pair.py: same flags
 (-y -m -v -i -r -p -e -tk -th -s), same yaml keys, same model_weights/<name>/{params.yaml,<version>.model}
 format, same three timing prints (reference predict_align_image_pair.py:141-143) -- computed on an
-MI355X through libmultipoint_hip.so.  -e computes NN-mAP and M-score like the reference
-(utils.compute_descriptor_metrics; per-sample arithmetic on the GPU) but not the RANSAC homography
-correctness (cv2.findHomography is outside the accelerated path).  The matplotlib/cv2 visualisation of
--p is replaced by a text summary of keypoints/matches (and --save-npz)."""
+MI355X through libmultipoint_hip.so.  -e computes NN-mAP, M-score and homography correctness like the
+reference (utils.compute_descriptor_metrics; per-sample arithmetic and a batched RANSAC on the GPU -- the
+RANSAC is the product's own, not OpenCV's RNG).  The matplotlib/cv2 visualisation of -p is replaced by a
+text summary of keypoints/matches, the estimated and the ground-truth homography (and --save-npz)."""
 import argparse
 import os
 import random
@@ -86,14 +86,14 @@ def main(argv=None):
     with torch.no_grad():
         if args.evaluation:
             # reference predict_align_image_pair.py:69-88: utils.compute_descriptor_metrics over the whole loader; the
-            # per-sample arithmetic runs on the GPU (mp_pair_metrics), the RANSAC homography estimate is not computed
+            # per-sample arithmetic (mp_pair_metrics) and the RANSAC homography estimate (mp_find_homography) run on the GPU
             synchronize(); t0 = time.time()
             results = utils.compute_descriptor_metrics(net, loader_dataset, device, pred, args.threshold_keypoints,
                                                        args.threshold_homography)
             synchronize(); dt = time.time() - t0
             print('NN-mAP: {}'.format(results['nn_map']))
             print('M-Score: {}'.format(results['m_score']))
-            print('Homography Correctness: n/a (cv2.findHomography RANSAC is outside the accelerated path)')
+            print('Homography Correctness: {}'.format(results['h_correctness']))
             print('Matches: {}  ({:.1f} pairs/s)'.format(len(results['tp_optical']), len(dataset) / dt))
             results['config'] = config
             results['threshold_keypoints'] = args.threshold_keypoints
@@ -150,6 +150,22 @@ def main(argv=None):
             if matches:
                 d = np.array([m.distance for m in matches])
                 print('Match distance: min {:.4f} mean {:.4f} max {:.4f}'.format(d.min(), d.mean(), d.max()))
+            print('--------------------------------------------------------')
+            # align the images: homography from the matches (reference :209-216) next to the ground truth (:252-257)
+            kpo = pred_optical.cpu().numpy(); kpt = pred_thermal.cpu().numpy()
+            optical_pts = np.array([kpo[m.queryIdx][::-1] for m in matches]).reshape(-1, 2)
+            thermal_pts = np.array([kpt[m.trainIdx][::-1] for m in matches]).reshape(-1, 2)
+            H_est, mask = utils.find_homography_points(optical_pts, thermal_pts, pred['reprojection_threshold'], device=device)
+            if H_est is None:
+                H_est = np.eye(3, 3)
+            eye = torch.eye(3)
+            H_gt = np.matmul(data['thermal'].get('homography', eye[None])[0].cpu().numpy(),
+                             np.linalg.inv(data['optical'].get('homography', eye[None])[0].cpu().numpy()))
+            print('Estimated Homography:')
+            print(H_est)
+            print('RANSAC inliers: {} of {} matches'.format(int(np.sum(mask)), len(matches)))
+            print('Ground Truth Homography:')
+            print(H_gt)
             print('--------------------------------------------------------')
             if args.save_npz:
                 np.savez_compressed(args.save_npz, kp_optical=pred_optical.cpu().numpy(), kp_thermal=pred_thermal.cpu().numpy(),

@@ -35,7 +35,7 @@ def test_predict_align_image_pair_cli(model_dir, oracle):
                          capture_output=True, text=True, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     for line in ('Predicting on device: cuda:0', 'Loading the data took:', 'Two forward passes took:', 'Box nms:',
-                 'NN-mAP:', 'M-Score:'):
+                 'NN-mAP:', 'M-Score:', 'Homography Correctness:', 'Estimated Homography:', 'Ground Truth Homography:'):
         assert line in out.stdout
     g = np.load(npz)
     # same sample through the oracle

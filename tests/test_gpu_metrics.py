@@ -86,7 +86,8 @@ def test_compute_descriptor_metrics_end_to_end(oracle):
         assert k in out
     assert len(out['tp_optical']) > 100 and out['tp_optical'].all() and out['tp_thermal'].all()
     assert abs(out['nn_map'] - 1.0) < 1e-9 and abs(out['m_score'] - 1.0) < 1e-9
-    assert out['h_correctness'] is None
+    # identical images: the estimated homography is the identity to sub-pixel accuracy
+    assert out['pts_dist'].shape == (2,) and out['pts_dist'].max() < 0.5 and out['h_correctness'] == 1.0
 
 
 @pytest.mark.parametrize('P,K,H,W,strength', [(3, 300, 240, 320, 1.0), (2, 1000, 480, 640, 0.3), (2, 64, 64, 64, 0.0)])
@@ -115,3 +116,72 @@ def test_compute_repeatability_end_to_end(oracle):
     config = {'prediction': {'nms': 4, 'detection_threshold': 0.015, 'topk': 300, 'cpu_nms': False}}
     mean, rep, n_o, n_t = U.compute_repeatability_multispectral(net, [batch], torch.device('cuda'), config, distance_thresh=3)
     assert mean == 1.0 and len(rep) == 2 and n_o == n_t and all(n > 50 for n in n_o)
+
+
+def _planted(rng, P, K, H, W, outlier_frac):
+    """Matched keypoint lists with a planted homography per pair: thermal = H(optical) + sub-pixel noise, rounded,
+    a fraction of the matches replaced by random points."""
+    from multipoint_amd.pipeline import PairResults
+    kp = np.zeros((2 * P, K, 2), np.int32); cnt = np.zeros(2 * P, np.int32); midx = -np.ones((P, K), np.int32)
+    planted = []
+    for p in range(P):
+        n = K if p % 2 == 0 else int(K * 0.6)
+        hm = np.eye(3); hm[:2, :2] += rng.normal(0, 0.03, (2, 2)); hm[:2, 2] += rng.normal(0, 8, 2); hm[2, :2] += rng.normal(0, 5e-5, 2)
+        o_xy = np.stack([rng.integers(0, W, n), rng.integers(0, H, n)], 1).astype(np.float64)
+        xy1 = np.concatenate([o_xy, np.ones((n, 1))], 1) @ hm.T
+        t_xy = np.round(xy1[:, :2] / xy1[:, 2:3] + rng.normal(0, 0.3, (n, 2)))
+        bad = rng.random(n) < outlier_frac
+        t_xy[bad] = np.stack([rng.integers(0, W, bad.sum()), rng.integers(0, H, bad.sum())], 1)
+        perm = rng.permutation(n)                                     # thermal list in a different order
+        kp[2 * p, :n] = o_xy[:, ::-1]; kp[2 * p + 1, perm] = t_xy[:, ::-1]
+        cnt[2 * p] = cnt[2 * p + 1] = n
+        matched = rng.random(n) < 0.9
+        midx[p, :n][matched] = perm[matched]
+        planted.append((hm, bad))
+    res = PairResults(torch.from_numpy(kp).cuda(), None, torch.from_numpy(cnt).cuda(), None, torch.from_numpy(midx).cuda(),
+                      torch.zeros((P, K), device='cuda'), None, H, W)
+    return res, kp, cnt, midx, planted
+
+
+@pytest.mark.parametrize('outlier_frac,K', [(0.0, 200), (0.3, 500), (0.6, 1000)])
+def test_find_homography_matches_oracle_and_recovers_planted(oracle, outlier_frac, K):
+    """mp_find_homography against the oracle's CPU restatement of the same algorithm (same winner / inlier set, H to
+    rounding) and against the planted model (the property cv2.findHomography is used for)."""
+    import multipoint_amd.utils as U
+    rng = np.random.default_rng(int(outlier_frac * 10) + K)
+    P, H, W, T, thr = 3, 480, 640, 512, 3.0
+    res, kp, cnt, midx, planted = _planted(rng, P, K, H, W, outlier_frac)
+    Hm, mask, nin = U.find_homography(res, thr, max_iters=T, seed=7)
+    Hm = Hm.cpu().numpy(); mask = mask.cpu().numpy().astype(bool); nin = nin.cpu().numpy()
+    corners = np.array([[0, 0, 1], [W, 0, 1], [0, H, 1], [W, H, 1]], dtype=np.float64)
+    for p in range(P):
+        n = cnt[2 * p]
+        q = np.nonzero(midx[p, :n] >= 0)[0]; t = midx[p, q]
+        a = kp[2 * p, q][:, ::-1]; b = kp[2 * p + 1, t][:, ::-1]
+        Ho, mo = oracle.ransac_homography(a, b, thr, T, 7, p)
+        assert Ho is not None and nin[p] == mo.sum() == mask[p].sum()
+        assert np.array_equal(mask[p, q], mo) and not mask[p, np.setdiff1d(np.arange(K), q)].any()
+        assert np.abs(Hm[p] - Ho).max() <= 1e-6 * max(1.0, np.abs(Ho).max())
+        # planted model: every clean match is an inlier region-wise; corners land within a pixel or two
+        hm, bad = planted[p]
+        ce = corners @ Hm[p].T; cg = corners @ hm.T
+        err = np.linalg.norm(ce[:, :2] / ce[:, 2:3] - cg[:, :2] / cg[:, 2:3], axis=1)
+        assert err.max() < 2.0
+        assert mask[p, q][~bad[q]].mean() > 0.95 and (outlier_frac == 0 or mask[p, q][bad[q]].mean() < 0.1)
+
+
+def test_find_homography_degenerate_inputs():
+    import multipoint_amd.utils as U
+    from multipoint_amd.pipeline import PairResults
+    K = 64
+    kp = torch.zeros((4, K, 2), dtype=torch.int32, device='cuda')
+    cnt = torch.tensor([3, 3, 10, 10], dtype=torch.int32, device='cuda')
+    midx = -torch.ones((2, K), dtype=torch.int32, device='cuda')
+    midx[0, :3] = torch.arange(3, dtype=torch.int32)                 # fewer than 4 matches
+    kp[2, :10, 1] = torch.arange(10, dtype=torch.int32); kp[3, :10, 1] = torch.arange(10, dtype=torch.int32)   # collinear
+    midx[1, :10] = torch.arange(10, dtype=torch.int32)
+    res = PairResults(kp, None, cnt, None, midx, torch.zeros((2, K), device='cuda'), None, 64, 64)
+    Hm, mask, nin = U.find_homography(res, 3.0, max_iters=256)
+    assert nin.tolist() == [0, 0] and not mask.any() and (Hm == 0).all()
+    with pytest.raises(ValueError):
+        U.find_homography(res, -1.0)
