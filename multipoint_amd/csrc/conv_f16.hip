@@ -504,7 +504,7 @@ void launch_h(const ConvParamsH& p, hipStream_t s)
 
 // ---- first encoder block, fp16 flavour: image (fp32 in HBM, rounded to fp16 as autocast casts the conv input)
 //      -> 64 fp16 channels.  HBM-write bound: thread = (pixel, 8 channels), one 16-byte store.
-constexpr int FTH = 8, FTW = 32, FLW = FTW + 2, FLH = FTH + 2;
+constexpr int FTH = 16, FTW = 64, FLW = FTW + 2, FLH = FTH + 2;
 
 __global__ __launch_bounds__(256) void conv_first_f16_kernel(const Conv1ParamsH p)
 {
