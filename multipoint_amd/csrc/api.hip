@@ -63,7 +63,8 @@ struct mp_handle {
     int* nms_total = nullptr;       // device: undecided candidates summed over all calls since the last read
     int last_nms_rounds = 0;
     void* dummy = nullptr;          // scratch line for masked-off store lanes of the fp16 kernels
-    bool persist = true;            // persistent conv workgroups (MP_NO_PERSIST=1 disables)
+    int persist = 8;                // persistent conv workgroups for launches with >= this many items per CU
+                                    // (MP_NO_PERSIST=1: never; MP_PERSIST_MIN_ITEMS=n overrides the threshold)
     bool fuse_first = true;         // fuse the Cin=1 block into the second convolution (MP_NO_FUSE=1 disables)
     int* pinned = nullptr;          // small pinned host scratch (img lists, counters)
     bool prof = false;
@@ -404,7 +405,7 @@ void run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride,
     p.pad_zero = h->cfg.reflection_pad ? 0 : 1;
     p.bn_first = h->cfg.bn_first;
     p.relu = L.relu ? 1 : 0;
-    p.persist = h->persist ? 1 : 0;
+    p.persist = h->persist;
     int mbw = 32;
     if (L.taps == 9) {
         mbw = pick_mbw(H, W);
@@ -606,7 +607,8 @@ int mp_create(mp_handle** out, int device)
     mp_handle* hh = new mp_handle();
     hh->device = device;
     { const char* e = getenv("MP_NO_FUSE"); hh->fuse_first = !(e && e[0] == '1'); }
-    { const char* e = getenv("MP_NO_PERSIST"); hh->persist = !(e && e[0] == '1'); }
+    { const char* e = getenv("MP_PERSIST_MIN_ITEMS"); if (e && atoi(e) > 0) hh->persist = atoi(e); }
+    { const char* e = getenv("MP_NO_PERSIST"); if (e && e[0] == '1') hh->persist = 0; }
     if (hipHostMalloc(reinterpret_cast<void**>(&hh->pinned), 4096) != hipSuccess) {
         delete hh;
         return fail(h, MP_ENOMEM, "mp_create: hipHostMalloc failed");

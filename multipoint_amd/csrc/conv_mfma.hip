@@ -895,8 +895,9 @@ void launch_t(const ConvParams& p, hipStream_t s)
     const ConvParams& pp = q;
     if constexpr (!FUSE1) {
         if constexpr (TAPS == 9) {
-            // persistent workgroups, ONE per CU, when every workgroup gets enough items for the tail not to matter
-            if (p.persist && nblk >= 256 * 8) {
+            // persistent workgroups, ONE per CU, when every workgroup gets enough items (p.persist, default 8) for the
+            // tail not to matter
+            if (p.persist && nblk >= 256ll * p.persist) {
                 if (p.bn_first)
                     hipLaunchKernelGGL((conv_mfma_persist_kernel<TAPS, MBW, POOL, true>), dim3(256), dim3(256), 0, s, pp);
                 else

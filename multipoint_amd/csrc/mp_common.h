@@ -38,7 +38,7 @@ struct ConvParams {
     long long total_px;   // TAPS==1 (flat) mode: number of pixels
     unsigned magic_slices, magic_tx, magic_ty;   // multiply-high division constants (filled in by the launcher)
     int nitems;           // work items (tile, slice) of the launch (filled in by the launcher)
-    int persist;          // 1: persistent workgroups where the layer has enough items (MP_NO_PERSIST=1 disables)
+    int persist;          // 0: per-tile kernel only; n > 0: persistent workgroups for launches with >= n items per CU
 };
 
 // first layer (Cin = 1, direct VALU conv, HBM-write bound)

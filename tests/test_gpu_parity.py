@@ -49,6 +49,22 @@ def test_forward_matches_oracle(oracle, shipped, B, H, W):
     assert (out['desc'].cpu() - ref['desc']).abs().max().item() <= DESC_TOL
 
 
+@pytest.mark.parametrize('env', [{'MP_PERSIST_MIN_ITEMS': '1'}, {'MP_NO_PERSIST': '1'}, {'MP_NO_FUSE': '1'}])
+@pytest.mark.parametrize('B,H,W', [(6, 120, 160), (3, 200, 328)])
+def test_forward_kernel_variants(oracle, monkeypatch, env, B, H, W):
+    """Every convolution kernel variant against the oracle on the same inputs: the persistent one-workgroup-per-CU
+    kernel forced onto small launches (all tile shapes, partial tiles at the right/bottom edge), the per-tile kernel
+    only, and the unfused first block."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    net, sd = _net(oracle, oracle.SHIPPED_MODEL_CONFIG, seed=4)          # new handle: reads the environment
+    img = oracle.make_images(300 + W, B, H, W)
+    ref = oracle.forward(sd, img, oracle.SHIPPED_MODEL_CONFIG)
+    out = net({'image': img.cuda()})
+    assert (out['prob'].cpu() - ref['prob']).abs().max().item() <= PROB_TOL
+    assert (out['desc'].cpu() - ref['desc']).abs().max().item() <= DESC_TOL
+
+
 def test_forward_matches_reference_golden(oracle, shipped, golden_dir):
     """Directly against outputs of the imported reference (no oracle in between)."""
     net, _ = shipped
