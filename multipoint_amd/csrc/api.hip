@@ -30,6 +30,7 @@ struct ConvLayer {            // one MFMA conv launch
 };
 
 struct FirstLayer {
+    int channels = 64;            // output channels incl. zero padding (64 or 32)
     float *w = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
     float *w_h = nullptr, *bias_h = nullptr;      // mixed_precision: fp16-representable copies
 };
@@ -62,6 +63,7 @@ struct mp_handle {
     DevBuf nms_state;               // 64 round counters + tile flags
     int* nms_total = nullptr;       // device: undecided candidates summed over all calls since the last read
     int last_nms_rounds = 0;
+    int head_channels = 256;        // width of each 3x3 head convolution (MultiPoint.py:38-53)
     void* dummy = nullptr;          // scratch line for masked-off store lanes of the fp16 kernels
     int persist = 8;                // persistent conv workgroups for launches with >= this many items per CU
                                     // (MP_NO_PERSIST=1: never; MP_PERSIST_MIN_ITEMS=n overrides the threshold)
@@ -209,7 +211,8 @@ bool bn_terms(TensorMap& tm, const std::string& prefix, int c, int padded, std::
 //   [slice][chunk][step = tap*4 + kgroup][nblock(2)][lane(64)][4]
 //   element e of lane l = W[cout = slice*64 + nblock*32 + (l&31)][cin = chunk*32 + kgroup*8 + (l>>5)*4 + e][tap]
 // srcs: list of OIHW tensors concatenated along O (the two 3x3 head convs share one launch).
-void pack_conv_weights(const std::vector<const float*>& srcs, const std::vector<int>& couts, int cin,
+// cin_real < cin: the input tensor carries zero padding channels up to a multiple of 32 (channel_version 1 / 2).
+void pack_conv_weights(const std::vector<const float*>& srcs, const std::vector<int>& couts, int cin, int cin_real,
                        int taps, std::vector<float>& out)
 {
     int cout = 0;
@@ -227,10 +230,10 @@ void pack_conv_weights(const std::vector<const float*>& srcs, const std::vector<
                             for (int e = 0; e < 4; ++e, ++o) {
                                 int co = s * 64 + nb * 32 + (l & 31);
                                 const int ci = c * 32 + g * 8 + (l >> 5) * 4 + e;
-                                if (co >= cout) continue;
+                                if (co >= cout || ci >= cin_real) continue;
                                 size_t t = 0;
                                 while (co >= couts[t]) { co -= couts[t]; ++t; }
-                                out[o] = srcs[t][((size_t)co * cin + ci) * taps + tap];
+                                out[o] = srcs[t][((size_t)co * cin_real + ci) * taps + tap];
                             }
 }
 
@@ -262,10 +265,15 @@ void pack_conv_weights_h(const std::vector<const float*>& srcs, const std::vecto
                             }
 }
 
+// cin: channel count of the (zero-padded) input tensor, a multiple of 32; cin_real: channels of the reference conv.
+// L.cout is rounded up to a multiple of 32: the extra output channels have zero weights/bias and identity BN, so
+// the kernel writes zeros there -- exactly the padding the next layer expects.
 int build_conv(mp_handle* h, TensorMap& tm, ConvLayer& L, const char* name,
                const std::vector<std::string>& conv_keys, const std::vector<std::string>& bn_keys,
-               const std::vector<int>& couts, int cin, int taps, bool pool, bool relu)
+               const std::vector<int>& couts, int cin, int taps, bool pool, bool relu, int cin_real = 0,
+               bool pad_cout = false)
 {
+    if (cin_real <= 0) cin_real = cin;
     std::string err;
     int cout = 0;
     for (int c : couts) cout += c;
@@ -274,7 +282,7 @@ int build_conv(mp_handle* h, TensorMap& tm, ConvLayer& L, const char* name,
     std::vector<float> bias(padded, 0.f), scale(padded, 1.f), shift(padded, 0.f);
     int off = 0;
     for (size_t i = 0; i < conv_keys.size(); ++i) {
-        const float* w = tm.get(conv_keys[i] + ".weight", (long long)couts[i] * cin * taps, err);
+        const float* w = tm.get(conv_keys[i] + ".weight", (long long)couts[i] * cin_real * taps, err);
         if (!w) return fail(h, MP_EINVAL, err);
         const float* b = tm.get(conv_keys[i] + ".bias", couts[i], err);
         if (!b) return fail(h, MP_EINVAL, err);
@@ -288,8 +296,8 @@ int build_conv(mp_handle* h, TensorMap& tm, ConvLayer& L, const char* name,
         off += couts[i];
     }
     std::vector<float> packed;
-    pack_conv_weights(srcs, couts, cin, taps, packed);
-    L.name = name; L.cin = cin; L.cout = cout; L.taps = taps; L.nslices = padded / 64;
+    pack_conv_weights(srcs, couts, cin, cin_real, taps, packed);
+    L.name = name; L.cin = cin; L.cout = pad_cout ? ((cout + 31) / 32) * 32 : cout; L.taps = taps; L.nslices = padded / 64;
     L.pool = pool; L.relu = relu;
     int rc;
     if ((rc = upload(h, packed, &L.wpack))) return rc;
@@ -321,7 +329,11 @@ int build_encoder(mp_handle* h, TensorMap& tm, Encoder& E, const std::string& pr
     // SuperPointMagicLeap (SuperPointMagicLeap.py:16-23): named convolutions, no BatchNorm.
     static const int conv_idx[8] = {1, 5, 10, 14, 19, 23, 28, 32};
     static const char* ml_names[8] = {"conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b"};
-    static const int chan[9] = {1, 64, 64, 64, 64, 128, 128, 128, 128};
+    // MultiPoint.py:38-53: channel_version 0 [1,64,64,128,128], 1 [1,32,64,96,128], 2 [1,8,16,32,64]
+    static const int stage_ch[3][5] = {{1, 64, 64, 128, 128}, {1, 32, 64, 96, 128}, {1, 8, 16, 32, 64}};
+    const int* sc = stage_ch[h->cfg.channel_version];
+    const int chan[9] = {1, sc[1], sc[1], sc[2], sc[2], sc[3], sc[3], sc[4], sc[4]};
+    auto pad32 = [](int c) { return ((c + 31) / 32) * 32; };
     static const bool pool[8] = {false, true, false, true, false, true, false, false};
     const int bn_off = h->cfg.bn_first ? 1 : 2;
     auto conv_key = [&](int i) {
@@ -331,14 +343,18 @@ int build_encoder(mp_handle* h, TensorMap& tm, Encoder& E, const std::string& pr
         return h->cfg.batchnorm ? prefix + "." + std::to_string(conv_idx[i] + bn_off) : std::string();
     };
     std::string err;
-    {   // first layer (Cin = 1): [tap][cout]
+    {   // first layer (Cin = 1): [tap][cout], cout zero-padded to 32 / 64
         const std::string ck = conv_key(0), bk = bn_key(0);
-        const float* w = tm.get(ck + ".weight", 64 * 9, err); if (!w) return fail(h, MP_EINVAL, err);
-        const float* b = tm.get(ck + ".bias", 64, err); if (!b) return fail(h, MP_EINVAL, err);
-        std::vector<float> wt(9 * 64), bias(b, b + 64), s(64, 1.f), t(64, 0.f);
-        for (int co = 0; co < 64; ++co)
-            for (int k = 0; k < 9; ++k) wt[k * 64 + co] = w[co * 9 + k];
-        if (!bk.empty() && !bn_terms(tm, bk, 64, 64, s, t, err)) return fail(h, MP_EINVAL, err);
+        const int c1 = chan[1], c1p = pad32(c1);
+        const float* w = tm.get(ck + ".weight", c1 * 9, err); if (!w) return fail(h, MP_EINVAL, err);
+        const float* b = tm.get(ck + ".bias", c1, err); if (!b) return fail(h, MP_EINVAL, err);
+        std::vector<float> wt(9 * c1p, 0.f), bias(c1p, 0.f), s(c1p, 1.f), t(c1p, 0.f);
+        for (int co = 0; co < c1; ++co) {
+            bias[co] = b[co];
+            for (int k = 0; k < 9; ++k) wt[k * c1p + co] = w[co * 9 + k];
+        }
+        if (!bk.empty() && !bn_terms(tm, bk, c1, c1p, s, t, err)) return fail(h, MP_EINVAL, err);
+        E.first.channels = c1p;
         int rc;
         if ((rc = upload(h, wt, &E.first.w))) return rc;
         if ((rc = upload(h, bias, &E.first.bias))) return rc;
@@ -352,8 +368,8 @@ int build_encoder(mp_handle* h, TensorMap& tm, Encoder& E, const std::string& pr
         }
     }
     for (int i = 1; i < 8; ++i) {
-        int rc = build_conv(h, tm, E.conv[i - 1], kEncNames[i - 1], {conv_key(i)}, {bn_key(i)}, {chan[i + 1]}, chan[i], 9,
-                            pool[i], true);
+        int rc = build_conv(h, tm, E.conv[i - 1], kEncNames[i - 1], {conv_key(i)}, {bn_key(i)}, {chan[i + 1]}, pad32(chan[i]), 9,
+                            pool[i], true, chan[i], true);
         if (rc) return rc;
     }
     return MP_OK;
@@ -638,9 +654,13 @@ int mp_load_weights(mp_handle* h, const mp_model_config* cfg, const mp_tensor* t
 {
     if (!h) return MP_EINVAL;
     if (!cfg || (!tensors && n_tensors > 0)) return fail(h, MP_EINVAL, "mp_load_weights: NULL argument");
-    if (cfg->channel_version != 0)
-        return fail(h, MP_EINVAL, "unsupported model config: channel_version must be 0 "
-                                  "(channels [1,64,64,128,128]; MultiPoint.py:38-40)");
+    if (cfg->channel_version < 0 || cfg->channel_version > 2)
+        return fail(h, MP_EINVAL, "unsupported model config: channel_version must be 0, 1 or 2 (MultiPoint.py:38-53)");
+    if (cfg->channel_version != 0 && cfg->mixed_precision)
+        return fail(h, MP_EINVAL, "unsupported model config: the fp16 path (mixed_precision) needs channel_version 0 "
+                                  "(its K chunks are 64 channels wide)");
+    if (cfg->channel_version != 0 && cfg->key_layout == 1)
+        return fail(h, MP_EINVAL, "unsupported model config: SuperPointMagicLeap has channel_version 0 shapes");
     if (!cfg->double_convolution)
         return fail(h, MP_EINVAL, "unsupported model config: double_convolution must be true");
     if (cfg->descriptor_head && cfg->descriptor_size != 64 && cfg->descriptor_size != 128 &&
@@ -675,15 +695,20 @@ int mp_load_weights(mp_handle* h, const mp_model_config* cfg, const mp_tensor* t
     const std::string det3bn = cfg->batchnorm ? det + bn3 : std::string(), dsc3bn = cfg->batchnorm ? dsc + bn3 : std::string();
     const std::string det1bn = cfg->final_batchnorm ? det + ".5" : std::string();
     const std::string dsc1bn = cfg->final_batchnorm ? dsc + ".5" : std::string();
-    // both 3x3 head convs read the same encoder output: one launch with N = 256 (+256)
+    // both 3x3 head convs read the same encoder output: one launch with N = hc (+hc); hc = 256 for channel_version 0,
+    // descriptor_size otherwise (MultiPoint.py:38-53)
+    const int hc = cfg->channel_version == 0 ? 256 : cfg->descriptor_size;
+    const int enc_out = h->enc[0].conv[6].cout;                 // 128 (64 for channel_version 2)
+    const int enc_real = cfg->channel_version == 2 ? 64 : 128;
+    h->head_channels = hc;
     if (cfg->descriptor_head)
-        rc = build_conv(h, tm, h->heads3, "heads.conv3x3", {det3, dsc3}, {det3bn, dsc3bn}, {256, 256}, 128, 9, false, true);
+        rc = build_conv(h, tm, h->heads3, "heads.conv3x3", {det3, dsc3}, {det3bn, dsc3bn}, {hc, hc}, enc_out, 9, false, true, enc_real);
     else
-        rc = build_conv(h, tm, h->heads3, "heads.conv3x3", {det3}, {det3bn}, {256}, 128, 9, false, true);
+        rc = build_conv(h, tm, h->heads3, "heads.conv3x3", {det3}, {det3bn}, {hc}, enc_out, 9, false, true, enc_real);
     if (rc) return rc;
-    if ((rc = build_conv(h, tm, h->det1, "det.conv1x1", {det1k}, {det1bn}, {65}, 256, 1, false, false))) return rc;
+    if ((rc = build_conv(h, tm, h->det1, "det.conv1x1", {det1k}, {det1bn}, {65}, hc, 1, false, false))) return rc;
     if (cfg->descriptor_head &&
-        (rc = build_conv(h, tm, h->desc1, "desc.conv1x1", {dsc1k}, {dsc1bn}, {cfg->descriptor_size}, 256, 1, false, false)))
+        (rc = build_conv(h, tm, h->desc1, "desc.conv1x1", {dsc1k}, {dsc1bn}, {cfg->descriptor_size}, hc, 1, false, false)))
         return rc;
     // strict=True semantics of load_state_dict: no unexpected keys
     for (auto& kv : tm.m)
@@ -713,7 +738,8 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
     const int Hc = H / 8, Wc = W / 8;
     const long long npx = (long long)B * Hc * Wc;
     const int D = h->cfg.descriptor_size;
-    const int headc = h->cfg.descriptor_head ? 512 : 256;
+    const int hc = h->head_channels;
+    const int headc = h->cfg.descriptor_head ? 2 * hc : hc;
     // workspace: P (B*H*W*64) | Q (B*H*W*16) | X encoder output (npx*128) | logits (npx*80) | img lists
     const size_t nP = (size_t)B * H * W * 64, nQ = (size_t)B * H * W * 16;
     const size_t nL = (size_t)npx * 80, nD = (size_t)npx * 128;
@@ -752,7 +778,8 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
         c1.in = images; c1.out = P; c1.w = E.first.w; c1.bias = E.first.bias; c1.scale = E.first.scale;
         c1.shift = E.first.shift; c1.img_list = lptr[e]; c1.B = nb; c1.H = H; c1.W = W;
         c1.pad_zero = h->cfg.reflection_pad ? 0 : 1; c1.bn_first = h->cfg.bn_first;
-        const bool fuse1 = h->fuse_first;
+        c1.channels = E.first.channels;
+        const bool fuse1 = h->fuse_first && h->cfg.channel_version == 0;     // the fused loader is a 64-channel kernel
         if (!fuse1) {
             prof_begin(h, "enc.conv1", 2.0 * 9 * 64 * (double)nb * H * W, s);
             launch_conv_first(c1, s);
@@ -770,7 +797,7 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
         }
     }
     // heads
-    run_conv(h, h->heads3, X, 128, 0, P, headc, 0, B, Hc, Wc, nullptr, s);
+    run_conv(h, h->heads3, X, h->heads3.cin, 0, P, headc, 0, B, Hc, Wc, nullptr, s);
     run_conv(h, h->det1, P, headc, 0, Lg, 80, 0, B, Hc, Wc, nullptr, s);
     if (prob || logits) {
         prof_begin(h, "det.softmax_shuffle", 0.0, s);
@@ -778,7 +805,7 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
         prof_end(h, s);
     }
     if (desc) {
-        run_conv(h, h->desc1, P, headc, 256, desc, D, 0, B, Hc, Wc, nullptr, s);
+        run_conv(h, h->desc1, P, headc, hc, desc, D, 0, B, Hc, Wc, nullptr, s);
         prof_begin(h, "desc.l2norm", 0.0, s);
         if (h->cfg.normalize_descriptors) launch_desc_l2norm(desc, desc, npx, D, 1, s);
         prof_end(h, s);

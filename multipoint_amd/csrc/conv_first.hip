@@ -19,6 +19,8 @@ __device__ __forceinline__ int reflect_clamp1(int v, int n)
     return v >= n ? n - 1 : v;
 }
 
+// C1 = output channels (64, or 32 for channel_version 1 / 2): C1/4 lanes share a pixel
+template <int C1>
 __global__ __launch_bounds__(256) void conv_first_kernel(const Conv1Params p)
 {
     __shared__ float tile[LH * LW];
@@ -47,11 +49,12 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const Conv1Params p)
     }
 
     // this lane's 4 output channels
-    const int c4 = (tid & 15) * 4;
+    constexpr int LPP = C1 / 4;                   // lanes per pixel
+    const int c4 = (tid % LPP) * 4;
     float w[9][4], bia[4], scl[4], sft[4];
 #pragma unroll
     for (int k = 0; k < 9; ++k) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(p.w + k * 64 + c4);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p.w + k * C1 + c4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) w[k][e] = v[e];
     }
@@ -64,11 +67,12 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const Conv1Params p)
     }
     __syncthreads();
 
-    float* out = p.out + (long long)img * p.H * p.W * 64;
-    const int psub = tid >> 4;                    // 16 pixels per pass
+    float* out = p.out + (long long)img * p.H * p.W * C1;
+    constexpr int PPP = 256 / LPP;                // pixels per pass
+    const int psub = tid / LPP;
 #pragma unroll 4
-    for (int it = 0; it < (TH * TW) / 16; ++it) {
-        const int pix = it * 16 + psub;
+    for (int it = 0; it < (TH * TW) / PPP; ++it) {
+        const int pix = it * PPP + psub;
         const int py = pix / TW, px = pix % TW;
         float x[9];
 #pragma unroll
@@ -88,7 +92,7 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const Conv1Params p)
         }
         const int oy = y0 + py, ox = x0 + px;
         if (oy < p.H && ox < p.W)
-            *reinterpret_cast<f32x4*>(out + ((long long)oy * p.W + ox) * 64 + c4) = o;
+            *reinterpret_cast<f32x4*>(out + ((long long)oy * p.W + ox) * C1 + c4) = o;
     }
 }
 
@@ -99,5 +103,6 @@ void launch_conv_first(const Conv1Params& p, hipStream_t s)
     const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
     const long long nblk = (long long)p.B * tiles_x * tiles_y;
     if (nblk <= 0) return;
-    hipLaunchKernelGGL(conv_first_kernel, dim3((unsigned)nblk), dim3(256), 0, s, p);
+    if (p.channels == 32) hipLaunchKernelGGL(conv_first_kernel<32>, dim3((unsigned)nblk), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL(conv_first_kernel<64>, dim3((unsigned)nblk), dim3(256), 0, s, p);
 }

@@ -44,12 +44,13 @@ struct ConvParams {
 // first layer (Cin = 1, direct VALU conv, HBM-write bound)
 struct Conv1Params {
     const float* in;      // [B][H][W]
-    float* out;           // [B][H][W][64]
-    const float* w;       // [9][64]  (tap-major, cout contiguous)
-    const float* bias; const float* scale; const float* shift;   // [64]
+    float* out;           // [B][H][W][channels]
+    const float* w;       // [9][channels]  (tap-major, cout contiguous)
+    const float* bias; const float* scale; const float* shift;   // [channels]
     const int* img_list;
     int B, H, W;
     int pad_zero, bn_first;
+    int channels;         // output channels incl. zero padding: 64 (channel_version 0) or 32
 };
 
 void launch_conv_mfma(const ConvParams& p, int taps, int mbw, bool pool, bool fuse1, hipStream_t s);

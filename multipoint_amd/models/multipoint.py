@@ -35,9 +35,10 @@ class MultiPoint:
             self.config = dict_update(copy.deepcopy(self.default_config), config)
         else:
             self.config = copy.deepcopy(self.default_config)
-        if self.config['channel_version'] != 0:
-            raise ValueError('multipoint_amd supports channel_version 0 only '
-                             '(channels [1,64,64,128,128], MultiPoint.py:38-40)')
+        if self.config['channel_version'] not in (0, 1, 2):
+            raise ValueError('channel_version must be 0, 1 or 2 (MultiPoint.py:38-53)')
+        if self.config['channel_version'] != 0 and self.config['mixed_precision']:
+            raise ValueError('mixed_precision (fp16 MFMA path) needs channel_version 0')
         if not self.config['double_convolution']:
             raise ValueError('multipoint_amd supports double_convolution=True only')
         self.training = False
@@ -67,7 +68,10 @@ class MultiPoint:
                 spec.append(('%s.%s' % (p, leaf), (ch,), torch.float32))
             spec.append((p + '.num_batches_tracked', (), torch.int64))
 
-        chan = [1, 64, 64, 64, 64, 128, 128, 128, 128]
+        # MultiPoint.py:38-53
+        stage = {0: [1, 64, 64, 128, 128], 1: [1, 32, 64, 96, 128], 2: [1, 8, 16, 32, 64]}[c['channel_version']]
+        head_channels = 256 if c['channel_version'] == 0 else c['descriptor_size']
+        chan = [1, stage[1], stage[1], stage[2], stage[2], stage[3], stage[3], stage[4], stage[4]]
         conv_idx = [1, 5, 10, 14, 19, 23, 28, 32]
         bn_off = 1 if c['bn_first'] else 2
         names = ['encoder_thermal', 'encoder_optical'] if c['multispectral'] else ['encoder']
@@ -79,9 +83,9 @@ class MultiPoint:
         if c['descriptor_head']:
             heads.append(('descriptor_head_convolutions', c['descriptor_size']))
         for name, nout in heads:
-            conv(name + '.1', 256, 128, 3)
-            bn('%s.%d' % (name, 1 + bn_off), 256)
-            conv(name + '.4', nout, 256, 1)
+            conv(name + '.1', head_channels, stage[4], 3)
+            bn('%s.%d' % (name, 1 + bn_off), head_channels)
+            conv(name + '.4', nout, head_channels, 1)
             if c['final_batchnorm']:
                 bn(name + '.5', nout)
         return spec

@@ -65,6 +65,28 @@ def test_forward_kernel_variants(oracle, monkeypatch, env, B, H, W):
     assert (out['desc'].cpu() - ref['desc']).abs().max().item() <= DESC_TOL
 
 
+@pytest.mark.parametrize('upd', [{'channel_version': 1}, {'channel_version': 2}, {'channel_version': 1, 'descriptor_size': 128},
+                                 {'channel_version': 2, 'multispectral': True, 'reflection_pad': False}])
+def test_forward_channel_versions(oracle, upd):
+    """channel_version 1 ([1,32,64,96,128]) and 2 ([1,8,16,32,64]) with head width = descriptor_size (MultiPoint.py:38-53):
+    the same kernels on tensors zero-padded to multiples of 32 channels."""
+    cfg = dict(oracle.SHIPPED_MODEL_CONFIG); cfg.update(upd)
+    net, sd = _net(oracle, cfg, seed=9)
+    B, H, W = 3, 72, 104
+    img = oracle.make_images(17, B, H, W)
+    is_opt = torch.tensor([[True], [False], [True]])
+    ref = oracle.forward(sd, img, cfg, is_optical=is_opt)
+    out = net({'image': img.cuda(), 'is_optical': is_opt.cuda()})
+    assert out['desc'].shape == (B, cfg['descriptor_size'], H // 8, W // 8)
+    assert (out['prob'].cpu() - ref['prob']).abs().max().item() <= PROB_TOL
+    assert (out['desc'].cpu() - ref['desc']).abs().max().item() <= DESC_TOL
+    big = oracle.make_images(18, 8, 240, 320)                               # large enough for the persistent kernel
+    refb = oracle.forward(sd, big, cfg, is_optical=torch.ones(8, 1, dtype=torch.bool))
+    outb = net({'image': big.cuda(), 'is_optical': torch.ones(8, 1, dtype=torch.bool).cuda()})
+    assert (outb['prob'].cpu() - refb['prob']).abs().max().item() <= PROB_TOL
+    assert (outb['desc'].cpu() - refb['desc']).abs().max().item() <= DESC_TOL
+
+
 def test_forward_matches_reference_golden(oracle, shipped, golden_dir):
     """Directly against outputs of the imported reference (no oracle in between)."""
     net, _ = shipped

@@ -105,7 +105,7 @@ def test_load_state_dict_is_strict(oracle):
     pre = {'module__' + k: v for k, v in sd.items()}
     M.MultiPoint(cfg).load_state_dict(U.fix_model_weigth_keys(pre))
     with pytest.raises(ValueError):
-        M.MultiPoint({'channel_version': 1})
+        M.MultiPoint({'channel_version': 3})
     with pytest.raises(ValueError):
         net.set_force_return_logits(1)
     with pytest.raises(NotImplementedError):

@@ -243,3 +243,21 @@ def test_repeatability_against_reference_driver(oracle, ref, monkeypatch):
         c1, c2, nt, no = oracle.repeatability_pair(kps[0], kps[1], ho[p], ht[p], H, W, 3)
         mine.append((c1 + c2) / (nt + no))
     assert np.allclose(rep, mine, atol=1e-12) and 0.2 < mean < 1.0
+
+
+@pytest.mark.parametrize('upd', [{'channel_version': 1}, {'channel_version': 2, 'descriptor_size': 128}])
+def test_channel_versions_against_reference(oracle, ref, upd):
+    models, utils = ref
+    cfg = dict(oracle.SHIPPED_MODEL_CONFIG); cfg.update(upd)
+    net = models.MultiPoint(dict(cfg)).eval()
+    spec = oracle.state_dict_spec(cfg)
+    assert [k for k, _, _ in spec] == list(net.state_dict().keys())
+    sd = oracle.make_weights(51, cfg)
+    net.load_state_dict(sd)
+    img = oracle.make_images(52, 2, 64, 96)
+    with torch.no_grad():
+        r = net({'image': img})
+    o = oracle.forward(sd, img, cfg)
+    assert (r['prob'] - o['prob']).abs().max().item() <= 1e-7 and (r['desc'] - o['desc']).abs().max().item() <= 1e-7
+    from multipoint_amd.models import MultiPoint
+    assert [(k, tuple(s)) for k, s, _ in MultiPoint(dict(cfg)).state_dict_spec()] == [(k, tuple(s)) for k, s, _ in spec]
