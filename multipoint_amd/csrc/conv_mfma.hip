@@ -610,9 +610,10 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_persist_kernel(const ConvPar
     constexpr int A_MB = G::MBH * G::LW * PS;
     const int nchunks = p.cin / CK;
     // Weight prefetch distance.  Vector memory loads return IN ORDER, so the wait for a weight fragment also waits
-    // for every older load -- including the HBM staging loads of the next image issued in between.  With the
-    // per-tile kernel's 2-step distance (2 k cycles) each chunk stalls for the rest of the HBM latency; one
-    // workgroup per CU has the registers for a ring of 9 (8 steps = 8 k cycles ahead).
+    // for every older load -- including the HBM staging loads of the next image issued in between.  One workgroup
+    // per CU has the registers for a ring of 9 (8 steps = 8 k cycles ahead of use, more than the HBM latency);
+    // measured against the per-tile kernel's 2-step distance it made no difference here (the staging loads land
+    // in time), it is kept as slack.
     constexpr int RB = 9, PF = 8;
     static_assert(G::STEPS % RB == 0 && G::STEPS % 2 == 0, "operand rings must stay aligned across chunks");
     f32x4 af2[3][2], bf[RB][2], stg[G::NITER];
