@@ -1,3 +1,6 @@
+// NOTE: the conclusion this probe suggested (5-8 cycles per foreign VALU instruction next to an MFMA stream) was WRONG:
+// waves 0-3 and 4-7 of one 512-thread workgroup do not share SIMDs the way it assumes.  mfma_probe7.hip places the
+// streaming and the timed wave in different workgroups on the same CU and shows total starvation.  Kept for the record.
 // Developer microbenchmark 6: how fast does a wave advance through ordinary instructions while the
 // OTHER wave of its SIMD streams fp32 MFMAs back to back?  (explains the 25-60k-cycle prologues /
 // epilogues measured with tools/conv_timing.py)   512 threads: waves 0-3 stream, waves 4-7 are timed.
