@@ -23,6 +23,7 @@ struct DevBuf {
 struct ConvLayer {            // one MFMA conv launch
     const char* name = "";
     float *wpack = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
+    float* upack = nullptr;       // 3x3 layers: Winograd-domain weights U = G g G^T (conv_wino.hip)
     _Float16* wpack_h = nullptr;  // mixed_precision: fp16 fragments (conv_f16.hip) and the fp16-rounded bias
     float* bias_h = nullptr;
     int cin = 0, cout = 0, taps = 9, nslices = 0;
@@ -65,6 +66,7 @@ struct mp_handle {
     int last_nms_rounds = 0;
     int head_channels = 256;        // width of each 3x3 head convolution (MultiPoint.py:38-53)
     void* dummy = nullptr;          // scratch line for masked-off store lanes of the fp16 kernels
+    bool wino = true;               // Winograd F(2x2,3x3) for the non-fused 3x3 layers (MP_NO_WINOGRAD=1 disables)
     int persist = 8;                // persistent conv workgroups for launches with >= this many items per CU
                                     // (MP_NO_PERSIST=1: never; MP_PERSIST_MIN_ITEMS=n overrides the threshold)
     bool fuse_first = true;         // fuse the Cin=1 block into the second convolution (MP_NO_FUSE=1 disables)
@@ -237,6 +239,38 @@ void pack_conv_weights(const std::vector<const float*>& srcs, const std::vector<
                             }
 }
 
+// Winograd F(2x2,3x3) weights for conv_wino_kernel: U[pos = 4a+b] = sum_ij G[a][i] g[i][j] G[b][j], fp32 on the host in
+// this fixed order (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]: the 0.5 factors are exact).  Layout
+//   [slice64][half(2)][chunk8 = cin/8][pos(16)][lane(64)][4]
+//   element e of lane l = U[pos][cout = slice*64 + half*32 + (l&31)][cin = chunk*8 + (l>>5)*4 + e]
+void pack_wino_weights(const std::vector<const float*>& srcs, const std::vector<int>& couts, int cin, int cin_real,
+                       std::vector<float>& out)
+{
+    static const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
+    int cout = 0;
+    for (int c : couts) cout += c;
+    const int nslices = (cout + 63) / 64, nchunks = cin / 8;
+    out.assign((size_t)nslices * 2 * nchunks * 16 * 64 * 4, 0.f);
+    size_t o = 0;
+    for (int s = 0; s < nslices; ++s)
+        for (int hf = 0; hf < 2; ++hf)
+            for (int c = 0; c < nchunks; ++c)
+                for (int pos = 0; pos < 16; ++pos)
+                    for (int l = 0; l < 64; ++l)
+                        for (int e = 0; e < 4; ++e, ++o) {
+                            int co = s * 64 + hf * 32 + (l & 31);
+                            const int ci = c * 8 + (l >> 5) * 4 + e;
+                            if (co >= cout || ci >= cin_real) continue;
+                            size_t t = 0;
+                            while (co >= couts[t]) { co -= couts[t]; ++t; }
+                            const float* g = srcs[t] + ((size_t)co * cin_real + ci) * 9;
+                            const int a = pos >> 2, b = pos & 3;
+                            float tmp[3];                      // (G g)[a][j]
+                            for (int j = 0; j < 3; ++j) tmp[j] = (G[a][0] * g[j] + G[a][1] * g[3 + j]) + G[a][2] * g[6 + j];
+                            out[o] = (tmp[0] * G[b][0] + tmp[1] * G[b][1]) + tmp[2] * G[b][2];
+                        }
+}
+
 // fp16 flavour for conv_f16_kernel: chunks of 64 input channels, steps of 16:
 //   [slice][chunk][step = tap*4 + kgroup][nblock(2)][lane(64)][8]
 //   element e of lane l = half(W[cout = slice*64 + nblock*32 + (l&31)][cin = chunk*64 + kgroup*16 + (l>>5)*8 + e][tap])
@@ -304,6 +338,11 @@ int build_conv(mp_handle* h, TensorMap& tm, ConvLayer& L, const char* name,
     if ((rc = upload(h, bias, &L.bias))) return rc;
     if ((rc = upload(h, scale, &L.scale))) return rc;
     if ((rc = upload(h, shift, &L.shift))) return rc;
+    if (taps == 9 && h->wino) {
+        std::vector<float> up;
+        pack_wino_weights(srcs, couts, cin, cin_real, up);
+        if ((rc = upload(h, up, &L.upack))) return rc;
+    }
     if (h->cfg.mixed_precision) {
         std::vector<uint16_t> ph;
         pack_conv_weights_h(srcs, couts, cin, taps, ph);
@@ -433,7 +472,12 @@ void run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride,
     prof_begin(h, fuse ? "enc.conv1+2" : L.name,
                2.0 * L.taps * L.cin * L.cout * (double)B * H * W + (fuse ? 2.0 * 9 * 64 * (double)B * H * W : 0.0), s);
     if (fuse) { p.img = images; p.w1 = fuse->w; p.b1 = fuse->bias; p.s1 = fuse->scale; p.t1 = fuse->shift; }
-    launch_conv_mfma(p, L.taps, mbw, L.pool, fuse != nullptr, s);
+    if (L.taps == 9 && !fuse && L.upack && h->wino) {
+        p.wpack = L.upack;
+        launch_conv_wino(p, L.pool, s);
+    } else {
+        launch_conv_mfma(p, L.taps, mbw, L.pool, fuse != nullptr, s);
+    }
     prof_end(h, s);
 }
 
@@ -623,6 +667,7 @@ int mp_create(mp_handle** out, int device)
     mp_handle* hh = new mp_handle();
     hh->device = device;
     { const char* e = getenv("MP_NO_FUSE"); hh->fuse_first = !(e && e[0] == '1'); }
+    { const char* e = getenv("MP_NO_WINOGRAD"); hh->wino = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_PERSIST_MIN_ITEMS"); if (e && atoi(e) > 0) hh->persist = atoi(e); }
     { const char* e = getenv("MP_NO_PERSIST"); if (e && e[0] == '1') hh->persist = 0; }
     if (hipHostMalloc(reinterpret_cast<void**>(&hh->pinned), 4096) != hipSuccess) {
@@ -779,7 +824,9 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
         c1.shift = E.first.shift; c1.img_list = lptr[e]; c1.B = nb; c1.H = H; c1.W = W;
         c1.pad_zero = h->cfg.reflection_pad ? 0 : 1; c1.bn_first = h->cfg.bn_first;
         c1.channels = E.first.channels;
-        const bool fuse1 = h->fuse_first && h->cfg.channel_version == 0;     // the fused loader is a 64-channel kernel
+        // the fused loader is a 64-channel direct-convolution kernel; with Winograd on, the standalone first block +
+        // Winograd second convolution is faster than the fused direct kernel
+        const bool fuse1 = h->fuse_first && h->cfg.channel_version == 0 && !h->wino;
         if (!fuse1) {
             prof_begin(h, "enc.conv1", 2.0 * 9 * 64 * (double)nb * H * W, s);
             launch_conv_first(c1, s);

@@ -1,0 +1,351 @@
+// 3x3 convolution by Winograd F(2x2, 3x3) on the fp32 matrix instruction: 16 element-wise GEMMs
+//   M[pos] (tiles x cout) += V[pos] (tiles x cin) * U[pos] (cin x cout),  pos = 0..15
+// instead of one GEMM with K = 9*cin -- 2.25x fewer MFMAs for the same convolution (reference: the Conv2d of
+// multipoint/models/MultiPoint.py:143-148; same ReflectionPad/ZeroPad -> conv -> ReLU -> BN [-> MaxPool] fusion as
+// conv_mfma.hip).  fp32 throughout: V = B^T d B and Y = A^T M A are exact-order additions, U = G g G^T is computed
+// once on the host; the result differs from the direct fp32 convolution only by summation order (measured <= the
+// direct kernel's own distance to an fp64 convolution; parity tolerances unchanged).
+//
+// Persistent workgroups, ONE per CU (256 threads = 4 waves).  Item = 16x16 output pixels (8x8 Winograd tiles) x 64
+// output channels; wave w multiplies tile group w>>1 (32 tiles) by channel half w&1 (32 couts) for ALL 16
+// positions: 16 accumulator tiles = 256 registers, so the output transform is in-register and, for pooled layers,
+// the 2x2 max-pool is exactly one Winograd tile.
+// K is walked in units of 8 input channels, software-pipelined three deep through double-buffered LDS:
+//   while unit n is multiplied,  unit n+1 is transformed (raw patch -> V, 32 packed adds per thread),
+//   the raw 18x18x8 patch of unit n+2 goes VGPR -> LDS, and the patch of unit n+3 is fetched global -> VGPR.
+#include "mp_common.h"
+
+#include <algorithm>
+#include <type_traits>
+
+namespace {
+
+constexpr int WT = 16;                       // output tile edge
+constexpr int PW = WT + 2;                   // raw patch edge (18)
+constexpr int NPX = PW * PW;                 // 324 patch pixels
+constexpr int UC = 8;                        // input channels per unit
+constexpr int TS = 12;                       // V tile stride in floats (8 channels + 4 pad: conflict-free b128 reads)
+constexpr int VPOS = 64 * TS;                // floats per position
+constexpr int VBUF = 16 * VPOS;              // floats per V buffer (49152 B)
+constexpr int RAWBUF = NPX * UC;             // floats per raw buffer (10368 B)
+constexpr int NRAW = (NPX * 2 + 255) / 256;  // raw 16-byte vectors per thread (3)
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ int reflect_clamp_w(int v, int n)
+{
+    v = v < 0 ? -v : v;
+    v = v >= n ? 2 * (n - 1) - v : v;
+    v = v < 0 ? 0 : v;
+    return v >= n ? n - 1 : v;
+}
+__device__ __forceinline__ float relu_w(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
+
+template <bool POOL, bool BNF>
+__global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
+{
+    __shared__ __attribute__((aligned(16))) float Vs[2 * VBUF];
+    __shared__ __attribute__((aligned(16))) float raw[2 * RAWBUF];
+    __shared__ __attribute__((aligned(16))) float prm[3 * 64];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tg = wave >> 1, chh = wave & 1;            // tile group, channel half of this wave's GEMMs
+    const int NC = p.cin / UC;                           // units per item
+
+    // ---- work items: (tile, slice) of this XCD's contiguous eighth ----
+    const int per_xcd = (p.nitems + 7) >> 3;
+    const int stride = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7;
+    const int item_end = min((xcd + 1) * per_xcd, p.nitems);
+    int item = xcd * per_xcd + (blockIdx.x >> 3);
+    if (item >= item_end) return;
+
+    auto udiv = [](unsigned n, unsigned magic, unsigned d) -> unsigned { return d == 1 ? n : __umulhi(n, magic); };
+    struct Where { int slice, img, y0, x0; const float* in_base; };
+    auto decode = [&](int it) __attribute__((always_inline)) -> Where {
+        Where w{};
+        const int tile = (int)udiv((unsigned)it, p.magic_slices, (unsigned)p.nslices);
+        w.slice = it - tile * p.nslices;
+        const int trow = (int)udiv((unsigned)tile, p.magic_tx, (unsigned)p.tiles_x);
+        const int tx = tile - trow * p.tiles_x;
+        const int bi = (int)udiv((unsigned)trow, p.magic_ty, (unsigned)p.tiles_y);
+        const int ty = trow - bi * p.tiles_y;
+        w.img = p.img_list ? p.img_list[bi] : bi;
+        w.y0 = ty * WT; w.x0 = tx * WT;
+        w.in_base = p.in + (long long)w.img * p.H * p.W * p.in_cstride + p.in_coff;
+        return w;
+    };
+
+    // ---- raw patch staging: vector f = tid + 256*j covers patch pixel f>>1, channel quad f&1; its LDS slot is f*4 ----
+    int roff[NRAW];
+    bool roff_rel = false;        // roff holds the item-invariant offsets of interior items
+    auto raw_offsets = [&](const Where& w) __attribute__((always_inline)) -> const float* {
+        const bool interior = (w.y0 >= 1) && (w.y0 + WT < p.H) && (w.x0 >= 1) && (w.x0 + WT < p.W);
+        if (interior) {
+            if (!roff_rel) {
+#pragma unroll
+                for (int j = 0; j < NRAW; ++j) {
+                    const int f = tid + j * 256, q = f >> 1;
+                    const int py = q / PW, px = q - py * PW;
+                    roff[j] = (f < NPX * 2) ? (py * p.W + px) * p.in_cstride + (f & 1) * 4 : 0;
+                }
+                roff_rel = true;
+            }
+            return w.in_base + (long long)((w.y0 - 1) * p.W + (w.x0 - 1)) * p.in_cstride;
+        }
+        roff_rel = false;
+#pragma unroll
+        for (int j = 0; j < NRAW; ++j) {
+            const int f = tid + j * 256, q = f >> 1;
+            const int py = q / PW, px = q - py * PW;
+            int off = -1;
+            if (f < NPX * 2) {
+                int gy = w.y0 + py - 1, gx = w.x0 + px - 1;
+                bool zero = false;
+                if (p.pad_zero) {
+                    zero = (gy < 0) | (gy >= p.H) | (gx < 0) | (gx >= p.W);
+                    gy = min(max(gy, 0), p.H - 1); gx = min(max(gx, 0), p.W - 1);
+                } else {
+                    gy = reflect_clamp_w(gy, p.H); gx = reflect_clamp_w(gx, p.W);
+                }
+                if (!zero) off = (gy * p.W + gx) * p.in_cstride + (f & 1) * 4;
+            }
+            roff[j] = off;
+        }
+        return w.in_base;
+    };
+    f32x4 rreg[NRAW];
+    auto raw_load = [&](const float* base, int chunk) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NRAW; ++j)
+            rreg[j] = *reinterpret_cast<const f32x4*>(base + chunk * UC + (roff[j] >= 0 ? roff[j] : 0));
+    };
+    unsigned rzero = 0;           // bit j: vector j of rreg is a zero-padding slot (set when the loads are issued)
+    auto raw_mark = [&]() __attribute__((always_inline)) {
+        rzero = 0;
+#pragma unroll
+        for (int j = 0; j < NRAW; ++j) rzero |= (roff[j] < 0 ? 1u : 0u) << j;
+    };
+    auto raw_put = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NRAW; ++j) {
+            const int f = tid + j * 256;
+            if (f < NPX * 2) {
+                f32x4 v = rreg[j];
+                if ((rzero >> j) & 1u) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(&raw[buf * RAWBUF + f * 4]) = v;
+            }
+        }
+    };
+
+    // ---- input transform V = B^T d B of one unit: thread = (tile t, channel pair cg) ----
+    const int t_tile = tid >> 2, t_cg = tid & 3;
+    const int tr_base = (((t_tile >> 3) * 2) * PW + (t_tile & 7) * 2) * UC + t_cg * 2;     // top-left of the 4x4 window
+    const int tw_base = t_tile * TS + t_cg * 2;
+    f32x2 dd[16];
+    auto tf_read = [&](int buf, int k) __attribute__((always_inline)) {      // window elements 2k, 2k+1
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = 2 * k + u, i = e >> 2, j = e & 3;
+            dd[e] = *reinterpret_cast<const f32x2*>(&raw[buf * RAWBUF + tr_base + (i * PW + j) * UC]);
+        }
+    };
+    auto tf_rows = [&]() __attribute__((always_inline)) {                    // dd <- B^T dd (over the row index)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x2 d0 = dd[j], d1 = dd[4 + j], d2 = dd[8 + j], d3 = dd[12 + j];
+            dd[j] = d0 - d2; dd[4 + j] = d1 + d2; dd[8 + j] = d2 - d1; dd[12 + j] = d1 - d3;
+        }
+    };
+    auto tf_cols = [&]() __attribute__((always_inline)) {                    // dd <- dd B (over the column index)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x2 d0 = dd[4 * i], d1 = dd[4 * i + 1], d2 = dd[4 * i + 2], d3 = dd[4 * i + 3];
+            dd[4 * i] = d0 - d2; dd[4 * i + 1] = d1 + d2; dd[4 * i + 2] = d2 - d1; dd[4 * i + 3] = d1 - d3;
+        }
+    };
+    auto tf_write = [&](int buf, int e) __attribute__((always_inline)) {     // position e = 4*i + j
+        *reinterpret_cast<f32x2*>(&Vs[buf * VBUF + e * VPOS + tw_base]) = dd[e];
+    };
+
+    // ---- GEMM operands ----
+    const int a_base = (tg * 32 + (lane & 31)) * TS + (lane >> 5) * 4;
+    constexpr int RBW = 8, PFW = 7;                     // U ring / prefetch distance in positions
+    f32x4 bfr[RBW], afr[3];
+    auto u_ptr = [&](int slice) __attribute__((always_inline)) -> const f32x4* {
+        return reinterpret_cast<const f32x4*>(p.wpack) + ((long long)(slice * 2 + chh) * NC) * (16 * 64) + lane;
+    };
+    auto load_prm = [&](int slice) __attribute__((always_inline)) {
+        if (tid < 64) {
+            prm[tid] = p.bias[slice * 64 + tid]; prm[64 + tid] = p.scale[slice * 64 + tid]; prm[128 + tid] = p.shift[slice * 64 + tid];
+        }
+    };
+
+    // ---- prologue: V(0) transformed, raw(1) in LDS, raw(2) in flight ----
+    Where cur = decode(item);
+    const float* rbase = raw_offsets(cur);               // base pointer the staging loads currently use
+    Where ld_item = cur;                                  // item the staging loads currently target
+    int ld_chunk = 0;                                     // next chunk to load for ld_item
+    bool ld_has_item = true;
+    int ld_next_item = item + stride;
+    auto ld_advance = [&]() __attribute__((always_inline)) {
+        // move the load cursor one unit on (into the next item after the last chunk)
+        if (++ld_chunk == NC) {
+            ld_chunk = 0;
+            if (ld_next_item < item_end) {
+                ld_item = decode(ld_next_item);
+                rbase = raw_offsets(ld_item);
+                ld_next_item += stride;
+            } else {
+                ld_has_item = false;                      // past the end: dummy re-reads of the last item
+            }
+        }
+    };
+    raw_mark(); raw_load(rbase, ld_chunk); ld_advance();          // raw(0)
+    raw_put(0);
+    raw_mark(); raw_load(rbase, ld_chunk); ld_advance();          // raw(1)
+    load_prm(cur.slice);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 8; ++k) tf_read(0, k);
+    tf_rows(); tf_cols();
+#pragma unroll
+    for (int e = 0; e < 16; ++e) tf_write(0, e);
+    raw_put(1);
+    raw_mark(); raw_load(rbase, ld_chunk); ld_advance();          // raw(2): written during unit 0
+    const f32x4* up = u_ptr(cur.slice);
+#pragma unroll
+    for (int s = 0; s < PFW; ++s) bfr[s] = up[s * 64];
+    __syncthreads();
+
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int n = 0;                                            // unit counter (parity selects the LDS buffers)
+    for (;;) {
+        f32x16 acc[16];
+        const int item_next = item + stride;
+        const bool has_next = item_next < item_end;
+        const int next_slice = has_next ? (int)(item_next - (int)udiv((unsigned)item_next, p.magic_slices, (unsigned)p.nslices) * p.nslices)
+                                        : cur.slice;
+        const f32x4* unext = u_ptr(next_slice);
+
+        auto unit_body = [&](const int c, auto first_tag) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_tag)::value;
+            const bool last = c + 1 == NC;
+            const int vb = n & 1;                                     // V buffer of this unit; raw(n+1) is in raw[vb ^ 1]
+            const float* const vr = Vs + vb * VBUF;
+            const f32x4* const uc = up + (long long)c * (16 * 64);
+            const f32x4* const ut = last ? unext : uc + 16 * 64;      // where the U prefetch continues
+            afr[0] = *reinterpret_cast<const f32x4*>(&vr[a_base]);
+            afr[1] = *reinterpret_cast<const f32x4*>(&vr[a_base + VPOS]);
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[s % 3][e], bfr[s % RBW][e], (FIRST && e == 0) ? zero16 : acc[s], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (e == 0) {
+                        bfr[(s + PFW) % RBW] = (s + PFW < 16) ? uc[(s + PFW) * 64] : ut[(s + PFW - 16) * 64];
+                    } else if (e == 1) {
+                        if (s + 2 < 16) afr[(s + 2) % 3] = *reinterpret_cast<const f32x4*>(&vr[a_base + (s + 2) * VPOS]);
+                    } else if (e == 2) {
+                        // input transform of unit n+1: raw[vb^1] -> V[vb^1]
+                        if (s < 8) tf_read(vb ^ 1, s);
+                        else if (s == 8) tf_rows();
+                        else if (s == 9) tf_cols();
+                        else if (s < 15) { tf_write(vb ^ 1, 3 * (s - 10)); tf_write(vb ^ 1, 3 * (s - 10) + 1); tf_write(vb ^ 1, 3 * (s - 10) + 2); }
+                        else tf_write(vb ^ 1, 15);
+                    } else {
+                        // raw(n+2): VGPR -> raw[vb] (its previous content was transformed during unit n-1), then the
+                        // loads of raw(n+3) reuse the registers
+                        if (s == 1) raw_put(vb);
+                        else if (s == 3) { raw_mark(); raw_load(rbase, ld_chunk); ld_advance(); }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            ++n;
+            __syncthreads();                                          // V(n+1) and raw(n+2) complete, V(n) consumed
+        };
+        unit_body(0, std::true_type{});
+        for (int c = 1; c < NC; ++c) unit_body(c, std::false_type{});
+
+        // ---- output transform Y = A^T M A (in registers), bias / ReLU / BN, [2x2 max-pool], store ----
+        // lane = output channel, register r = tile (r&3) + 8*(r>>2) + 4*(lane>>5) of the wave's tile group
+        {
+            const int cl = chh * 32 + (lane & 31);
+            const float bia = prm[cl], scl = prm[64 + cl], sft = prm[128 + cl];
+            const int ch = cur.slice * 64 + cl;
+            auto act = [&](float v) __attribute__((always_inline)) -> float {
+                v += bia;
+                if (BNF) return relu_w(v * scl + sft);
+                return relu_w(v) * scl + sft;
+            };
+            const int cs = p.out_cstride;
+            const int Ho = POOL ? p.H >> 1 : p.H, Wo = POOL ? p.W >> 1 : p.W;
+            float* const obase = p.out + ((long long)cur.img * Ho * Wo) * cs + p.out_coff + ch;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float m[16];
+#pragma unroll
+                for (int s = 0; s < 16; ++s) m[s] = acc[s][r];
+                // rows: t[a][j] = sum_i A^T[a][i] m[i][j];  A^T = [[1,1,1,0],[0,1,-1,-1]]
+                float t0[4], t1[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { t0[j] = (m[j] + m[4 + j]) + m[8 + j]; t1[j] = (m[4 + j] - m[8 + j]) - m[12 + j]; }
+                const float y00 = (t0[0] + t0[1]) + t0[2], y01 = (t0[1] - t0[2]) - t0[3];
+                const float y10 = (t1[0] + t1[1]) + t1[2], y11 = (t1[1] - t1[2]) - t1[3];
+                const int tl = tg * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int ty = tl >> 3, tx = tl & 7;
+                if constexpr (POOL) {
+                    const float v = fmaxf(fmaxf(act(y00), act(y01)), fmaxf(act(y10), act(y11)));
+                    const int oy = (cur.y0 >> 1) + ty, ox = (cur.x0 >> 1) + tx;
+                    if (oy < Ho && ox < Wo && ch < p.cout) obase[((long long)oy * Wo + ox) * cs] = v;
+                } else {
+                    const int oy = cur.y0 + 2 * ty, ox = cur.x0 + 2 * tx;
+                    if (ch < p.cout) {
+                        if (oy < Ho && ox < Wo) obase[((long long)oy * Wo + ox) * cs] = act(y00);
+                        if (oy < Ho && ox + 1 < Wo) obase[((long long)oy * Wo + ox + 1) * cs] = act(y01);
+                        if (oy + 1 < Ho && ox < Wo) obase[((long long)(oy + 1) * Wo + ox) * cs] = act(y10);
+                        if (oy + 1 < Ho && ox + 1 < Wo) obase[((long long)(oy + 1) * Wo + ox + 1) * cs] = act(y11);
+                    }
+                }
+            }
+        }
+        if (!has_next) return;
+        if (next_slice != cur.slice) {
+            __syncthreads();
+            load_prm(next_slice);
+        }
+        item = item_next;
+        cur = decode(item);
+        up = unext;
+    }
+}
+
+template <bool POOL>
+void launch_w(const ConvParams& p, hipStream_t s)
+{
+    ConvParams q = p;
+    q.tiles_x = (p.W + WT - 1) / WT; q.tiles_y = (p.H + WT - 1) / WT;
+    const long long nitems = (long long)p.B * q.tiles_x * q.tiles_y * p.nslices;
+    if (nitems <= 0) return;
+    auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ull / (unsigned)d) + 1ull); };
+    q.magic_slices = magic(p.nslices); q.magic_tx = magic(q.tiles_x); q.magic_ty = magic(q.tiles_y);
+    const long long dmax = std::max(std::max(p.nslices, q.tiles_x), q.tiles_y);
+    if (nitems * dmax >= 0x100000000ll) return;
+    q.nitems = (int)nitems;
+    const unsigned grid = (unsigned)std::min<long long>(256, ((nitems + 7) / 8) * 8);
+    const ConvParams& pp = q;
+    if (p.bn_first) hipLaunchKernelGGL((conv_wino_kernel<POOL, true>), dim3(grid), dim3(256), 0, s, pp);
+    else hipLaunchKernelGGL((conv_wino_kernel<POOL, false>), dim3(grid), dim3(256), 0, s, pp);
+}
+
+}  // namespace
+
+// p.wpack must point at the Winograd-domain weights packed by pack_wino_weights() (api.hip)
+void launch_conv_wino(const ConvParams& p, bool pool, hipStream_t s)
+{
+    if (pool) launch_w<true>(p, s); else launch_w<false>(p, s);
+}
