@@ -185,14 +185,17 @@ def main():
             dist.destroy_process_group()
         return
 
-    # roofline of the dominant kernel: conv_mfma_kernel<9,32,true,true,false> = encoder conv1 (1->64, computed on the
-    # VALU inside the tile loader) fused into conv2 (64->64 @480x640, MFMA) + bias/ReLU/BN + 2x2 max-pool: one
-    # launch per step, 44 % of all FLOPs and of the time.  Timed with hipEvents on the launch stream inside
-    # the timed region; algorithmic FLOPs = conv1 + conv2 = 2*9*(1*64 + 64*64)*H*W per image.
+    # roofline of the dominant kernel.  fp32 path: conv_wino_kernel<true,false> = encoder conv2 (64->64 @480x640) by
+    # Winograd F(2x2,3x3) + bias/ReLU/BN + 2x2 max-pool, one launch per step (~38 % of the time).  `achieved` is the
+    # ALGORITHMIC (direct-convolution) FLOP count 2*9*Cin*Cout*H*W per image / launch time, as the contract asks; the
+    # kernel executes 2.25x fewer MFMA FLOPs than that, so `frac` can exceed 1 -- `mfma_executed_frac` is the share of
+    # the fp32 MFMA peak the instructions actually issued amount to.  Timed with hipEvents on the launch stream
+    # inside the timed region.
     by_name = {}
     for name, ms, flop in prof:
         by_name.setdefault(name, []).append((ms, flop))
     roof = None
+    wino = os.environ.get('MP_NO_WINOGRAD') != '1' and not c5
     dom = by_name.get('enc.conv1+2') or by_name.get('enc.conv2')
     if dom:
         ms = float(np.mean([m for m, _ in dom])); flop = dom[0][1]
@@ -203,14 +206,25 @@ def main():
                     'kernel': 'conv_f16_kernel<9,32,true,false> (enc.conv2 64->64 @1024x1280 on v_mfma_f32_32x32x16_f16 '
                               '+ bias/ReLU/BN + 2x2 max-pool)',
                     'launches_per_step': 1, 'ms_per_launch': round(ms, 4), 'flop_per_launch': flop}
+        elif 'enc.conv1+2' in by_name or not wino:
+            roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(),
+                    'kernel': 'conv_mfma_kernel<9,32,true,true,false> (encoder conv1 fused into conv2 64->64 @480x640, direct '
+                              'convolution + bias/ReLU/BN + 2x2 max-pool)' if 'enc.conv1+2' in by_name
+                              else 'conv_mfma_persist_kernel<9,32,true,false> (enc.conv2, direct convolution)',
+                    'launches_per_step': 1, 'ms_per_launch': round(ms, 4), 'flop_per_launch': flop}
         else:
-          roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(),
-                'kernel': 'conv_mfma_kernel<9,32,true,true,false> (encoder conv1 fused into conv2 64->64 @480x640 + '
-                          'bias/ReLU/BN + 2x2 max-pool)' if 'enc.conv1+2' in by_name else 'conv_mfma_kernel<9,32,true,false,false> (enc.conv2)',
-                'launches_per_step': 1, 'ms_per_launch': round(ms, 4), 'flop_per_launch': flop,
-                'note': 'timed while the previous batch\'s NMS/top-k/sampling/matching kernels run concurrently on the '
-                        'pipeline\'s side stream; the same launch alone takes 10.9 ms (0.86 of peak, tools/bench_layers.py)'}
+            roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(),
+                    'kernel': 'conv_wino_kernel<true,false> (enc.conv2 64->64 @480x640 by Winograd F(2x2,3x3) on '
+                              'v_mfma_f32_32x32x2_f32 + bias/ReLU/BN + 2x2 max-pool)',
+                    'launches_per_step': 1, 'ms_per_launch': round(ms, 4), 'flop_per_launch': flop,
+                    'mfma_flop_executed_per_launch': flop / 2.25,
+                    'mfma_executed_frac': round(ach / 2.25 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    'note': 'achieved/frac use the ALGORITHMIC direct-convolution FLOPs (contract); Winograd F(2x2,3x3) issues '
+                            '2.25x fewer MFMA FLOPs for the same fp32 result (within the unchanged parity tolerances), so '
+                            'frac > 1 is expected; mfma_executed_frac is the matrix-pipe utilisation.  Timed while the '
+                            'previous batch\'s NMS/top-k/sampling/matching kernels run on the side stream.'}
     conv_ms = sum(float(np.mean([m for m, _ in v])) for k, v in by_name.items())
     conv_flop = sum(v[0][1] for v in by_name.values())
     layers = {k: round(float(np.mean([m for m, _ in v])), 4) for k, v in by_name.items()}

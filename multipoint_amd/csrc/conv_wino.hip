@@ -18,6 +18,22 @@
 #include <algorithm>
 #include <type_traits>
 
+#ifdef MP_TIMING
+// developer instrumentation (tools/conv_timing_wino.py): per-workgroup cycle sums per phase, wave 0
+__device__ unsigned long long g_timing_w[256 * 8];
+__device__ int g_timing_w_sel = 240;
+extern "C" int mp_debug_select_height_wino(int h) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_timing_w_sel), &h, sizeof(int)); }
+extern "C" int mp_debug_read_timing_wino(unsigned long long* host, int n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_timing_w), sizeof(unsigned long long) * n);
+}
+#define MPW_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define MPW_ADD(slot, a, b) do { tsum[slot] += (b) - (a); } while (0)
+#else
+#define MPW_T(var) do { } while (0)
+#define MPW_ADD(slot, a, b) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int WT = 16;                       // output tile edge
@@ -27,7 +43,9 @@ constexpr int UC = 8;                        // input channels per unit
 constexpr int TS = 12;                       // V tile stride in floats (8 channels + 4 pad: conflict-free b128 reads)
 constexpr int VPOS = 64 * TS;                // floats per position
 constexpr int VBUF = 16 * VPOS;              // floats per V buffer (49152 B)
-constexpr int RAWBUF = NPX * UC;             // floats per raw buffer (10368 B)
+constexpr int RS = 12;                       // raw patch pixel stride in floats (8 channels + 4 pad: the 8-byte window
+                                             // reads of 8 neighbouring tiles then hit 64 distinct banks)
+constexpr int RAWBUF = NPX * RS;             // floats per raw buffer (15552 B)
 constexpr int NRAW = (NPX * 2 + 255) / 256;  // raw 16-byte vectors per thread (3)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -135,21 +153,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
             if (f < NPX * 2) {
                 f32x4 v = rreg[j];
                 if ((rzero >> j) & 1u) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4*>(&raw[buf * RAWBUF + f * 4]) = v;
+                *reinterpret_cast<f32x4*>(&raw[buf * RAWBUF + (f >> 1) * RS + (f & 1) * 4]) = v;
             }
         }
     };
 
     // ---- input transform V = B^T d B of one unit: thread = (tile t, channel pair cg) ----
     const int t_tile = tid >> 2, t_cg = tid & 3;
-    const int tr_base = (((t_tile >> 3) * 2) * PW + (t_tile & 7) * 2) * UC + t_cg * 2;     // top-left of the 4x4 window
+    const int tr_base = (((t_tile >> 3) * 2) * PW + (t_tile & 7) * 2) * RS + t_cg * 2;     // top-left of the 4x4 window
     const int tw_base = t_tile * TS + t_cg * 2;
     f32x2 dd[16];
     auto tf_read = [&](int buf, int k) __attribute__((always_inline)) {      // window elements 2k, 2k+1
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = 2 * k + u, i = e >> 2, j = e & 3;
-            dd[e] = *reinterpret_cast<const f32x2*>(&raw[buf * RAWBUF + tr_base + (i * PW + j) * UC]);
+            dd[e] = *reinterpret_cast<const f32x2*>(&raw[buf * RAWBUF + tr_base + (i * PW + j) * RS]);
         }
     };
     auto tf_rows = [&]() __attribute__((always_inline)) {                    // dd <- B^T dd (over the row index)
@@ -222,7 +240,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
 
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int n = 0;                                            // unit counter (parity selects the LDS buffers)
+#ifdef MP_TIMING
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool t_on = (p.H == g_timing_w_sel);
+#endif
     for (;;) {
+        MPW_T(t_item);
         f32x16 acc[16];
         const int item_next = item + stride;
         const bool has_next = item_next < item_end;
@@ -237,6 +260,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
             const float* const vr = Vs + vb * VBUF;
             const f32x4* const uc = up + (long long)c * (16 * 64);
             const f32x4* const ut = last ? unext : uc + 16 * 64;      // where the U prefetch continues
+            MPW_T(t_u0);
             afr[0] = *reinterpret_cast<const f32x4*>(&vr[a_base]);
             afr[1] = *reinterpret_cast<const f32x4*>(&vr[a_base + VPOS]);
 #pragma unroll
@@ -266,11 +290,17 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                 }
             }
             ++n;
+            MPW_T(t_u1);
+            MPW_ADD(0, t_u0, t_u1);                                   // MFMA steps of a unit
             __syncthreads();                                          // V(n+1) and raw(n+2) complete, V(n) consumed
+            MPW_T(t_u2);
+            MPW_ADD(1, t_u1, t_u2);                                   // unit barrier
         };
         unit_body(0, std::true_type{});
         for (int c = 1; c < NC; ++c) unit_body(c, std::false_type{});
 
+        MPW_T(t_e0);
+        MPW_ADD(3, t_item, t_e0);                                      // whole unit loop of the item
         // ---- output transform Y = A^T M A (in registers), bias / ReLU / BN, [2x2 max-pool], store ----
         // lane = output channel, register r = tile (r&3) + 8*(r>>2) + 4*(lane>>5) of the wave's tile group
         {
@@ -313,6 +343,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                 }
             }
         }
+        MPW_T(t_e1);
+        MPW_ADD(2, t_e0, t_e1);                                        // epilogue
+#ifdef MP_TIMING
+        tsum[7] += 1;
+        if (!has_next && tid == 0 && t_on)
+            for (int i = 0; i < 8; ++i) g_timing_w[blockIdx.x * 8 + i] = tsum[i];
+#endif
         if (!has_next) return;
         if (next_slice != cur.slice) {
             __syncthreads();

@@ -35,7 +35,7 @@ def counters(prefix):
 
 shutil.copy(os.path.join(src, 'stats_kernel_stats.csv'), os.path.join(dst, tag + '_bench_kernel_stats.csv'))
 
-DOMINANT = 'conv_mfma_kernel<9, 32, true, true, false>'      # fused encoder conv1+conv2 @480x640
+DOMINANT = 'conv_wino_kernel<true, false>'      # encoder conv2 (Winograd) @480x640: the largest-grid launch of this kernel
 
 fetch, write = counters('fetch'), counters('write')
 kernels = []
@@ -52,6 +52,7 @@ out = {'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, 
                'stream, MI355X_MICROARCH.md section HBM); WRITE_SIZE uncalibrated',
        'kernels': kernels, 'dominant_kernel': DOMINANT}
 dom = [k for k in kernels if k['kernel'] == DOMINANT]
+dom = [k for k in dom if k['fetch_size_bytes'] == max(d['fetch_size_bytes'] for d in dom)] if dom else dom
 if dom:
     out['dominant_kernel_mean_traffic_bytes_per_launch'] = sum(k['fetch_bytes_corrected'] + k['write_size_bytes']
                                                                for k in dom) / len(dom)
