@@ -6,7 +6,7 @@
 
 One "step" = one pass of the full hot path (detect + describe + match) over one batch of synthetic
 pairs already resident in HBM:  BASELINE.json configs[2] -- 32 pairs (64 grayscale 480x640 images) per
-GPU: encoder + detector/descriptor heads (fp32) -> box-NMS (size 4, iou 0.1, thr 0.015) -> top-k 1000
+GPU: encoder + detector/descriptor heads (fp32; 3x3 layers as Winograd F(2x2,3x3) GEMMs on the fp32 MFMA) -> box-NMS (size 4, iou 0.1, thr 0.015) -> top-k 1000
 -> bilinear descriptor sampling + L2 norm -> mutual-NN match.  Pairs shard independently over ranks
 (weak scaling, no data-path collective); RCCL only gathers the per-pair metric records.
 

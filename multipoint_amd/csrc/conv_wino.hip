@@ -267,7 +267,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
             for (int s = 0; s < 16; ++s) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    acc[s] = __builtin_amdgcn_mfma_f32_32x32x2f32(afr[s % 3][e], bfr[s % RBW][e], (FIRST && e == 0) ? zero16 : acc[s], 0, 0, 0);
+                    // pooled: C rows = tiles, columns = output channels (lane = channel: the pool window is one tile = one
+                    // register); otherwise the operands are swapped so that lane = tile and a register quad = 4 consecutive
+                    // channels (16-byte stores)
+                    acc[s] = POOL ? __builtin_amdgcn_mfma_f32_32x32x2f32(afr[s % 3][e], bfr[s % RBW][e], (FIRST && e == 0) ? zero16 : acc[s], 0, 0, 0)
+                                  : __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[s % RBW][e], afr[s % 3][e], (FIRST && e == 0) ? zero16 : acc[s], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (e == 0) {
                         bfr[(s + PFW) % RBW] = (s + PFW < 16) ? uc[(s + PFW) * 64] : ut[(s + PFW - 16) * 64];
@@ -302,8 +306,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
         MPW_T(t_e0);
         MPW_ADD(3, t_item, t_e0);                                      // whole unit loop of the item
         // ---- output transform Y = A^T M A (in registers), bias / ReLU / BN, [2x2 max-pool], store ----
-        // lane = output channel, register r = tile (r&3) + 8*(r>>2) + 4*(lane>>5) of the wave's tile group
-        {
+        if constexpr (POOL) {
+            // lane = output channel, register r = tile (r&3) + 8*(r>>2) + 4*(lane>>5) of the wave's tile group
             const int cl = chh * 32 + (lane & 31);
             const float bia = prm[cl], scl = prm[64 + cl], sft = prm[128 + cl];
             const int ch = cur.slice * 64 + cl;
@@ -313,7 +317,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                 return relu_w(v) * scl + sft;
             };
             const int cs = p.out_cstride;
-            const int Ho = POOL ? p.H >> 1 : p.H, Wo = POOL ? p.W >> 1 : p.W;
+            const int Ho = p.H >> 1, Wo = p.W >> 1;
             float* const obase = p.out + ((long long)cur.img * Ho * Wo) * cs + p.out_coff + ch;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -328,18 +332,57 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                 const float y10 = (t1[0] + t1[1]) + t1[2], y11 = (t1[1] - t1[2]) - t1[3];
                 const int tl = tg * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 const int ty = tl >> 3, tx = tl & 7;
-                if constexpr (POOL) {
-                    const float v = fmaxf(fmaxf(act(y00), act(y01)), fmaxf(act(y10), act(y11)));
-                    const int oy = (cur.y0 >> 1) + ty, ox = (cur.x0 >> 1) + tx;
-                    if (oy < Ho && ox < Wo && ch < p.cout) obase[((long long)oy * Wo + ox) * cs] = v;
+                const float v = fmaxf(fmaxf(act(y00), act(y01)), fmaxf(act(y10), act(y11)));
+                const int oy = (cur.y0 >> 1) + ty, ox = (cur.x0 >> 1) + tx;
+                if (oy < Ho && ox < Wo && ch < p.cout) obase[((long long)oy * Wo + ox) * cs] = v;
+            }
+        } else {
+            // lane = tile (lane&31) of the wave's tile group, register r = output channel (r&3) + 8*(r>>2) + 4*(lane>>5)
+            // of the wave's channel half: each register quad is 4 consecutive channels of the tile's 2x2 pixels
+            const int tl = tg * 32 + (lane & 31);
+            const int oy = cur.y0 + 2 * (tl >> 3), ox = cur.x0 + 2 * (tl & 7);
+            const int cs = p.out_cstride;
+            float* const opix = p.out + (((long long)cur.img * p.H + oy) * p.W + ox) * cs + p.out_coff + cur.slice * 64;
+            const bool ok00 = (oy < p.H) & (ox < p.W), ok01 = (oy < p.H) & (ox + 1 < p.W);
+            const bool ok10 = (oy + 1 < p.H) & (ox < p.W), ok11 = (oy + 1 < p.H) & (ox + 1 < p.W);
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int cl = chh * 32 + 8 * rq + 4 * (lane >> 5);
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(&prm[cl]);
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(&prm[64 + cl]);
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(&prm[128 + cl]);
+                f32x4 y00, y01, y10, y11;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float m[16];
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) m[s] = acc[s][rq * 4 + e];
+                    float t0[4], t1[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { t0[j] = (m[j] + m[4 + j]) + m[8 + j]; t1[j] = (m[4 + j] - m[8 + j]) - m[12 + j]; }
+                    auto act = [&](float v) __attribute__((always_inline)) -> float {
+                        v += b4[e];
+                        if (BNF) return relu_w(v * s4[e] + t4[e]);
+                        return relu_w(v) * s4[e] + t4[e];
+                    };
+                    y00[e] = act((t0[0] + t0[1]) + t0[2]); y01[e] = act((t0[1] - t0[2]) - t0[3]);
+                    y10[e] = act((t1[0] + t1[1]) + t1[2]); y11[e] = act((t1[1] - t1[2]) - t1[3]);
+                }
+                const int ch0 = cur.slice * 64 + cl;
+                if (ch0 + 3 < p.cout) {
+                    if (ok00) *reinterpret_cast<f32x4*>(opix + cl) = y00;
+                    if (ok01) *reinterpret_cast<f32x4*>(opix + cs + cl) = y01;
+                    if (ok10) *reinterpret_cast<f32x4*>(opix + (long long)p.W * cs + cl) = y10;
+                    if (ok11) *reinterpret_cast<f32x4*>(opix + (long long)p.W * cs + cs + cl) = y11;
                 } else {
-                    const int oy = cur.y0 + 2 * ty, ox = cur.x0 + 2 * tx;
-                    if (ch < p.cout) {
-                        if (oy < Ho && ox < Wo) obase[((long long)oy * Wo + ox) * cs] = act(y00);
-                        if (oy < Ho && ox + 1 < Wo) obase[((long long)oy * Wo + ox + 1) * cs] = act(y01);
-                        if (oy + 1 < Ho && ox < Wo) obase[((long long)(oy + 1) * Wo + ox) * cs] = act(y10);
-                        if (oy + 1 < Ho && ox + 1 < Wo) obase[((long long)(oy + 1) * Wo + ox + 1) * cs] = act(y11);
-                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (ch0 + e < p.cout) {
+                            if (ok00) opix[cl + e] = y00[e];
+                            if (ok01) opix[cs + cl + e] = y01[e];
+                            if (ok10) opix[(long long)p.W * cs + cl + e] = y10[e];
+                            if (ok11) opix[(long long)p.W * cs + cs + cl + e] = y11[e];
+                        }
                 }
             }
         }
