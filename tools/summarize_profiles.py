@@ -51,11 +51,20 @@ out = {'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, 
                'launch; fetch_bytes_corrected = 2 x FETCH_SIZE (gfx950 reports half of a wide 16 B/lane coalesced '
                'stream, MI355X_MICROARCH.md section HBM); WRITE_SIZE uncalibrated',
        'kernels': kernels, 'dominant_kernel': DOMINANT}
-dom = [k for k in kernels if k['kernel'] == DOMINANT]
-dom = [k for k in dom if k['fetch_size_bytes'] == max(d['fetch_size_bytes'] for d in dom)] if dom else dom
-if dom:
-    out['dominant_kernel_mean_traffic_bytes_per_launch'] = sum(k['fetch_bytes_corrected'] + k['write_size_bytes']
-                                                               for k in dom) / len(dom)
+# the pooled Winograd kernel is launched three times per step with the same grid (conv2, conv4, conv6, in this order):
+# separate them by launch position and report conv2 (the dominant launch)
+NPER = 3
+key = (DOMINANT, [k for k in fetch if k[0] == DOMINANT][0][1]) if any(k[0] == DOMINANT for k in fetch) else None
+if key:
+    f = fetch[key]['FETCH_SIZE']; w = write.get(key, {}).get('WRITE_SIZE', [])
+    per = []
+    for i in range(NPER):
+        fi = f[i::NPER]; wi = w[i::NPER] or [0.0]
+        per.append({'launch_position': i, 'fetch_size_bytes': sum(fi) / len(fi) * 1024.0,
+                    'fetch_bytes_corrected': 2 * sum(fi) / len(fi) * 1024.0, 'write_size_bytes': sum(wi) / len(wi) * 1024.0})
+    out['dominant_kernel_by_launch_position'] = per
+    d = max(per, key=lambda r: r['fetch_size_bytes'])
+    out['dominant_kernel_mean_traffic_bytes_per_launch'] = d['fetch_bytes_corrected'] + d['write_size_bytes']
 json.dump(out, open(os.path.join(dst, tag + '_pmc_hbm_traffic.json'), 'w'), indent=1)
 print('dominant traffic', out.get('dominant_kernel_mean_traffic_bytes_per_launch'))
 
