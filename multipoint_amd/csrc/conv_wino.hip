@@ -58,6 +58,15 @@ __device__ __forceinline__ int reflect_clamp_w(int v, int n)
     return v >= n ? n - 1 : v;
 }
 __device__ __forceinline__ float relu_w(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
+// Accumulator element -> arch VGPR exactly where it is needed.  Left to itself hipcc copies all 256 accumulator AGPRs to
+// VGPRs at the top of the epilogue, which spills the whole loop state (and every spill reload is an s_waitcnt vmcnt(0)
+// that also waits for the epilogue's own stores to be acknowledged).
+__device__ __forceinline__ float acc_read(float a)
+{
+    float x;
+    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a));
+    return x;
+}
 
 template <bool POOL, bool BNF>
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
     int n = 0;                                            // unit counter (parity selects the LDS buffers)
 #ifdef MP_TIMING
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    const bool t_on = (p.H == g_timing_w_sel);
+    const bool t_on = ((POOL ? p.H : -p.H) == g_timing_w_sel);      // select a pooled launch by +H, an un-pooled one by -H
 #endif
     for (;;) {
         MPW_T(t_item);
@@ -323,7 +332,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
             for (int r = 0; r < 16; ++r) {
                 float m[16];
 #pragma unroll
-                for (int s = 0; s < 16; ++s) m[s] = acc[s][r];
+                for (int s = 0; s < 16; ++s) m[s] = acc_read(acc[s][r]);
                 // rows: t[a][j] = sum_i A^T[a][i] m[i][j];  A^T = [[1,1,1,0],[0,1,-1,-1]]
                 float t0[4], t1[4];
 #pragma unroll
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                 for (int e = 0; e < 4; ++e) {
                     float m[16];
 #pragma unroll
-                    for (int s = 0; s < 16; ++s) m[s] = acc[s][rq * 4 + e];
+                    for (int s = 0; s < 16; ++s) m[s] = acc_read(acc[s][rq * 4 + e]);
                     float t0[4], t1[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { t0[j] = (m[j] + m[4 + j]) + m[8 + j]; t1[j] = (m[4 + j] - m[8 + j]) - m[12 + j]; }

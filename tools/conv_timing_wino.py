@@ -1,6 +1,7 @@
 """Developer tool (GPU box; library built with -DMP_TIMING, MP_LIB pointing at it): cycles per phase of the persistent
 Winograd conv workgroups per work item (one wave per SIMD, so s_memtime is uncontended).  MP_TIMING_H selects the launch
-by input height (480: conv2, 240: conv3 then conv4 (last writer), 120: conv5/6, 60: conv7/8/heads)."""
+by input height: +H a pooled layer (480: conv2, 240: conv4, 120: conv6), -H an un-pooled one (-240: conv3, -120: conv5,
+-60: conv7, conv8, heads -- the last writer)."""
 import sys, os, ctypes
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -26,8 +27,8 @@ n = t[:, 7]
 for i, nm in enumerate(['MFMA steps (all units)', 'unit barriers', 'epilogue', 'unit loop incl. barriers']):
     v = t[:, i] / n
     print('%-28s mean %8.0f  p10 %8.0f  p90 %8.0f cycles/item' % (nm, v.mean(), np.percentile(v, 10), np.percentile(v, 90)))
-layer = {480: 'enc.conv2', 240: 'enc.conv4', 120: 'enc.conv6'}.get(sel)
-nunits = {480: 8, 240: 8, 120: 16}.get(sel, 0)
+layer = {480: 'enc.conv2', 240: 'enc.conv4', 120: 'enc.conv6', -240: 'enc.conv3', -120: 'enc.conv5', -60: 'heads.conv3x3'}.get(sel)
+nunits = {480: 8, 240: 8, 120: 16, -240: 8, -120: 8, -60: 16}.get(sel, 0)
 print('workgroups %d, items per workgroup %.1f; MFMA per item: %d units x 64 MFMA x 64 = %d cycles' % (len(t), n.mean(), nunits, nunits * 4096))
 if layer in prof:
     tot = (t[:, 2] + t[:, 3]).mean()
