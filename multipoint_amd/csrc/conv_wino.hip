@@ -316,34 +316,42 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
         MPW_ADD(3, t_item, t_e0);                                      // whole unit loop of the item
         // ---- output transform Y = A^T M A (in registers), bias / ReLU / BN, [2x2 max-pool], store ----
         if constexpr (POOL) {
-            // lane = output channel, register r = tile (r&3) + 8*(r>>2) + 4*(lane>>5) of the wave's tile group
+            // lane = output channel, register r = tile (r&3) + 8*(r>>2) + 4*(lane>>5) of the wave's tile group, i.e.
+            // tile row tg*4 + (r>>2), tile column (r&3) + 4*(lane>>5).  Two registers (= two tiles) at a time so that
+            // the 24 additions of Y = A^T M A and the BN affine are packed instructions.
             const int cl = chh * 32 + (lane & 31);
             const float bia = prm[cl], scl = prm[64 + cl], sft = prm[128 + cl];
+            const f32x2 bia2 = {bia, bia}, scl2 = {scl, scl}, sft2 = {sft, sft};
             const int ch = cur.slice * 64 + cl;
-            auto act = [&](float v) __attribute__((always_inline)) -> float {
-                v += bia;
-                if (BNF) return relu_w(v * scl + sft);
-                return relu_w(v) * scl + sft;
+            auto act2 = [&](f32x2 v) __attribute__((always_inline)) -> f32x2 {
+                v += bia2;
+                if (BNF) { v = v * scl2 + sft2; return f32x2{relu_w(v[0]), relu_w(v[1])}; }
+                v = f32x2{relu_w(v[0]), relu_w(v[1])};
+                return v * scl2 + sft2;
             };
             const int cs = p.out_cstride;
             const int Ho = p.H >> 1, Wo = p.W >> 1;
-            float* const obase = p.out + ((long long)cur.img * Ho * Wo) * cs + p.out_coff + ch;
+            const int oy0 = (cur.y0 >> 1) + tg * 4, ox0 = (cur.x0 >> 1) + 4 * (lane >> 5);
+            float* const obase = p.out + (((long long)cur.img * Ho + oy0) * Wo + (cur.x0 >> 1)) * cs + p.out_coff + cur.slice * 64;
+            const int lane_off = 4 * (lane >> 5) * cs + cl;
+            const bool chok = ch < p.cout;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float m[16];
+            for (int r = 0; r < 16; r += 2) {
+                f32x2 m[16];
 #pragma unroll
-                for (int s = 0; s < 16; ++s) m[s] = acc_read(acc[s][r]);
+                for (int s = 0; s < 16; ++s) m[s] = f32x2{acc_read(acc[s][r]), acc_read(acc[s][r + 1])};
                 // rows: t[a][j] = sum_i A^T[a][i] m[i][j];  A^T = [[1,1,1,0],[0,1,-1,-1]]
-                float t0[4], t1[4];
+                f32x2 t0[4], t1[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { t0[j] = (m[j] + m[4 + j]) + m[8 + j]; t1[j] = (m[4 + j] - m[8 + j]) - m[12 + j]; }
-                const float y00 = (t0[0] + t0[1]) + t0[2], y01 = (t0[1] - t0[2]) - t0[3];
-                const float y10 = (t1[0] + t1[1]) + t1[2], y11 = (t1[1] - t1[2]) - t1[3];
-                const int tl = tg * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int ty = tl >> 3, tx = tl & 7;
-                const float v = fmaxf(fmaxf(act(y00), act(y01)), fmaxf(act(y10), act(y11)));
-                const int oy = (cur.y0 >> 1) + ty, ox = (cur.x0 >> 1) + tx;
-                if (oy < Ho && ox < Wo && ch < p.cout) obase[((long long)oy * Wo + ox) * cs] = v;
+                const f32x2 y00 = act2((t0[0] + t0[1]) + t0[2]), y01 = act2((t0[1] - t0[2]) - t0[3]);
+                const f32x2 y10 = act2((t1[0] + t1[1]) + t1[2]), y11 = act2((t1[1] - t1[2]) - t1[3]);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float v = fmaxf(fmaxf(y00[u], y01[u]), fmaxf(y10[u], y11[u]));
+                    const int dy = (r + u) >> 2, dx = (r + u) & 3;               // wave-uniform part of the tile position
+                    if (oy0 + dy < Ho && ox0 + dx < Wo && chok) obase[((long long)dy * Wo + dx) * cs + lane_off] = v;
+                }
             }
         } else {
             // lane = tile (lane&31) of the wave's tile group, register r = output channel (r&3) + 8*(r>>2) + 4*(lane>>5)
