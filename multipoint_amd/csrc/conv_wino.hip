@@ -369,21 +369,26 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                 const f32x4 s4 = *reinterpret_cast<const f32x4*>(&prm[64 + cl]);
                 const f32x4 t4 = *reinterpret_cast<const f32x4*>(&prm[128 + cl]);
                 f32x4 y00, y01, y10, y11;
+                // two channels at a time: packed additions / BN affine
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float m[16];
+                for (int e = 0; e < 4; e += 2) {
+                    f32x2 m[16];
 #pragma unroll
-                    for (int s = 0; s < 16; ++s) m[s] = acc_read(acc[s][rq * 4 + e]);
-                    float t0[4], t1[4];
+                    for (int s = 0; s < 16; ++s) m[s] = f32x2{acc_read(acc[s][rq * 4 + e]), acc_read(acc[s][rq * 4 + e + 1])};
+                    f32x2 t0[4], t1[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { t0[j] = (m[j] + m[4 + j]) + m[8 + j]; t1[j] = (m[4 + j] - m[8 + j]) - m[12 + j]; }
-                    auto act = [&](float v) __attribute__((always_inline)) -> float {
-                        v += b4[e];
-                        if (BNF) return relu_w(v * s4[e] + t4[e]);
-                        return relu_w(v) * s4[e] + t4[e];
+                    const f32x2 bb = {b4[e], b4[e + 1]}, ss = {s4[e], s4[e + 1]}, tt = {t4[e], t4[e + 1]};
+                    auto act2 = [&](f32x2 v) __attribute__((always_inline)) -> f32x2 {
+                        v += bb;
+                        if (BNF) { v = v * ss + tt; return f32x2{relu_w(v[0]), relu_w(v[1])}; }
+                        v = f32x2{relu_w(v[0]), relu_w(v[1])};
+                        return v * ss + tt;
                     };
-                    y00[e] = act((t0[0] + t0[1]) + t0[2]); y01[e] = act((t0[1] - t0[2]) - t0[3]);
-                    y10[e] = act((t1[0] + t1[1]) + t1[2]); y11[e] = act((t1[1] - t1[2]) - t1[3]);
+                    const f32x2 a00 = act2((t0[0] + t0[1]) + t0[2]), a01 = act2((t0[1] - t0[2]) - t0[3]);
+                    const f32x2 a10 = act2((t1[0] + t1[1]) + t1[2]), a11 = act2((t1[1] - t1[2]) - t1[3]);
+                    y00[e] = a00[0]; y00[e + 1] = a00[1]; y01[e] = a01[0]; y01[e + 1] = a01[1];
+                    y10[e] = a10[0]; y10[e + 1] = a10[1]; y11[e] = a11[0]; y11[e + 1] = a11[1];
                 }
                 const int ch0 = cur.slice * 64 + cl;
                 if (ch0 + 3 < p.cout) {
