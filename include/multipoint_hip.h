@@ -165,6 +165,44 @@ int mp_find_homography(mp_handle* h, const int* kp_yx, const int* kp_count, cons
                        double reproj_threshold, int max_iters, unsigned long long seed, double* homography,
                        unsigned char* inlier_mask, int* n_inliers, void* stream);
 
+/* ---- homographic adaptation: multipoint/utils/homographies.py:38-189, export_keypoints.py:64-103 ----
+ * Homographies are device double [n][9], row-major 3x3 acting on pixel coordinates (x, y, 1).
+ *
+ * mp_warp_perspective replaces WarpingModule / warp_perspective_tensor (homographies.py:404-433; kornia's
+ * homography_warp = F.grid_sample(align_corners=True) on the homography in normalised coordinates): single-channel
+ * maps src [n_src][H][W] -> dst [n_out][Ho][Wo],  dst[n](x, y) = src[n % n_src] sampled at dst_to_src[n] * (x, y, 1)
+ * (dst_to_src = inverse of the M the reference passes); mode 0 bilinear / 1 nearest (half to even);
+ * padding 0 zeros / 1 reflection (about pixel centres 0 and size-1). */
+int mp_warp_perspective(mp_handle* h, const float* src, int n_src, int H, int W, const double* dst_to_src, int n_out,
+                        int Ho, int Wo, int mode, int padding, float* dst, void* stream);
+
+/* replaces compute_valid_mask (homographies.py:361-389) for G homographies: cv2.warpPerspective(ones, M, INTER_NEAREST)
+ * (1 where the rounded source pixel hom_inv * (x, y, 1) lies in the frame) followed by cv2.erode with a
+ * (2*erosion_radius+1)^2 box (erosion_radius <= 16); mask_border != 0 also erodes from the image border.
+ * mask: uint8 [G][H][W]. */
+int mp_ha_valid_mask(mp_handle* h, const double* hom_inv, int G, int H, int W, int erosion_radius, int mask_border,
+                     unsigned char* mask, void* stream);
+
+/* aggregation state of homographic_adaptation(_multispectral): prob, count fp32 [B][H][W].
+ * aggregation 0: one map (prob_b NULL); 1 'prod' / 2 'sum' of the optical and thermal maps (homographies.py:63-68).
+ *   mp_ha_begin       prob = map(s) of the un-warped images, count = 1                            (:60-68, :149-150)
+ *   mp_ha_accumulate  for g < G in order: cs = nearest(mask[g], hom[g]); count += cs;
+ *                     prob += bilinear(map[g][b], hom[g]) * cs   (zeros padding)                   (:111-113, :178-180)
+ *                     prob_a / prob_b: [G][B][H][W] heat maps of the images warped by hom[g]
+ *   mp_ha_finalize    out = prob / count; sqrt (prod) or * 0.5 (sum); 0 where count < min_count    (:115-127, :182-187) */
+int mp_ha_begin(mp_handle* h, const float* prob_a, const float* prob_b, int B, int H, int W, int aggregation,
+                float* prob, float* count, void* stream);
+int mp_ha_accumulate(mp_handle* h, const float* prob_a, const float* prob_b, const unsigned char* mask,
+                     const double* hom, int G, int B, int H, int W, int aggregation, float* prob, float* count,
+                     void* stream);
+int mp_ha_finalize(mp_handle* h, const float* prob, const float* count, int B, int H, int W, int aggregation,
+                   float min_count, float* out, void* stream);
+
+/* replaces filter(pad(prob)) (homographies.py:55-58: ReflectionPad2d((k-1)/2) + the k x k depthwise filter of
+ * utils.get_gaussian_filter, utils.py:124-160): in/out fp32 [B][H][W], weights device fp32 [k][k], k odd, k <= 31. */
+int mp_gaussian_filter(mp_handle* h, const float* in, int B, int H, int W, int ksize, const float* weights, float* out,
+                       void* stream);
+
 /* per-launch timing of mp_forward with hipEvents on the caller's stream (bench.py roofline leg).
  * mp_profile_read synchronises; names[i] points to static strings. */
 int mp_profile_enable(mp_handle* h, int enable);

@@ -54,6 +54,14 @@ SIGNATURES = {
                                  c_void_p, c_void_p]),
     'mp_find_homography': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_double, c_int,
                                    ctypes.c_ulonglong, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mp_warp_perspective': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                    c_void_p, c_void_p]),
+    'mp_ha_valid_mask': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    'mp_ha_begin': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    'mp_ha_accumulate': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                 c_void_p, c_void_p, c_void_p]),
+    'mp_ha_finalize': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    'mp_gaussian_filter': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'mp_profile_enable': (c_int, [c_void_p, c_int]),
     'mp_profile_read': (c_int, [c_void_p, ctypes.POINTER(ctypes.c_char_p), ctypes.POINTER(c_float),
                                 ctypes.POINTER(ctypes.c_double), c_int, ctypes.POINTER(c_int)]),

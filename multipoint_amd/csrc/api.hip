@@ -1010,6 +1010,98 @@ int mp_find_homography(mp_handle* h, const int* kp_yx, const int* kp_count, cons
     return MP_OK;
 }
 
+int mp_warp_perspective(mp_handle* h, const float* src, int n_src, int H, int W, const double* dst_to_src, int n_out,
+                        int Ho, int Wo, int mode, int padding, float* dst, void* stream)
+{
+    if (!h) return MP_EINVAL;
+    if (!src || !dst_to_src || !dst) return fail(h, MP_EINVAL, "mp_warp_perspective: NULL tensor");
+    if (n_src <= 0 || n_out <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || n_out > 65535)
+        return fail(h, MP_EINVAL, "mp_warp_perspective: sizes must be positive (n_out <= 65535)");
+    if ((mode != 0 && mode != 1) || (padding != 0 && padding != 1))
+        return fail(h, MP_EINVAL, "mp_warp_perspective: mode must be 0 (bilinear) / 1 (nearest), padding 0 (zeros) / 1 (reflection)");
+    MP_HIP(hipSetDevice(h->device));
+    launch_warp_perspective(src, n_src, H, W, dst_to_src, n_out, Ho, Wo, mode, padding, dst, static_cast<hipStream_t>(stream));
+    MP_HIP(hipGetLastError());
+    return MP_OK;
+}
+
+int mp_ha_valid_mask(mp_handle* h, const double* hom_inv, int G, int H, int W, int erosion_radius, int mask_border,
+                     unsigned char* mask, void* stream)
+{
+    if (!h) return MP_EINVAL;
+    if (!hom_inv || !mask) return fail(h, MP_EINVAL, "mp_ha_valid_mask: NULL tensor");
+    if (G <= 0 || G > 65535 || H <= 0 || W <= 0) return fail(h, MP_EINVAL, "mp_ha_valid_mask: need 0 < G <= 65535, H, W > 0");
+    if (erosion_radius < 0 || erosion_radius > 16) return fail(h, MP_EINVAL, "mp_ha_valid_mask: erosion_radius must be in [0, 16]");
+    MP_HIP(hipSetDevice(h->device));
+    launch_ha_valid_mask(hom_inv, G, H, W, erosion_radius, mask_border != 0, mask, static_cast<hipStream_t>(stream));
+    MP_HIP(hipGetLastError());
+    return MP_OK;
+}
+
+static int ha_check(mp_handle* h, const char* fn, const float* pa, const float* pb, int B, int H, int W, int aggregation)
+{
+    if (!pa || (aggregation != 0 && !pb)) return fail(h, MP_EINVAL, std::string(fn) + ": NULL heat map");
+    if (aggregation < 0 || aggregation > 2) return fail(h, MP_EINVAL, std::string(fn) + ": aggregation must be 0 (single), 1 (prod) or 2 (sum)");
+    if (B <= 0 || B > 65535 || H <= 0 || W <= 0) return fail(h, MP_EINVAL, std::string(fn) + ": need 0 < B <= 65535, H, W > 0");
+    return MP_OK;
+}
+
+int mp_ha_begin(mp_handle* h, const float* prob_a, const float* prob_b, int B, int H, int W, int aggregation,
+                float* prob, float* count, void* stream)
+{
+    if (!h) return MP_EINVAL;
+    int rc;
+    if ((rc = ha_check(h, "mp_ha_begin", prob_a, prob_b, B, H, W, aggregation))) return rc;
+    if (!prob || !count) return fail(h, MP_EINVAL, "mp_ha_begin: NULL tensor");
+    MP_HIP(hipSetDevice(h->device));
+    launch_ha_begin(prob_a, prob_b, (long long)B * H * W, aggregation, prob, count, static_cast<hipStream_t>(stream));
+    MP_HIP(hipGetLastError());
+    return MP_OK;
+}
+
+int mp_ha_accumulate(mp_handle* h, const float* prob_a, const float* prob_b, const unsigned char* mask,
+                     const double* hom, int G, int B, int H, int W, int aggregation, float* prob, float* count,
+                     void* stream)
+{
+    if (!h) return MP_EINVAL;
+    int rc;
+    if ((rc = ha_check(h, "mp_ha_accumulate", prob_a, prob_b, B, H, W, aggregation))) return rc;
+    if (!mask || !hom || !prob || !count) return fail(h, MP_EINVAL, "mp_ha_accumulate: NULL tensor");
+    if (G <= 0) return fail(h, MP_EINVAL, "mp_ha_accumulate: G must be positive");
+    MP_HIP(hipSetDevice(h->device));
+    launch_ha_accumulate(prob_a, prob_b, mask, hom, G, B, H, W, aggregation, prob, count, static_cast<hipStream_t>(stream));
+    MP_HIP(hipGetLastError());
+    return MP_OK;
+}
+
+int mp_ha_finalize(mp_handle* h, const float* prob, const float* count, int B, int H, int W, int aggregation,
+                   float min_count, float* out, void* stream)
+{
+    if (!h) return MP_EINVAL;
+    int rc;
+    if ((rc = ha_check(h, "mp_ha_finalize", prob, count, B, H, W, aggregation))) return rc;
+    if (!out) return fail(h, MP_EINVAL, "mp_ha_finalize: NULL tensor");
+    MP_HIP(hipSetDevice(h->device));
+    launch_ha_finalize(prob, count, (long long)B * H * W, aggregation, min_count, out, static_cast<hipStream_t>(stream));
+    MP_HIP(hipGetLastError());
+    return MP_OK;
+}
+
+int mp_gaussian_filter(mp_handle* h, const float* in, int B, int H, int W, int ksize, const float* weights, float* out,
+                       void* stream)
+{
+    if (!h) return MP_EINVAL;
+    if (!in || !weights || !out) return fail(h, MP_EINVAL, "mp_gaussian_filter: NULL tensor");
+    if (in == out) return fail(h, MP_EINVAL, "mp_gaussian_filter: in-place filtering is not supported");
+    if (B <= 0 || B > 65535 || H <= 0 || W <= 0) return fail(h, MP_EINVAL, "mp_gaussian_filter: need 0 < B <= 65535, H, W > 0");
+    if (ksize < 1 || ksize > 31 || (ksize & 1) == 0) return fail(h, MP_EINVAL, "mp_gaussian_filter: ksize must be odd and <= 31");
+    if ((ksize - 1) / 2 >= H || (ksize - 1) / 2 >= W) return fail(h, MP_EINVAL, "mp_gaussian_filter: reflection padding needs (ksize-1)/2 < H, W");
+    MP_HIP(hipSetDevice(h->device));
+    launch_gaussian_filter(in, B, H, W, ksize, weights, out, static_cast<hipStream_t>(stream));
+    MP_HIP(hipGetLastError());
+    return MP_OK;
+}
+
 int mp_profile_enable(mp_handle* h, int enable)
 {
     if (!h) return MP_EINVAL;

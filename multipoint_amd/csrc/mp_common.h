@@ -155,3 +155,18 @@ void launch_repeatability(const int* kp_yx, const int* kp_count, const double* h
 void launch_ransac_homography(const int* kp_yx, const int* kp_count, const int* match_idx, int P, int K, int T, double thr,
                               unsigned long long seed, unsigned long long* best, double* H_out, unsigned char* mask,
                               int* n_inliers, hipStream_t s);
+
+// homographic adaptation (homog_adapt.hip; reference multipoint/utils/homographies.py:38-189, 361-433).
+// hom arrays are device double [n][9], row-major 3x3 acting on pixel (x, y, 1).
+// warp: dst[n](x, y) = src[n % n_src] sampled at hom[n] * (x, y, 1); mode 0 bilinear / 1 nearest, padding 0 zeros / 1 reflection
+void launch_warp_perspective(const float* src, int n_src, int H, int W, const double* hom, int n_out, int Ho, int Wo,
+                             int mode, int padding, float* dst, hipStream_t s);
+void launch_ha_valid_mask(const double* hom_inv, int G, int H, int W, int r, int mask_border, unsigned char* mask,
+                          hipStream_t s);
+void launch_ha_begin(const float* pa, const float* pb, long long n, int aggregation, float* prob, float* count,
+                     hipStream_t s);
+void launch_ha_accumulate(const float* pa, const float* pb, const unsigned char* mask, const double* hom, int G, int B,
+                          int H, int W, int aggregation, float* prob, float* count, hipStream_t s);
+void launch_ha_finalize(const float* prob, const float* count, long long n, int aggregation, float min_count, float* out,
+                        hipStream_t s);
+void launch_gaussian_filter(const float* in, int B, int H, int W, int k, const float* wgt, float* out, hipStream_t s);

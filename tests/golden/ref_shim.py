@@ -34,3 +34,23 @@ def install():
     import multipoint.models as models
     import multipoint.utils as utils
     return models, utils
+
+
+def install_homographies():
+    """multipoint.utils.homographies of the reference with its absent third-party calls (cv2.getPerspectiveTransform /
+    warpPerspective / erode, kornia's dst_norm_to_dst_norm / homography_warp) supplied by the oracle's restatements
+    (oracle/ha_oracle.py): what then runs is the REFERENCE's own sample_homography, compute_valid_mask and
+    homographic_adaptation(_multispectral) driver code."""
+    install()
+    import cv2
+    import multipoint.utils.homographies as RH
+    from oracle import ha_oracle as HA
+    cv2.getPerspectiveTransform = HA.cv2_get_perspective_transform
+    cv2.INTER_NEAREST = 0
+    cv2.warpPerspective = lambda src, M, dsize, flags=None: HA.cv2_warp_perspective_nearest(src, M, dsize)
+    cv2.erode = lambda src, kernel, iterations=1: HA.cv2_erode(src, kernel, iterations)
+    ns = types.SimpleNamespace
+    RH.kornia = ns(geometry=ns(transform=ns(imgwarp=ns(dst_norm_to_dst_norm=HA.dst_norm_to_dst_norm))))
+    RH.homography_warp = HA.kornia_homography_warp
+    RH.kornia_available = True
+    return RH

@@ -261,3 +261,67 @@ def test_channel_versions_against_reference(oracle, ref, upd):
     assert (r['prob'] - o['prob']).abs().max().item() <= 1e-7 and (r['desc'] - o['desc']).abs().max().item() <= 1e-7
     from multipoint_amd.models import MultiPoint
     assert [(k, tuple(s)) for k, s, _ in MultiPoint(dict(cfg)).state_dict_spec()] == [(k, tuple(s)) for k, s, _ in spec]
+
+
+# ---- homographic adaptation (reference multipoint/utils/homographies.py) ---------------------------------------
+@pytest.fixture(scope='module')
+def ref_homographies(ref):
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+    import ref_shim
+    return ref_shim.install_homographies()
+
+
+def test_product_sample_homography_matches_reference(ref_homographies):
+    """host logic of the product (no GPU): draw for draw the reference's sampler, on fresh seeds"""
+    from multipoint_amd.utils.homographies import sample_homography, homography_adaptation_default_config
+    RH = ref_homographies
+    cases = [{}, {'allow_artifacts': False, 'max_angle': 0.4}, {'perspective': False, 'n_scales': 3},
+             {'rotation': False, 'translation': False, 'scaling_amplitude': 0.5},
+             dict(homography_adaptation_default_config['homographies'])]
+    for seed in range(100, 112):
+        for kw in cases:
+            for shape in ((240, 320), (64, 64)):
+                np.random.seed(seed); want = RH.sample_homography(np.array(shape), **kw)
+                state = np.random.get_state()[1][:4].copy()
+                np.random.seed(seed); got = sample_homography(np.array(shape), **kw)
+                assert np.allclose(got, want, rtol=1e-9, atol=1e-11), (seed, kw)
+                assert np.array_equal(np.random.get_state()[1][:4], state)       # same number of draws consumed
+
+
+def test_oracle_homographic_adaptation_matches_reference_driver(oracle, ref, ref_homographies):
+    import copy
+    from oracle import ha_oracle as HA
+    models, utils = ref
+    RH = ref_homographies
+    pristine = copy.deepcopy(RH.homography_adaptation_default_config)
+    for pair, agg, hc in ((False, None, {'num': 3, 'erosion_radius': 2, 'mask_border': True, 'min_count': 2, 'filter_size': 0}),
+                          (False, None, {'num': 3, 'erosion_radius': 4, 'mask_border': False, 'min_count': 0, 'filter_size': 5}),
+                          (True, 'prod', {'num': 3, 'aggregation': 'prod', 'erosion_radius': 3, 'min_count': 3}),
+                          (True, 'sum', {'num': 2, 'aggregation': 'sum', 'erosion_radius': 0, 'filter_size': 3})):
+        cfg = {'multispectral': True, 'descriptor_size': 64} if pair else dict(oracle.SHIPPED_MODEL_CONFIG)
+        sd = oracle.make_weights(17, cfg)
+        net = models.MultiPoint(dict(cfg)).eval()
+        net.load_state_dict(sd)
+        img = oracle.make_images(41, 4 if pair else 2, 48, 56)
+        RH.homography_adaptation_default_config.clear()          # the reference's dict_update writes into its default
+        RH.homography_adaptation_default_config.update(copy.deepcopy(pristine))
+        np.random.seed(23)
+        with torch.no_grad():
+            if pair:
+                flags = [torch.ones(2, 1, dtype=torch.bool), torch.zeros(2, 1, dtype=torch.bool)]
+                data = {'optical': {'image': img[:2], 'is_optical': flags[0]},
+                        'thermal': {'image': img[2:], 'is_optical': flags[1]}}
+                want = RH.homographic_adaptation_multispectral(data, net, copy.deepcopy(hc))
+                fwd = lambda i, x: oracle.forward(sd, x, cfg, is_optical=flags[i])['prob']
+                streams = [img[:2], img[2:]]
+            else:
+                want = RH.homographic_adaptation({'image': img}, net, copy.deepcopy(hc))
+                fwd = lambda i, x: oracle.forward(sd, x, cfg)['prob']
+                streams = [img]
+        full = HA.full_config(hc)
+        np.random.seed(23)
+        homs = [RH.sample_homography(np.array([48, 56]), **full['homographies']) for _ in range(hc['num'] - 1)]
+        got, _ = HA.homographic_adaptation(streams, fwd, hc, homs, aggregation=agg)
+        assert (got - want).abs().max().item() <= 1e-6, hc
+    RH.homography_adaptation_default_config.clear()
+    RH.homography_adaptation_default_config.update(pristine)
