@@ -176,6 +176,14 @@ int mp_find_homography(mp_handle* h, const int* kp_yx, const int* kp_count, cons
 int mp_warp_perspective(mp_handle* h, const float* src, int n_src, int H, int W, const double* dst_to_src, int n_out,
                         int Ho, int Wo, int mode, int padding, float* dst, void* stream);
 
+/* replaces cv2.warpPerspective(image, M, (W, H), borderMode=...) with the default INTER_LINEAR, as the dataset's
+ * homographic augmentation calls it (multipoint/datasets/augmentation/augmentation.py:33-36): source coordinates in
+ * 1/32-pixel fixed point (OpenCV's INTER_BITS = 5), float32 bilinear weight table, block-wise float64 coordinate
+ * arithmetic.  src/dst fp32 [n][H][W] (dst != src); hom_inv device double [n][9] = inverse of the M the reference
+ * passes (cv2 inverts it first); border 0 = BORDER_CONSTANT (0), 1 = BORDER_REFLECT_101. */
+int mp_warp_perspective_cv(mp_handle* h, const float* src, int n, int H, int W, const double* hom_inv, int border,
+                           float* dst, void* stream);
+
 /* replaces compute_valid_mask (homographies.py:361-389) for G homographies: cv2.warpPerspective(ones, M, INTER_NEAREST)
  * (1 where the rounded source pixel hom_inv * (x, y, 1) lies in the frame) followed by cv2.erode with a
  * (2*erosion_radius+1)^2 box (erosion_radius <= 16); mask_border != 0 also erodes from the image border.

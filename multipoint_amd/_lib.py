@@ -56,6 +56,7 @@ SIGNATURES = {
                                    ctypes.c_ulonglong, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mp_warp_perspective': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                     c_void_p, c_void_p]),
+    'mp_warp_perspective_cv': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     'mp_ha_valid_mask': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     'mp_ha_begin': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     'mp_ha_accumulate': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,

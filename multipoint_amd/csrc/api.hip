@@ -1025,6 +1025,22 @@ int mp_warp_perspective(mp_handle* h, const float* src, int n_src, int H, int W,
     return MP_OK;
 }
 
+int mp_warp_perspective_cv(mp_handle* h, const float* src, int n, int H, int W, const double* hom_inv, int border,
+                           float* dst, void* stream)
+{
+    if (!h) return MP_EINVAL;
+    if (!src || !hom_inv || !dst) return fail(h, MP_EINVAL, "mp_warp_perspective_cv: NULL tensor");
+    if (n <= 0 || n > 65535 || H <= 0 || W <= 0 || H > 32767 || W > 32767)
+        return fail(h, MP_EINVAL, "mp_warp_perspective_cv: need 0 < n <= 65535 and 0 < H, W <= 32767");
+    if (border != 0 && border != 1)
+        return fail(h, MP_EINVAL, "mp_warp_perspective_cv: border must be 0 (BORDER_CONSTANT 0) or 1 (BORDER_REFLECT_101)");
+    if (src == dst) return fail(h, MP_EINVAL, "mp_warp_perspective_cv: in-place warp is not supported");
+    MP_HIP(hipSetDevice(h->device));
+    launch_cv_warp_linear(src, n, H, W, hom_inv, border, dst, static_cast<hipStream_t>(stream));
+    MP_HIP(hipGetLastError());
+    return MP_OK;
+}
+
 int mp_ha_valid_mask(mp_handle* h, const double* hom_inv, int G, int H, int W, int erosion_radius, int mask_border,
                      unsigned char* mask, void* stream)
 {

@@ -97,6 +97,80 @@ __global__ __launch_bounds__(256) void warp_kernel(const float* __restrict__ src
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// cv2.warpPerspective(image, M, (W, H), flags=INTER_LINEAR, borderMode=BORDER_REFLECT_101 | BORDER_CONSTANT) as the
+// dataset's homographic augmentation calls it (multipoint/datasets/augmentation/augmentation.py:33-36), restated from
+// OpenCV's published algorithm (opencv-python==4.2.0.34, imgproc WarpPerspectiveInvoker + remapBilinear<float>):
+//  * the destination is cut into blocks 64 wide (bw0 below); per row of a block X0 = M0*xb + M1*y + M2 (likewise Y0,
+//    W0) in float64, per pixel W = 32 / (W0 + M6*x1), (X0 + M0*x1)*W rounded half-to-even to an integer in 1/32 px
+//    units: source pixel = that >> 5 (saturated to int16), fraction = that & 31;
+//  * the four taps are weighted by the float32 table (1-fy)(1-fx), (1-fy)fx, fy(1-fx), fy*fx with f = frac/32 and
+//    summed left to right in float32 without contraction;
+//  * out-of-frame taps: BORDER_CONSTANT -> 0, BORDER_REFLECT_101 -> reflected about the edge pixel centres.
+// M is the INVERTED homography (dst -> src), as cv2 computes it before the loop.
+__device__ __forceinline__ int cv_border_101(int p, int len)
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    do {
+        p = p < 0 ? -p : 2 * len - 2 - p;
+    } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
+
+// Every product and sum below is rounded separately, as OpenCV's scalar code does: contraction is switched off for the
+// two functions (hipcc's __dmul_rn / __fadd_rn wrappers are inline operators that carry their own `contract` flag).
+__device__ __forceinline__ int cv_fixed_coord(double num, double w)
+{
+#pragma clang fp contract(off)
+    double f = num * w;
+    f = fmax(-2147483648.0, fmin(2147483647.0, f));
+    return (int)rint(f);
+}
+
+template <int BORDER>   // 0 BORDER_CONSTANT (value 0), 1 BORDER_REFLECT_101
+__global__ __launch_bounds__(256) void cv_warp_linear_kernel(const float* __restrict__ src, int H, int W,
+                                                             const double* __restrict__ hom_inv, int bw0,
+                                                             float* __restrict__ dst)
+{
+#pragma clang fp contract(off)
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int n = blockIdx.z;
+    if (x >= W || y >= H) return;
+    const Hom h = load_hom(hom_inv + (size_t)n * 9);
+    const float* img = src + (size_t)n * H * W;
+    const int xb = (x / bw0) * bw0;
+    const double dxb = (double)xb, dx1 = (double)(x - xb), dy = (double)y;
+    const double X0 = (h.m[0] * dxb + h.m[1] * dy) + h.m[2];
+    const double Y0 = (h.m[3] * dxb + h.m[4] * dy) + h.m[5];
+    const double W0 = (h.m[6] * dxb + h.m[7] * dy) + h.m[8];
+    double w = W0 + h.m[6] * dx1;
+    w = w != 0.0 ? 32.0 / w : 0.0;
+    const int X = cv_fixed_coord(X0 + h.m[0] * dx1, w);
+    const int Y = cv_fixed_coord(Y0 + h.m[3] * dx1, w);
+    const int sx = max(-32768, min(32767, X >> 5)), sy = max(-32768, min(32767, Y >> 5));
+    const float fx = (float)(X & 31) * (1.f / 32.f), fy = (float)(Y & 31) * (1.f / 32.f);
+    const float ax = 1.f - fx, ay = 1.f - fy;
+    const float w0 = ay * ax, w1 = ay * fx, w2 = fy * ax, w3 = fy * fx;
+    float v0, v1, v2, v3;
+    if (BORDER == 0) {
+        const bool xa = (unsigned)sx < (unsigned)W, xc = (unsigned)(sx + 1) < (unsigned)W;
+        const bool ya = (unsigned)sy < (unsigned)H, yc = (unsigned)(sy + 1) < (unsigned)H;
+        v0 = (ya && xa) ? img[(size_t)sy * W + sx] : 0.f;
+        v1 = (ya && xc) ? img[(size_t)sy * W + sx + 1] : 0.f;
+        v2 = (yc && xa) ? img[(size_t)(sy + 1) * W + sx] : 0.f;
+        v3 = (yc && xc) ? img[(size_t)(sy + 1) * W + sx + 1] : 0.f;
+    } else {
+        const int xa = cv_border_101(sx, W), xc = cv_border_101(sx + 1, W);
+        const int ya = cv_border_101(sy, H), yc = cv_border_101(sy + 1, H);
+        v0 = img[(size_t)ya * W + xa]; v1 = img[(size_t)ya * W + xc];
+        v2 = img[(size_t)yc * W + xa]; v3 = img[(size_t)yc * W + xc];
+    }
+    const float p0 = v0 * w0, p1 = v1 * w1, p2 = v2 * w2, p3 = v3 * w3;
+    dst[((size_t)n * H + y) * W + x] = ((p0 + p1) + p2) + p3;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // valid mask: tile 32 x 32 outputs, halo r (<= 16) staged in LDS as the raw cv2.warpPerspective(ones) mask
 constexpr int VT = 32, VR_MAX = 16, VL = VT + 2 * VR_MAX;
 
@@ -244,6 +318,17 @@ void launch_warp_perspective(const float* src, int n_src, int H, int W, const do
     else if (mode == 0) warp_kernel<0, 1><<<g, 256, 0, s>>>(src, n_src, H, W, hom, n_out, Ho, Wo, dst);
     else if (padding == 0) warp_kernel<1, 0><<<g, 256, 0, s>>>(src, n_src, H, W, hom, n_out, Ho, Wo, dst);
     else warp_kernel<1, 1><<<g, 256, 0, s>>>(src, n_src, H, W, hom, n_out, Ho, Wo, dst);
+}
+
+void launch_cv_warp_linear(const float* src, int n, int H, int W, const double* hom_inv, int border, float* dst,
+                           hipStream_t s)
+{
+    // OpenCV's block width: bh0 = min(16, H); bw0 = min(1024 / bh0, W)
+    const int bh0 = H < 16 ? H : 16;
+    const int bw0 = (1024 / bh0) < W ? (1024 / bh0) : W;
+    const dim3 g = px_grid(W, H, n);
+    if (border == 0) cv_warp_linear_kernel<0><<<g, 256, 0, s>>>(src, H, W, hom_inv, bw0, dst);
+    else cv_warp_linear_kernel<1><<<g, 256, 0, s>>>(src, H, W, hom_inv, bw0, dst);
 }
 
 void launch_ha_valid_mask(const double* hom_inv, int G, int H, int W, int r, int mask_border, unsigned char* mask,

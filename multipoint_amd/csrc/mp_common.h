@@ -161,6 +161,8 @@ void launch_ransac_homography(const int* kp_yx, const int* kp_count, const int* 
 // warp: dst[n](x, y) = src[n % n_src] sampled at hom[n] * (x, y, 1); mode 0 bilinear / 1 nearest, padding 0 zeros / 1 reflection
 void launch_warp_perspective(const float* src, int n_src, int H, int W, const double* hom, int n_out, int Ho, int Wo,
                              int mode, int padding, float* dst, hipStream_t s);
+void launch_cv_warp_linear(const float* src, int n, int H, int W, const double* hom_inv, int border, float* dst,
+                           hipStream_t s);
 void launch_ha_valid_mask(const double* hom_inv, int G, int H, int W, int r, int mask_border, unsigned char* mask,
                           hipStream_t s);
 void launch_ha_begin(const float* pa, const float* pb, long long n, int aggregation, float* prob, float* count,

@@ -8,6 +8,7 @@ import torch
 from torch.utils.data.dataset import Dataset
 
 from ..utils.utils import dict_update
+from .image_pair_dataset import build_sample, check_augmentation_config
 
 
 class SyntheticPairs(Dataset):
@@ -17,13 +18,22 @@ class SyntheticPairs(Dataset):
         'width': 640,
         'seed': 0,
         'single_image': False,
+        'random_pairs': False,
         'return_name': True,
+        # same block as ImagePairDataset (ImagePairDataset.py:26-39); homographic.enable gives every pair a
+        # ground-truth homography + valid mask the way the reference's prediction config does
+        'augmentation': {
+            'photometric': {'enable': False, 'primitives': 'all', 'params': {}, 'random_order': True},
+            'homographic': {'enable': False, 'params': {}, 'border_reflect': True,
+                            'valid_border_margin': 0, 'mask_border': True},
+        },
     }
 
     def __init__(self, config=None):
         self.config = dict_update(copy.deepcopy(self.default_config), config or {})
         if self.config['height'] % 8 or self.config['width'] % 8:
             raise ValueError('SyntheticPairs: height and width must be divisible by 8')
+        check_augmentation_config(self.config, 'SyntheticPairs')
 
     @staticmethod
     def make_pair(seed, index, H, W):
@@ -38,6 +48,8 @@ class SyntheticPairs(Dataset):
             raise IndexError(index)
         H, W = self.config['height'], self.config['width']
         optical, thermal = self.make_pair(self.config['seed'], index, H, W)
+        if self.config['augmentation']['homographic']['enable'] or self.config['random_pairs']:
+            return build_sample(optical[0], thermal[0], None, self.config, self.get_name(index))
         ones = torch.ones((1, H, W), dtype=torch.bool)
         if self.config['single_image']:
             out = {'image': torch.from_numpy(optical), 'valid_mask': ones,
@@ -48,7 +60,7 @@ class SyntheticPairs(Dataset):
                    'thermal': {'image': torch.from_numpy(thermal), 'valid_mask': ones.clone(),
                                'is_optical': torch.BoolTensor([False])}}
         if self.config['return_name']:
-            out['name'] = 'synthetic_%06d' % index
+            out['name'] = self.get_name(index)
         return out
 
     def get_name(self, index):

@@ -16,6 +16,9 @@ golden matrices are committed).  The pixel arithmetic lives in third-party packa
   * opencv-python==4.2.0.34 (requirements.txt:1): `cv2.getPerspectiveTransform` (8x8 system, h33 = 1),
     `cv2.warpPerspective(..., INTER_NEAREST)` (inverts M, cvRound of the source coordinate, constant border 0),
     `cv2.erode` (minimum over the kernel window, border = +inf)         -> `cv2_*`
+  * the dataset's homographic augmentation (multipoint/datasets/augmentation/augmentation.py:25-54):
+    `cv2.warpPerspective(image, M, size, borderMode=...)` with INTER_LINEAR (1/32-pixel fixed-point source
+    coordinates, float32 weight table)                                   -> `cv2_warp_perspective_linear`
 """
 import copy
 from math import pi
@@ -85,6 +88,118 @@ def cv2_warp_perspective_nearest(src, M, dsize):
     out = np.zeros((H, W), dtype=src.dtype)
     out[ok] = src[ry[ok], rx[ok]]
     return out
+
+
+def cv2_invert3(M):
+    """cv::invert of a 3x3 float64 matrix (DECOMP_LU takes the closed-form adjugate path for n <= 3), which
+    cv2.warpPerspective applies to M before mapping destination to source pixels.  Singular -> zeros."""
+    S = np.asarray(M, np.float64).reshape(3, 3)
+    d = (S[0, 0] * (S[1, 1] * S[2, 2] - S[1, 2] * S[2, 1]) - S[0, 1] * (S[1, 0] * S[2, 2] - S[1, 2] * S[2, 0]) +
+         S[0, 2] * (S[1, 0] * S[2, 1] - S[1, 1] * S[2, 0]))
+    if d == 0.0:
+        return np.zeros((3, 3))
+    d = 1.0 / d
+    t = [(S[1, 1] * S[2, 2] - S[1, 2] * S[2, 1]) * d, (S[0, 2] * S[2, 1] - S[0, 1] * S[2, 2]) * d,
+         (S[0, 1] * S[1, 2] - S[0, 2] * S[1, 1]) * d, (S[1, 2] * S[2, 0] - S[1, 0] * S[2, 2]) * d,
+         (S[0, 0] * S[2, 2] - S[0, 2] * S[2, 0]) * d, (S[0, 2] * S[1, 0] - S[0, 0] * S[1, 2]) * d,
+         (S[1, 0] * S[2, 1] - S[1, 1] * S[2, 0]) * d, (S[0, 1] * S[2, 0] - S[0, 0] * S[2, 1]) * d,
+         (S[0, 0] * S[1, 1] - S[0, 1] * S[1, 0]) * d]
+    return np.array(t, np.float64).reshape(3, 3)
+
+
+def _cv2_border_101(p, n):
+    """cv::borderInterpolate(p, n, BORDER_REFLECT_101) on an int64 array."""
+    if n == 1:
+        return np.zeros_like(p)
+    p = p.copy()
+    while True:
+        bad = (p < 0) | (p >= n)
+        if not bad.any():
+            return p
+        p = np.where(p < 0, -p, np.where(p >= n, 2 * n - 2 - p, p))
+
+
+def cv2_warp_perspective_linear(src, M, dsize, border='reflect101'):
+    """cv2.warpPerspective(src, M, dsize, borderMode=BORDER_REFLECT_101 | BORDER_CONSTANT) with the default
+    INTER_LINEAR on a float32 image (call site multipoint/datasets/augmentation/augmentation.py:33-36), restated
+    from OpenCV 4.2's WarpPerspectiveInvoker + remapBilinear<float>:
+
+      M <- invert(M);  destination blocks are bw0 = min(1024 / min(16, H), W) wide; for the block starting at xb,
+      X0 = M00*xb + M01*y + M02 (Y0, W0 alike, float64);  per pixel x1 = x - xb:  W = 32 / (W0 + M20*x1) (0 if the
+      denominator is 0),  X = cvRound(clamp((X0 + M00*x1) * W, INT_MIN, INT_MAX))  -- coordinates in 1/32 px;
+      source pixel (X >> 5, Y >> 5) saturated to int16, table index (Y & 31, X & 31);
+      value = v00*w0 + v01*w1 + v10*w2 + v11*w3 in float32, left to right, weights
+      (1-fy)(1-fx), (1-fy)fx, fy(1-fx), fy*fx computed in float32 from f = idx/32.
+    Only dsize == src size is restated (the block width depends on the destination size)."""
+    src = np.ascontiguousarray(src, dtype=np.float32)
+    H, W = src.shape
+    assert (int(dsize[0]), int(dsize[1])) == (W, H)
+    Mi = cv2_invert3(M)
+    bh0 = min(16, H)
+    bw0 = min(1024 // bh0, W)
+    ys, xs = np.mgrid[0:H, 0:W]
+    xb = ((xs // bw0) * bw0).astype(np.float64)
+    x1 = xs.astype(np.float64) - xb
+    yf = ys.astype(np.float64)
+    X0 = (Mi[0, 0] * xb + Mi[0, 1] * yf) + Mi[0, 2]
+    Y0 = (Mi[1, 0] * xb + Mi[1, 1] * yf) + Mi[1, 2]
+    W0 = (Mi[2, 0] * xb + Mi[2, 1] * yf) + Mi[2, 2]
+    den = W0 + Mi[2, 0] * x1
+    with np.errstate(divide='ignore', invalid='ignore'):
+        w = np.where(den != 0, 32.0 / den, 0.0)
+    with np.errstate(invalid='ignore', over='ignore'):
+        fX = np.clip((X0 + Mi[0, 0] * x1) * w, -2147483648.0, 2147483647.0)
+        fY = np.clip((Y0 + Mi[1, 0] * x1) * w, -2147483648.0, 2147483647.0)
+    X, Y = np.rint(fX).astype(np.int64), np.rint(fY).astype(np.int64)
+    sx, sy = np.clip(X >> 5, -32768, 32767), np.clip(Y >> 5, -32768, 32767)
+    fx = ((X & 31).astype(np.float32) * np.float32(1.0 / 32)).astype(np.float32)
+    fy = ((Y & 31).astype(np.float32) * np.float32(1.0 / 32)).astype(np.float32)
+    ax, ay = (np.float32(1) - fx).astype(np.float32), (np.float32(1) - fy).astype(np.float32)
+    w0, w1, w2, w3 = ay * ax, ay * fx, fy * ax, fy * fx
+
+    def tap(yy, xx):
+        if border == 'constant':
+            ok = (xx >= 0) & (xx < W) & (yy >= 0) & (yy < H)
+            return np.where(ok, src[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)], np.float32(0)).astype(np.float32)
+        assert border == 'reflect101'
+        return src[_cv2_border_101(yy, H), _cv2_border_101(xx, W)]
+
+    out = tap(sy, sx) * w0
+    out = (out + tap(sy, sx + 1) * w1).astype(np.float32)
+    out = (out + tap(sy + 1, sx) * w2).astype(np.float32)
+    out = (out + tap(sy + 1, sx + 1) * w3).astype(np.float32)
+    return out
+
+
+def warp_keypoints_int(keypoints, homography):
+    """warp_keypoints (homographies.py:329-346): cv2.perspectiveTransform in float64, truncated to int."""
+    keypoints = np.asarray(keypoints)
+    if len(keypoints) == 0:
+        return keypoints
+    h = np.asarray(homography, np.float64)
+    xy = keypoints[:, ::-1].astype(np.float64)
+    w = h[2, 0] * xy[:, 0] + h[2, 1] * xy[:, 1] + h[2, 2]
+    with np.errstate(divide='ignore', invalid='ignore'):
+        iw = np.where(w != 0, 1.0 / w, 0.0)
+    x = (h[0, 0] * xy[:, 0] + h[0, 1] * xy[:, 1] + h[0, 2]) * iw
+    y = (h[1, 0] * xy[:, 0] + h[1, 1] * xy[:, 1] + h[1, 2]) * iw
+    return np.stack([y, x], axis=1).astype(int)
+
+
+def homographic_augmentation(image, keypoints, homography, border_reflect=True, valid_border_margin=0,
+                             mask_border=True):
+    """multipoint/datasets/augmentation/augmentation.py:25-54 for an already-sampled homography: warped image,
+    warped + in-frame keypoints (or None), valid mask."""
+    H, W = image.shape
+    warped = cv2_warp_perspective_linear(image, homography, (W, H), 'reflect101' if border_reflect else 'constant')
+    mask = compute_valid_mask((H, W), homography, valid_border_margin * 2, mask_border)
+    pts = None
+    if keypoints is not None:
+        pts = keypoints
+        if keypoints.size > 0:
+            pts = warp_keypoints_int(keypoints, homography)
+            pts = pts[(pts[:, 0] >= 0) & (pts[:, 1] >= 0) & (pts[:, 0] < H) & (pts[:, 1] < W)]
+    return warped, pts, mask
 
 
 def cv2_erode(src, kernel, iterations=1):

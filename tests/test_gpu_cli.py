@@ -24,6 +24,9 @@ def model_dir(tmp_path, oracle):
     cfg = yaml.safe_load(open(os.path.join(ROOT, 'configs', 'config_image_pair_dataset_prediction.yaml')))
     cfg['dataset'].update({'num_samples': 4, 'height': 240, 'width': 320})
     cfg['prediction'].update({'topk': 300, 'batchsize': 2})
+    assert cfg['dataset']['augmentation']['homographic']['enable'] is True        # as the reference's config
+    (tmp_path / 'cfg_aug.yaml').write_text(yaml.safe_dump(cfg))
+    cfg['dataset']['augmentation']['homographic']['enable'] = False               # un-warped pairs: oracle comparison
     (tmp_path / 'cfg.yaml').write_text(yaml.safe_dump(cfg))
     return tmp_path
 
@@ -63,3 +66,20 @@ def test_predict_keypoints_cli(model_dir):
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'predict_keypoints.py'), '-y', str(model_dir / 'cfg.yaml'),
                           '-m', str(model_dir / 'multipoint'), '-v', 'none'], capture_output=True, text=True, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
+
+
+def test_cli_with_homographic_augmentation(model_dir):
+    """The shipped prediction config (augmentation.homographic.enable = true, as the reference's): the evaluation
+    modes get a ground-truth homography and a valid mask from the dataset."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'predict_align_image_pair.py'), '-y', str(model_dir / 'cfg_aug.yaml'),
+                          '-m', str(model_dir / 'multipoint'), '-i', '0', '-p', '-e'],
+                         capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    for line in ('NN-mAP:', 'M-Score:', 'Homography Correctness:', 'Ground Truth Homography:'):
+        assert line in out.stdout
+    gt = out.stdout.split('Ground Truth Homography:')[1]
+    assert '1.' in gt and not all(tok in gt for tok in ('[[1. 0. 0.]', '[0. 1. 0.]'))      # not the identity
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'predict_keypoints.py'), '-y', str(model_dir / 'cfg_aug.yaml'),
+                          '-m', str(model_dir / 'multipoint'), '-e'], capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'Repeatability:' in out.stdout

@@ -174,3 +174,58 @@ def test_cli_surface():
     assert set(cfg['prediction']['matching']) == {'method', 'method_kwargs', 'knn_matches'}
     params = yaml.safe_load(open(os.path.join(ROOT, 'model_weights', 'multipoint', 'params.yaml')))['model']
     assert params['type'] == 'MultiPoint' and params['descriptor_size'] == 64 and params['multispectral'] is False
+
+
+def test_image_pair_dataset_npz_schema(tmp_path):
+    """ImagePairDataset.py:88-243 without augmentation (no GPU needed): crop, label maps, random_pairs, names."""
+    import random
+    import numpy as np
+    from multipoint_amd.datasets import ImagePairDataset
+    rng = np.random.default_rng(0)
+    arrays, labels = {}, {}
+    for i in range(2):
+        arrays['p%d/optical' % i] = rng.random((40, 56), dtype=np.float32)
+        arrays['p%d/thermal' % i] = rng.random((40, 56), dtype=np.float32)
+        arrays['p%d/thermal_raw' % i] = rng.random((40, 56), dtype=np.float32)
+        labels['p%d/keypoints' % i] = np.stack([rng.integers(0, 40, 25), rng.integers(0, 56, 25)], axis=1)
+    fn, kfn = str(tmp_path / 'd.npz'), str(tmp_path / 'k.npz')
+    np.savez(fn, **arrays); np.savez(kfn, **labels)
+    ds = ImagePairDataset({'filename': fn, 'keypoints_filename': kfn, 'single_image': False})
+    s = ds[1]
+    assert len(ds) == 2 and ds.get_name(1) == 'p1' and s['name'] == 'p1' and ds.returns_pair()
+    assert np.array_equal(s['optical']['image'][0].numpy(), arrays['p1/optical'])
+    assert np.array_equal(s['thermal']['image'][0].numpy(), arrays['p1/thermal'])
+    assert s['optical']['valid_mask'].all() and s['optical']['valid_mask'].dtype == torch.bool
+    assert 'homography' not in s['optical']
+    km = np.zeros((40, 56), bool); km[labels['p1/keypoints'][:, 0], labels['p1/keypoints'][:, 1]] = True
+    assert np.array_equal(s['optical']['keypoints'].numpy(), km) and np.array_equal(s['thermal']['keypoints'].numpy(), km)
+    # raw thermal + crop: the same random.randint draws as the reference (ImagePairDataset.py:122-123)
+    dc = ImagePairDataset({'filename': fn, 'keypoints_filename': kfn, 'single_image': False, 'raw_thermal': True,
+                           'height': 24, 'width': 32})
+    random.seed(3); s = dc[0]
+    random.seed(3); i_h = random.randint(0, 16); i_w = random.randint(0, 24)
+    assert np.array_equal(s['thermal']['image'][0].numpy(), arrays['p0/thermal_raw'][i_h:i_h + 24, i_w:i_w + 32])
+    k = labels['p0/keypoints'] - np.array([[i_h, i_w]])
+    k = k[(k[:, 0] >= 0) & (k[:, 0] < 24) & (k[:, 1] >= 0) & (k[:, 1] < 32)]
+    km = np.zeros((24, 32), bool); km[k[:, 0], k[:, 1]] = True
+    assert np.array_equal(s['optical']['keypoints'].numpy(), km)
+    # single image: one spectrum chosen by random.randint(0, 1)
+    d1 = ImagePairDataset({'filename': fn, 'single_image': True})
+    random.seed(5); s = d1[0]
+    random.seed(5); is_optical = bool(random.randint(0, 1))
+    assert bool(s['is_optical'][0]) is is_optical and not d1.returns_pair() and 'keypoints' not in s
+    assert np.array_equal(s['image'][0].numpy(), arrays['p0/optical' if is_optical else 'p0/thermal'])
+    # errors of the reference
+    with pytest.raises(ValueError):
+        ImagePairDataset({'filename': fn, 'single_image': False, 'height': 100})[0]
+    with pytest.raises(IndexError):
+        np.savez(str(tmp_path / 'k2.npz'), **{'p0/keypoints': labels['p0/keypoints']})
+        ImagePairDataset({'filename': fn, 'keypoints_filename': str(tmp_path / 'k2.npz')})
+    with pytest.raises(NotImplementedError):
+        ImagePairDataset({'filename': fn, 'augmentation': {'photometric': {'enable': True}}})
+    # the homographic augmentation computes on the GPU: no CPU fallback
+    if not torch.cuda.is_available():
+        da = ImagePairDataset({'filename': fn, 'single_image': False,
+                               'augmentation': {'homographic': {'enable': True, 'params': {}}}})
+        with pytest.raises((RuntimeError, AssertionError)):
+            da[0]

@@ -106,3 +106,73 @@ def test_host_side_checks_without_gpu():
     assert torch.allclose(k, HA.gaussian_weights(5), atol=1e-8)
     pts = np.array([[0, 0], [5, 7], [-1, 3], [4, 9]])
     assert U.filter_points(pts, (5, 9)).tolist() == [[0, 0]]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# cv2.warpPerspective(INTER_LINEAR) restatement used by the dataset's homographic augmentation (parity unpinned: cv2
+# is absent; these are the defining properties of the published algorithm)
+# ------------------------------------------------------------------------------------------------------------------
+def test_cv2_linear_warp_properties():
+    rng = np.random.default_rng(0)
+    img = rng.random((48, 80), dtype=np.float32)
+    for border in ('reflect101', 'constant'):
+        assert np.array_equal(HA.cv2_warp_perspective_linear(img, np.eye(3), (80, 48), border), img)
+    T = np.array([[1, 0, 3.], [0, 1, -2.], [0, 0, 1]])
+    o = HA.cv2_warp_perspective_linear(img, T, (80, 48), 'constant')
+    assert np.array_equal(o[:46, 3:], img[2:, :77]) and (o[:, :3] == 0).all() and (o[46:] == 0).all()
+    o = HA.cv2_warp_perspective_linear(img, T, (80, 48), 'reflect101')
+    assert np.array_equal(o[:46, 3:], img[2:, :77])
+    assert np.array_equal(o[0, :3], img[2, [3, 2, 1]])                 # gfedcb|abcdefgh|gfedcba
+    assert np.array_equal(o[46:, 3:], img[[46, 45], :77])
+    # half-pixel shift: weights 16/32 exactly -> mean of the two neighbours
+    o = HA.cv2_warp_perspective_linear(img, np.array([[1, 0, .5], [0, 1, 0.], [0, 0, 1]]), (80, 48), 'constant')
+    assert np.array_equal(o[:, 1:], (img[:, 1:] * np.float32(.5) + img[:, :-1] * np.float32(.5)).astype(np.float32))
+    # coordinates are quantised to 1/32 px: shifts of 1/64 px less than a grid point round to it (half to even)
+    a = HA.cv2_warp_perspective_linear(img, np.array([[1, 0, 10 / 32], [0, 1, 0.], [0, 0, 1]]), (80, 48))
+    b = HA.cv2_warp_perspective_linear(img, np.array([[1, 0, 10 / 32 + 1 / 80], [0, 1, 0.], [0, 0, 1]]), (80, 48))
+    assert np.array_equal(a, b)
+    # a constant image stays constant under reflection for any homography (weights sum to 1 up to fp32 rounding)
+    np.random.seed(3)
+    from multipoint_amd.utils.homographies import sample_homography
+    Hm = sample_homography((48, 80), perspective_amplitude_x=0.2, perspective_amplitude_y=0.2)
+    c = HA.cv2_warp_perspective_linear(np.full((48, 80), 0.75, np.float32), Hm, (80, 48), 'reflect101')
+    assert np.abs(c - 0.75).max() <= 2e-7
+    # against float64 bilinear interpolation at the exact coordinates: within the 1/64 px quantisation x gradient
+    ys, xs = np.mgrid[0:48, 0:80].astype(np.float64)
+    smooth = (np.sin(xs / 9.0) + np.cos(ys / 7.0)).astype(np.float32)
+    w = HA.cv2_warp_perspective_linear(smooth, Hm, (80, 48), 'constant')
+    Mi = np.linalg.inv(Hm)
+    den = Mi[2, 0] * xs + Mi[2, 1] * ys + Mi[2, 2]
+    u, v = (Mi[0, 0] * xs + Mi[0, 1] * ys + Mi[0, 2]) / den, (Mi[1, 0] * xs + Mi[1, 1] * ys + Mi[1, 2]) / den
+    inside = (u >= 0) & (u <= 78.9) & (v >= 0) & (v <= 46.9)
+    u0, v0 = np.floor(u).astype(int).clip(0, 78), np.floor(v).astype(int).clip(0, 46)
+    fu, fv = u - u0, v - v0
+    s64 = smooth.astype(np.float64)
+    exact = (s64[v0, u0] * (1 - fu) * (1 - fv) + s64[v0, u0 + 1] * fu * (1 - fv) +
+             s64[v0 + 1, u0] * (1 - fu) * fv + s64[v0 + 1, u0 + 1] * fu * fv)
+    # |gradient| <= 1/9 + 1/7 per pixel, coordinate error <= 1/64 px per axis
+    assert inside.sum() > 500 and np.abs(w - exact)[inside].max() < (1 / 9 + 1 / 7) / 64 + 1e-6
+
+
+def test_cv2_invert3_and_host_mirror():
+    from multipoint_amd.datasets.augmentation import cv_invert3
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        M = rng.normal(size=(3, 3)) + 2 * np.eye(3)
+        assert np.allclose(HA.cv2_invert3(M), np.linalg.inv(M), rtol=1e-10, atol=1e-12)
+        assert np.array_equal(HA.cv2_invert3(M), cv_invert3(M))      # product host code and oracle: same bits
+    assert np.array_equal(HA.cv2_invert3(np.ones((3, 3))), np.zeros((3, 3)))
+    assert np.array_equal(cv_invert3(np.ones((3, 3))), np.zeros((3, 3)))
+
+
+def test_oracle_homographic_augmentation_keypoints():
+    rng = np.random.default_rng(2)
+    img = rng.random((40, 64), dtype=np.float32)
+    kp = np.stack([rng.integers(0, 40, 30), rng.integers(0, 64, 30)], axis=1)
+    T = np.array([[1, 0, 10.], [0, 1, 5.], [0, 0, 1]])
+    w, pts, mask = HA.homographic_augmentation(img, kp, T)
+    keep = (kp[:, 0] + 5 < 40) & (kp[:, 1] + 10 < 64)
+    assert np.array_equal(pts, kp[keep] + np.array([[5, 10]]))
+    assert mask[5:, 10:].all() and not mask[:5].any() and not mask[:, :10].any()
+    w, pts, mask = HA.homographic_augmentation(img, np.zeros((0, 2), int), T)
+    assert pts.shape == (0, 2)
