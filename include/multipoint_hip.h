@@ -165,6 +165,23 @@ int mp_find_homography(mp_handle* h, const int* kp_yx, const int* kp_count, cons
                        double reproj_threshold, int max_iters, unsigned long long seed, double* homography,
                        unsigned char* inlier_mask, int* n_inliers, void* stream);
 
+/* ---- single-image detector metrics: multipoint/utils/evaluation.py:10-97 (predict_keypoints.py:88-104) ----
+ * mp_detector_metrics replaces compute_tp_fp_dist (evaluation.py:56-97) for B heat maps at once:
+ *   prob          fp32 [B][H][W]  detector map after valid mask / NMS (evaluation.py:19-25)
+ *   keypoint_map  uint8 [B][H][W] ground-truth label map (nonzero = keypoint; ImagePairDataset 'keypoints')
+ * predictions = pixels with prob > zero_threshold (reference default 1e-4), ranked by (prob desc, flat index asc);
+ * each prediction names the first ground-truth point in row-major order within distance_thresh (reference default
+ * 2.0; must be < 3) and is a true positive iff it is the best-ranked prediction naming that point (the closed form
+ * of the reference's greedy loop, :84-93).  Outputs, one record per prediction in arbitrary order:
+ *   rec_index int32 [B][H*W] flat pixel index y*W+x;  rec_prob fp32 [B][H*W];
+ *   rec_bits uint32 [B][H*W]: bit (dy+2)*5+(dx+2) set for every ground-truth point at offset (dy, dx) within
+ *             distance_thresh (the entries of `dist[matches]`, :97), bit 31 = true positive;
+ *   rec_count int32 [B] predictions per image;  n_gt int32 [B] ground-truth points per image (`len(kp)`);
+ *   work uint64 [B][H][W] scratch. */
+int mp_detector_metrics(mp_handle* h, const float* prob, const unsigned char* keypoint_map, int B, int H, int W,
+                        float zero_threshold, float distance_thresh, unsigned long long* work, int* rec_index,
+                        float* rec_prob, unsigned int* rec_bits, int* rec_count, int* n_gt, void* stream);
+
 /* ---- homographic adaptation: multipoint/utils/homographies.py:38-189, export_keypoints.py:64-103 ----
  * Homographies are device double [n][9], row-major 3x3 acting on pixel coordinates (x, y, 1).
  *

@@ -54,6 +54,8 @@ SIGNATURES = {
                                  c_void_p, c_void_p]),
     'mp_find_homography': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, ctypes.c_double, c_int,
                                    ctypes.c_ulonglong, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mp_detector_metrics': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mp_warp_perspective': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                     c_void_p, c_void_p]),
     'mp_warp_perspective_cv': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),

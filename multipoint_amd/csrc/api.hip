@@ -1010,6 +1010,29 @@ int mp_find_homography(mp_handle* h, const int* kp_yx, const int* kp_count, cons
     return MP_OK;
 }
 
+int mp_detector_metrics(mp_handle* h, const float* prob, const unsigned char* keypoint_map, int B, int H, int W,
+                        float zero_threshold, float distance_thresh, unsigned long long* work, int* rec_index,
+                        float* rec_prob, unsigned int* rec_bits, int* rec_count, int* n_gt, void* stream)
+{
+    if (!h) return MP_EINVAL;
+    if (!prob || !keypoint_map || !work || !rec_index || !rec_prob || !rec_bits || !rec_count || !n_gt)
+        return fail(h, MP_EINVAL, "mp_detector_metrics: NULL tensor");
+    if (B <= 0 || B > 65535 || H <= 0 || W <= 0 || (long long)H * W > 0x7fffffffLL)
+        return fail(h, MP_EINVAL, "mp_detector_metrics: need 0 < B <= 65535, H, W > 0");
+    if (!(distance_thresh >= 0.f) || !(distance_thresh < 3.f))
+        return fail(h, MP_EINVAL, "mp_detector_metrics: distance_thresh must be in [0, 3) (5 x 5 window)");
+    if (!(zero_threshold >= 0.f)) return fail(h, MP_EINVAL, "mp_detector_metrics: zero_threshold must be >= 0");
+    MP_HIP(hipSetDevice(h->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MP_HIP(hipMemsetAsync(work, 0, sizeof(unsigned long long) * (size_t)B * H * W, s));
+    MP_HIP(hipMemsetAsync(rec_count, 0, sizeof(int) * (size_t)B, s));
+    MP_HIP(hipMemsetAsync(n_gt, 0, sizeof(int) * (size_t)B, s));
+    launch_detector_metrics(prob, keypoint_map, B, H, W, zero_threshold, distance_thresh, work, rec_index, rec_prob,
+                            rec_bits, rec_count, n_gt, s);
+    MP_HIP(hipGetLastError());
+    return MP_OK;
+}
+
 int mp_warp_perspective(mp_handle* h, const float* src, int n_src, int H, int W, const double* dst_to_src, int n_out,
                         int Ho, int Wo, int mode, int padding, float* dst, void* stream)
 {

@@ -177,6 +177,7 @@ constexpr int VT = 32, VR_MAX = 16, VL = VT + 2 * VR_MAX;
 __global__ __launch_bounds__(256) void valid_mask_kernel(const double* __restrict__ hom_inv, int H, int W, int r,
                                                          int mask_border, unsigned char* __restrict__ mask)
 {
+#pragma clang fp contract(off)    // OpenCV's scalar code rounds every product and sum separately
     __shared__ unsigned char raw[VL * VL];
     __shared__ unsigned char rowmin[VL * VT];
     const int g = blockIdx.z;

@@ -156,6 +156,12 @@ void launch_ransac_homography(const int* kp_yx, const int* kp_count, const int* 
                               unsigned long long seed, unsigned long long* best, double* H_out, unsigned char* mask,
                               int* n_inliers, hipStream_t s);
 
+// single-image detector metrics (detector_metrics.hip; evaluation.py:56-97): best [B][H][W] scratch, rec_count / n_gt [B]
+// (all three pre-set to 0), records [B][H*W]
+void launch_detector_metrics(const float* prob, const unsigned char* gt, int B, int H, int W, float zero_thr,
+                             float distance_thr, unsigned long long* best, int* rec_index, float* rec_prob,
+                             unsigned* rec_bits, int* rec_count, int* n_gt, hipStream_t s);
+
 // homographic adaptation (homog_adapt.hip; reference multipoint/utils/homographies.py:38-189, 361-433).
 // hom arrays are device double [n][9], row-major 3x3 acting on pixel (x, y, 1).
 // warp: dst[n](x, y) = src[n % n_src] sampled at hom[n] * (x, y, 1); mode 0 bilinear / 1 nearest, padding 0 zeros / 1 reflection

@@ -17,6 +17,7 @@ __global__ __launch_bounds__(256) void warp_kernel(const int* __restrict__ kp_yx
                                                    const double* __restrict__ hom, int K, int H, int W,
                                                    double* __restrict__ warped, int* __restrict__ metrics)
 {
+#pragma clang fp contract(off)    // cv2.perspectiveTransform rounds every product and sum separately
     const int b = blockIdx.y;                    // image slot: 2p = optical, 2p+1 = thermal
     const int k = blockIdx.x * 256 + threadIdx.x;
     const int n = min(kp_count[b], K);
@@ -24,10 +25,10 @@ __global__ __launch_bounds__(256) void warp_kernel(const int* __restrict__ kp_yx
     if (k < n) {
         const double* m = hom + (size_t)b * 9;
         const double y = (double)kp_yx[((size_t)b * K + k) * 2], x = (double)kp_yx[((size_t)b * K + k) * 2 + 1];
-        double w = __dadd_rn(__dadd_rn(__dmul_rn(x, m[6]), __dmul_rn(y, m[7])), m[8]);
+        double w = (((x * m[6]) + (y * m[7])) + m[8]);
         w = (fabs(w) > 2.220446049250313e-16) ? 1.0 / w : 0.0;
-        const double xo = __dmul_rn(__dadd_rn(__dadd_rn(__dmul_rn(x, m[0]), __dmul_rn(y, m[1])), m[2]), w);
-        const double yo = __dmul_rn(__dadd_rn(__dadd_rn(__dmul_rn(x, m[3]), __dmul_rn(y, m[4])), m[5]), w);
+        const double xo = ((((x * m[0]) + (y * m[1])) + m[2]) * w);
+        const double yo = ((((x * m[3]) + (y * m[4])) + m[5]) * w);
         warped[((size_t)b * K + k) * 2] = yo;
         warped[((size_t)b * K + k) * 2 + 1] = xo;
         inside = (yo >= 0.0) & (xo >= 0.0) & (yo < (double)H) & (xo < (double)W);
@@ -101,11 +102,12 @@ __global__ __launch_bounds__(256) void invert_kernel(const int* __restrict__ mat
 // (frame -> world by inv(h_own), world -> other frame by h_other), then filter_points keeps in-image points.
 __device__ __forceinline__ void warp_trunc(const double* m, long long& y, long long& x)
 {
+#pragma clang fp contract(off)
     const double xd = (double)x, yd = (double)y;
-    double w = __dadd_rn(__dadd_rn(__dmul_rn(xd, m[6]), __dmul_rn(yd, m[7])), m[8]);
+    double w = (((xd * m[6]) + (yd * m[7])) + m[8]);
     w = (fabs(w) > 2.220446049250313e-16) ? 1.0 / w : 0.0;
-    const double xo = __dmul_rn(__dadd_rn(__dadd_rn(__dmul_rn(xd, m[0]), __dmul_rn(yd, m[1])), m[2]), w);
-    const double yo = __dmul_rn(__dadd_rn(__dadd_rn(__dmul_rn(xd, m[3]), __dmul_rn(yd, m[4])), m[5]), w);
+    const double xo = ((((xd * m[0]) + (yd * m[1])) + m[2]) * w);
+    const double yo = ((((xd * m[3]) + (yd * m[4])) + m[5]) * w);
     x = (long long)xo; y = (long long)yo;
 }
 
@@ -113,6 +115,7 @@ __global__ __launch_bounds__(256) void rep_warp_kernel(const int* __restrict__ k
                                                        const double* __restrict__ hom, int K, int H, int W,
                                                        long long* __restrict__ warped, int* __restrict__ out)
 {
+#pragma clang fp contract(off)    // cv2.perspectiveTransform rounds every product and sum separately
     const int b = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
     const int n = min(kp_count[b], K);
     int inside = 0;

@@ -246,3 +246,92 @@ def compute_repeatability_multispectral(net, dataloader, device, config, distanc
                 if verbose:
                     print('repeatability: %f' % repeatability[-1])
     return np.mean(repeatability), repeatability, n_kp_optical, n_kp_thermal
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# single-image detector metrics (evaluation.py:10-103; predict_keypoints.py:88-104)
+# ----------------------------------------------------------------------------------------------------------------------
+_WINDOW_DIST = np.sqrt(np.add.outer((np.arange(5) - 2) ** 2, (np.arange(5) - 2) ** 2).astype(np.float32)).reshape(-1)
+
+
+def detector_records(prob, keypoint_map, zero_threshold=1e-4, distance_thresh=2.0):
+    """GPU arithmetic of compute_tp_fp_dist for a batch: prob (B,H,W) / (B,1,H,W) fp32, keypoint_map (B,H,W) bool.
+    Returns per image the tuple of the reference (tp, fp, prob, n_gt, dist) with the predictions ranked by
+    (prob descending, row-major index ascending)."""
+    if prob.dim() == 4:
+        prob = prob[:, 0]
+    if prob.dim() != 3 or tuple(keypoint_map.shape) != tuple(prob.shape):
+        raise ValueError('detector_records: prob and keypoint_map must both be (B,H,W); got {} and {}'.format(
+            tuple(prob.shape), tuple(keypoint_map.shape)))
+    dev = _lib.require_cuda(prob.device if prob.device.type == 'cuda' else None)
+    p = prob.to(dev, torch.float32).contiguous()
+    g = keypoint_map.to(dev).ne(0).to(torch.uint8).contiguous()
+    B, H, W = p.shape
+    work = torch.empty((B, H * W), dtype=torch.int64, device=dev)
+    rec_index = torch.empty((B, H * W), dtype=torch.int32, device=dev)
+    rec_prob = torch.empty((B, H * W), dtype=torch.float32, device=dev)
+    rec_bits = torch.empty((B, H * W), dtype=torch.int32, device=dev)
+    rec_count = torch.empty((B,), dtype=torch.int32, device=dev)
+    n_gt = torch.empty((B,), dtype=torch.int32, device=dev)
+    h = _lib.get_handle(dev)
+    with torch.cuda.device(dev):
+        h.check(h.lib.mp_detector_metrics(h.ptr, _lib.ptr(p), _lib.ptr(g), B, H, W, float(zero_threshold),
+                                          float(distance_thresh), _lib.ptr(work), _lib.ptr(rec_index),
+                                          _lib.ptr(rec_prob), _lib.ptr(rec_bits), _lib.ptr(rec_count), _lib.ptr(n_gt),
+                                          _lib.stream_ptr(dev)))
+    cnt = rec_count.cpu().numpy()
+    ngt = n_gt.cpu().numpy()
+    nmax = int(cnt.max()) if B else 0
+    idx = rec_index[:, :nmax].cpu().numpy()
+    prb = rec_prob[:, :nmax].cpu().numpy()
+    bits = rec_bits[:, :nmax].cpu().numpy().view(np.uint32)
+    out = []
+    for b in range(B):
+        n = int(cnt[b])
+        order = np.lexsort((idx[b, :n], -prb[b, :n].astype(np.float64)))        # prob desc, then index asc
+        bb = bits[b, :n][order]
+        tp = (bb >> np.uint32(31)).astype(bool)
+        m = ((bb[:, None] >> np.arange(25, dtype=np.uint32)[None]) & np.uint32(1)).astype(bool)
+        dist = np.broadcast_to(_WINDOW_DIST[None], m.shape)[m]                   # (prediction, window row-major) order
+        out.append((tp, np.logical_not(tp), prb[b, :n][order], int(ngt[b]), dist.astype(np.float32)))
+    return out
+
+
+def compute_tp_fp_dist(prob, keypoints, zero_threshold=1e-4, distance_thresh=2.0):
+    """evaluation.py:56-97 for one (H,W) heat map; `keypoints` is the (H,W) label map or an (N,2) (y,x) list."""
+    prob = torch.as_tensor(prob)
+    keypoints = torch.as_tensor(keypoints)
+    if prob.shape != keypoints.shape:
+        kk = keypoints.to(torch.int64).cpu()
+        km = torch.zeros(tuple(prob.shape), dtype=torch.bool)
+        km[kk[:, 0], kk[:, 1]] = True
+        keypoints = km
+    return detector_records(prob[None], keypoints[None], zero_threshold, distance_thresh)[0]
+
+
+def compute_detector_metrics(net, dataloader, device, config):
+    """Precision, recall and localisation error of the detector on a single-image loader with 'keypoints' labels;
+    same signature and return value as the reference (evaluation.py:10-54): (precision, recall, prob, dist)."""
+    from .utils import box_nms, data_to_device
+    tp, fp, prob, n_gt, dist = [], [], [], 0, []
+    for data in dataloader:
+        data = data_to_device(data, device)
+        out = net(data)
+        if config['nms'] > 0:
+            pred = box_nms(out['prob'], config['nms'], config['detection_threshold'], valid_mask=data['valid_mask'])
+        else:
+            pred = out['prob'] * data['valid_mask'].to(out['prob'].dtype)
+        for item in detector_records(pred, data['keypoints']):
+            tp.append(item[0]); fp.append(item[1]); prob.append(item[2]); n_gt += item[3]; dist.append(item[4])
+    tp, fp = np.concatenate(tp), np.concatenate(fp)
+    prob, dist = np.concatenate(prob), np.concatenate(dist)
+    # evaluation.py:38-54
+    sort_idx = np.argsort(prob)[::-1]
+    tp, fp, prob = tp[sort_idx], fp[sort_idx], prob[sort_idx]
+    tp_cum, fp_cum = np.cumsum(tp), np.cumsum(fp)
+    recall = div0(tp_cum, n_gt)
+    precision = div0(tp_cum, tp_cum + fp_cum)
+    recall = np.concatenate([[0], recall, [1]])
+    precision = np.concatenate([[0], precision, [0]])
+    precision = np.maximum.accumulate(precision[::-1])[::-1]
+    return precision, recall, prob, dist

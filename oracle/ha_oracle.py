@@ -41,6 +41,15 @@ DEFAULT_CONFIG = {
 }
 
 
+# augmentation.homographic block of the reference's configs/config_image_pair_dataset_prediction.yaml:20-36
+PREDICTION_AUGMENTATION = {
+    'enable': True,
+    'params': {'translation': True, 'rotation': True, 'scaling': True, 'perspective': True,
+               'scaling_amplitude': 0.2, 'perspective_amplitude_x': 0.2, 'perspective_amplitude_y': 0.2,
+               'patch_ratio': 0.85, 'max_angle': 1.57, 'allow_artifacts': True, 'translation_overflow': 0.05},
+    'valid_border_margin': 0, 'border_reflect': True, 'mask_border': True}
+
+
 def full_config(cfg=None):
     out = copy.deepcopy(DEFAULT_CONFIG)
     for k, v in (cfg or {}).items():

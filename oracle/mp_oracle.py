@@ -623,6 +623,54 @@ def repeatability_pair(kp_optical, kp_thermal, h_optical, h_thermal, H, W, dista
 _M64 = (1 << 64) - 1
 
 
+def compute_tp_fp_dist(prob, keypoint_map, zero_threshold=1e-4, distance_thresh=2.0):
+    """compute_tp_fp_dist (multipoint/utils/evaluation.py:56-97) for one (H,W) map, restated with numpy and the
+    reference's sequential loop: predictions = pixels with prob > zero_threshold ranked by prob descending (ties:
+    row-major index ascending -- torch.sort leaves them open), ground truth = nonzero label pixels in row-major order,
+    matches = float32 distance <= distance_thresh; each ranked prediction takes the FIRST ground-truth point it
+    matches and is a true positive iff that point is still unmatched (:84-93).
+    Returns (tp, fp, prob_sorted, n_gt, dist[matches])."""
+    prob = np.asarray(prob, np.float32)
+    kp = np.argwhere(np.asarray(keypoint_map) != 0)                                   # :65
+    mask = np.argwhere(prob > np.float32(zero_threshold))                             # :68
+    p = prob[mask[:, 0], mask[:, 1]]
+    order = np.lexsort((np.arange(len(p)), -p.astype(np.float64)))                    # :71, stated tie-break
+    p, pred = p[order], mask[order]
+    diff = (pred[:, None, :] - kp[None, :, :]).astype(np.float32)                     # :80
+    dist = np.sqrt((diff * diff).sum(-1, dtype=np.float32)).astype(np.float32)        # :81
+    matches = dist <= np.float32(distance_thresh)                                     # :82
+    tp = []
+    matched = np.zeros(len(kp), bool)
+    for m in matches:                                                                 # :86-93
+        if m.any() and not matched.all():
+            g = int(np.argmax(m))
+            tp.append(not matched[g])
+            matched[g] = True
+        else:
+            tp.append(False)
+    tp = np.array(tp, bool)
+    return tp, np.logical_not(tp), p, len(kp), dist[matches]
+
+
+def detector_precision_recall(tp, fp, prob, n_gt):
+    """Tail of compute_detector_metrics (evaluation.py:33-54) on the concatenated per-image lists."""
+    sort_idx = np.argsort(prob)[::-1]
+    tp, fp, prob = tp[sort_idx], fp[sort_idx], prob[sort_idx]
+    tp_cum, fp_cum = np.cumsum(tp), np.cumsum(fp)
+    with np.errstate(divide='ignore', invalid='ignore'):
+        def div0(a, b):
+            c = np.true_divide(a, b)
+            idx = ~np.isfinite(c)
+            c[idx] = np.where(a[idx] == 0, 1, 0)
+            return c
+        recall = div0(tp_cum, n_gt)
+        precision = div0(tp_cum, tp_cum + fp_cum)
+    recall = np.concatenate([[0], recall, [1]])
+    precision = np.concatenate([[0], precision, [0]])
+    precision = np.maximum.accumulate(precision[::-1])[::-1]
+    return precision, recall, prob
+
+
 def _mix64(z):
     z = (z + 0x9e3779b97f4a7c15) & _M64
     z = ((z ^ (z >> 30)) * 0xbf58476d1ce4e5b9) & _M64

@@ -2,9 +2,9 @@
 """Drop-in for the hot path of the reference's predict_keypoints.py (flags -y -m -v -i -r -p -e -b -t
 -mask -s): forward + box_nms (without the valid-mask multiply, reference predict_keypoints.py:136-156)
 for a single sample or a batch (-b).  -e computes the keypoint repeatability of an image-pair dataset like the
-reference (utils.compute_repeatability_multispectral; per-sample arithmetic on the GPU); the single-image detector
-mAP (compute_detector_metrics, needs labelled keypoints) is outside the accelerated path.  Drawing (-p) is replaced
-by a text summary."""
+reference (utils.compute_repeatability_multispectral) and, for a single-image dataset with 'keypoints' labels, the
+detector precision / recall / mAP (utils.compute_detector_metrics) -- per-sample arithmetic on the GPU in both
+cases.  Drawing (-p) is replaced by a text summary."""
 import argparse
 import os
 import time
@@ -53,17 +53,20 @@ def main(argv=None):
             # reference predict_keypoints.py:60-107
             import random
             random.seed(args.seed); np.random.seed(args.seed); torch.manual_seed(args.seed)
-            if not dataset.returns_pair():
-                raise NotImplementedError('single-image detector mAP (compute_detector_metrics) is outside the '
-                                          'accelerated hot path')
-            repeatability_mean, repeatability, n_kp_optical, n_kp_thermal = utils.compute_repeatability_multispectral(
-                net, loader_dataset, device, config, distance_thresh=args.threshold)
-            print('Repeatability: {}'.format(repeatability_mean))
-            print('Number of optical keypoints: {}'.format(np.mean(n_kp_optical)))
-            print('Number of thermal keypoints: {}'.format(np.mean(n_kp_thermal)))
-            results = {'repeatability_mean': repeatability_mean, 'repeatability': repeatability,
-                       'n_kp_optical': n_kp_optical, 'n_kp_thermal': n_kp_thermal,
-                       'distance_threshold': args.threshold, 'config': config}
+            if dataset.returns_pair():
+                repeatability_mean, repeatability, n_kp_optical, n_kp_thermal = utils.compute_repeatability_multispectral(
+                    net, loader_dataset, device, config, distance_thresh=args.threshold)
+                print('Repeatability: {}'.format(repeatability_mean))
+                print('Number of optical keypoints: {}'.format(np.mean(n_kp_optical)))
+                print('Number of thermal keypoints: {}'.format(np.mean(n_kp_thermal)))
+                results = {'repeatability_mean': repeatability_mean, 'repeatability': repeatability,
+                           'n_kp_optical': n_kp_optical, 'n_kp_thermal': n_kp_thermal,
+                           'distance_threshold': args.threshold, 'config': config}
+            else:
+                precision, recall, prob, dist = utils.compute_detector_metrics(net, loader_dataset, device, pred)
+                results = {'precision': precision, 'recall': recall, 'prob': prob, 'dist': dist, 'config': config}
+                print('Average distance error for true positives: {}'.format(dist.mean()))
+                print('mAP: {}'.format(utils.compute_mAP(precision, recall)))
             target_dir = os.path.join(args.model_dir, 'detector_evaluation')
             os.makedirs(target_dir, exist_ok=True)
             np.save(os.path.join(target_dir, os.path.split(args.model_dir.strip('/'))[-1] + '_' +

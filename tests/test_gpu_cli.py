@@ -83,3 +83,27 @@ def test_cli_with_homographic_augmentation(model_dir):
                           '-m', str(model_dir / 'multipoint'), '-e'], capture_output=True, text=True, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     assert 'Repeatability:' in out.stdout
+
+
+def test_predict_keypoints_single_image_evaluation(model_dir, tmp_path):
+    """-e on a single-image dataset with labels: detector mAP (reference predict_keypoints.py:88-104) over an .npz
+    archive in the ImagePairDataset layout, homographic augmentation on."""
+    rng = np.random.default_rng(0)
+    arrays, labels = {}, {}
+    for i in range(3):
+        arrays['s%d/optical' % i] = rng.random((120, 160), dtype=np.float32)
+        arrays['s%d/thermal' % i] = rng.random((120, 160), dtype=np.float32)
+        labels['s%d/keypoints' % i] = np.stack([rng.integers(0, 120, 400), rng.integers(0, 160, 400)], axis=1)
+    np.savez(str(tmp_path / 'd.npz'), **arrays); np.savez(str(tmp_path / 'k.npz'), **labels)
+    cfg = yaml.safe_load(open(model_dir / 'cfg_aug.yaml'))
+    cfg['dataset'] = {'type': 'ImagePairDataset', 'filename': str(tmp_path / 'd.npz'),
+                      'keypoints_filename': str(tmp_path / 'k.npz'), 'single_image': True,
+                      'augmentation': cfg['dataset']['augmentation']}
+    (tmp_path / 'cfg_single.yaml').write_text(yaml.safe_dump(cfg))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'predict_keypoints.py'), '-y', str(tmp_path / 'cfg_single.yaml'),
+                          '-m', str(model_dir / 'multipoint'), '-e'], capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'mAP:' in out.stdout and 'Average distance error for true positives:' in out.stdout
+    m = float(out.stdout.split('mAP:')[1].split()[0])
+    assert 0.0 <= m <= 1.0
+    assert 'image keypoints per image:' in out.stdout

@@ -15,12 +15,7 @@ from oracle import ha_oracle as HA
 
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
-# augmentation.homographic block of configs/config_image_pair_dataset_prediction.yaml (reference :20-36)
-HCFG = {'enable': True,
-        'params': {'translation': True, 'rotation': True, 'scaling': True, 'perspective': True,
-                   'scaling_amplitude': 0.2, 'perspective_amplitude_x': 0.2, 'perspective_amplitude_y': 0.2,
-                   'patch_ratio': 0.85, 'max_angle': 1.57, 'allow_artifacts': True, 'translation_overflow': 0.05},
-        'valid_border_margin': 0, 'border_reflect': True, 'mask_border': True}
+HCFG = HA.PREDICTION_AUGMENTATION          # the reference's prediction-config augmentation block
 
 
 def _homs(seed, n, H, W):
@@ -145,3 +140,41 @@ def test_descriptor_metrics_over_augmented_pairs():
     res = U.compute_descriptor_metrics(net, loader, DEV, pred, 4, 3)
     assert set(res) >= {'nn_map', 'm_score', 'h_correctness'}
     assert np.isfinite(res['nn_map']) and np.isfinite(res['m_score'])
+
+
+def test_dataset_against_reference_golden(tmp_path, golden_dir):
+    """The product's ImagePairDataset (GPU warp + mask) vs the samples the REFERENCE's ImagePairDataset emitted for the
+    same arrays and seeds (tests/golden/dataset_augmentation.npz, make_golden_eval.py): schema, which image is
+    warped, homography, warped image, valid mask and label maps all equal."""
+    from multipoint_amd.datasets import ImagePairDataset
+    g = np.load(os.path.join(golden_dir, 'dataset_augmentation.npz'))
+    arrays, labels = {}, {}
+    for i in range(3):
+        arrays['s%d/optical' % i], arrays['s%d/thermal' % i] = g['in_optical_%d' % i], g['in_thermal_%d' % i]
+        labels['s%d/keypoints' % i] = g['in_keypoints_%d' % i]
+    fn, kfn = str(tmp_path / 'pairs.npz'), str(tmp_path / 'labels.npz')
+    np.savez(fn, **arrays); np.savez(kfn, **labels)
+    hcfg = {k: v for k, v in HCFG.items() if k != 'mask_border'}           # as in the reference's yaml (default true)
+    pair = ImagePairDataset({'filename': fn, 'keypoints_filename': kfn, 'single_image': False,
+                             'augmentation': {'homographic': hcfg}})
+    for i in range(3):
+        random.seed(302 + i); np.random.seed(400 + i)
+        s = pair[i]
+        assert s['name'] == 's%d' % i and set(s) == {'optical', 'thermal', 'name'}
+        for side in ('optical', 'thermal'):
+            assert set(s[side]) == {'image', 'valid_mask', 'keypoints', 'homography', 'is_optical'}
+            for k in ('image', 'valid_mask', 'keypoints', 'homography', 'is_optical'):
+                want = g['pair_%d_%s_%s' % (i, side, k)]
+                got = s[side][k].numpy()
+                assert got.dtype == want.dtype and got.shape == want.shape, (i, side, k, got.dtype, want.dtype)
+                assert np.array_equal(got, want), (i, side, k)
+    single = ImagePairDataset({'filename': fn, 'keypoints_filename': kfn, 'single_image': True,
+                               'augmentation': {'homographic': hcfg}})
+    for i in range(3):
+        random.seed(502 + i); np.random.seed(600 + i)
+        s = single[i]
+        assert set(s) == {'image', 'valid_mask', 'keypoints', 'is_optical', 'name'}
+        for k in ('image', 'valid_mask', 'keypoints', 'is_optical'):
+            want = g['single_%d_%s' % (i, k)]
+            got = s[k].numpy()
+            assert got.dtype == want.dtype and np.array_equal(got, want), (i, k)

@@ -1,10 +1,13 @@
 """GPU (MI355X): mp_pair_metrics (the per-sample arithmetic of utils.compute_descriptor_metrics, reference
 multipoint/utils/evaluation.py:259,287-328) against the oracle's restatement -- integer results, bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
 
 
 def _random_homography(rng, H, W, strength):
@@ -185,3 +188,105 @@ def test_find_homography_degenerate_inputs():
     assert nin.tolist() == [0, 0] and not mask.any() and (Hm == 0).all()
     with pytest.raises(ValueError):
         U.find_homography(res, -1.0)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# single-image detector metrics (mp_detector_metrics; multipoint/utils/evaluation.py:10-97)
+# ----------------------------------------------------------------------------------------------------------------------
+def _check_records(got, want):
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert np.array_equal(got[2], want[2]) and got[3] == want[3]
+    assert got[4].dtype == np.float32 and np.array_equal(got[4], want[4])
+
+
+def test_detector_metrics_golden(golden_dir):
+    """GPU vs the outputs of the reference's compute_tp_fp_dist (tests/golden/detector_metrics.npz)."""
+    import multipoint_amd.utils as U
+    g = np.load(os.path.join(golden_dir, 'detector_metrics.npz'))
+    prob = torch.from_numpy(np.stack([g['prob_%d' % i] for i in range(4)])).to(DEV)
+    km = torch.from_numpy(np.stack([g['keypoints_%d' % i] for i in range(4)])).to(DEV)
+    recs = U.detector_records(prob, km)
+    for i, r in enumerate(recs):
+        _check_records(r, (g['tp_%d' % i], ~g['tp_%d' % i], g['sorted_prob_%d' % i], int(g['n_gt_%d' % i]), g['dist_%d' % i]))
+    one = U.compute_tp_fp_dist(prob[1].cpu(), km[1].cpu())
+    _check_records(one, recs[1])
+    lst = U.compute_tp_fp_dist(prob[1], torch.nonzero(km[1]))                 # (N,2) label list instead of a map
+    _check_records(lst, recs[1])
+
+
+@pytest.mark.parametrize('H,W,density', [(37, 53, 0.05), (120, 160, 0.3), (64, 64, 1.0)])
+def test_detector_metrics_vs_oracle(oracle, H, W, density):
+    """random maps incl. tied scores, dense predictions (nms = 0 case), clustered labels, empty images."""
+    import multipoint_amd.utils as U
+    rng = np.random.default_rng(H * W)
+    B = 4
+    prob = (rng.random((B, H, W)) * (rng.random((B, H, W)) < density)).astype(np.float32)
+    prob[1] = np.round(prob[1] * 8) / 8                                       # many exact ties
+    prob[3] = 0                                                               # no prediction at all
+    km = rng.random((B, H, W)) < 0.02
+    km[0, 10:14, 10:14] = True                                                # clustered labels
+    km[2] = False                                                             # no label at all
+    for thr in (2.0, 1.0, 1.5, 0.0, 2.9):
+        recs = U.detector_records(torch.from_numpy(prob).to(DEV), torch.from_numpy(km).to(DEV), 1e-4, thr)
+        for b in range(B):
+            _check_records(recs[b], oracle.compute_tp_fp_dist(prob[b], km[b], 1e-4, thr))
+    assert recs[3][0].size == 0 and recs[2][0].sum() == 0
+    with pytest.raises(ValueError):
+        U.detector_records(torch.from_numpy(prob).to(DEV), torch.from_numpy(km).to(DEV), 1e-4, 3.0)
+    with pytest.raises(ValueError):
+        U.detector_records(torch.from_numpy(prob).to(DEV), torch.from_numpy(km[:, :-1]).to(DEV))
+
+
+def test_detector_metrics_full_size_properties():
+    """BASELINE size (64 maps 480x640), dense predictions: every label is claimed by at most one true positive, a
+    true positive exists exactly for the labels with a prediction in range, ranks are non-increasing."""
+    import multipoint_amd.utils as U
+    g = torch.Generator(device='cpu').manual_seed(5)
+    B, H, W = 64, 480, 640
+    prob = torch.rand((B, H, W), generator=g) * (torch.rand((B, H, W), generator=g) < 0.02)
+    km = torch.rand((B, H, W), generator=g) < 0.004
+    recs = U.detector_records(prob.to(DEV), km.to(DEV))
+    tot_tp = 0
+    for b in (0, 17, 63):
+        tp, fp, p, n_gt, dist = recs[b]
+        assert n_gt == int(km[b].sum()) and len(p) == int((prob[b] > 1e-4).sum())
+        assert np.all(np.diff(p) <= 0) and np.array_equal(fp, ~tp)
+        # labels with at least one prediction within 2 px whose FIRST label is that label
+        assert tp.sum() <= n_gt and set(np.unique(dist)) <= {np.float32(0), np.float32(1), np.float32(2 ** .5), np.float32(2)}
+        tot_tp += tp.sum()
+    assert tot_tp > 0
+
+
+def test_compute_detector_metrics_driver(oracle):
+    """The driver (forward + valid mask + NMS on the GPU, mp_detector_metrics, numpy tail) vs the oracle pipeline."""
+    import multipoint_amd.models as models
+    import multipoint_amd.utils as U
+    cfg = dict(oracle.SHIPPED_MODEL_CONFIG)
+    sd = oracle.make_weights(31, cfg)
+    net = models.MultiPoint(cfg); net.load_state_dict(sd); net.to(DEV); net.eval()
+    rng = np.random.default_rng(9)
+    H, W = 64, 96
+    batches, mine = [], []
+    for b in range(2):
+        img = oracle.make_images(50 + b, 2, H, W)
+        vm = torch.ones((2, 1, H, W), dtype=torch.bool); vm[:, :, :6] = False
+        pn = U.box_nms(net({'image': img.to(DEV)})['prob'], 4, 0.015, valid_mask=vm.to(DEV)).cpu().numpy()
+        km = torch.zeros((2, H, W), dtype=torch.bool)
+        for i in range(2):
+            kept = np.argwhere(pn[i, 0] > 0.015)
+            sel = kept[rng.choice(len(kept), len(kept) // 2, replace=False)]
+            sel = np.clip(sel + rng.integers(-2, 3, sel.shape), 0, [H - 1, W - 1])
+            km[i, sel[:, 0], sel[:, 1]] = True
+            mine.append(oracle.compute_tp_fp_dist(pn[i, 0], km[i].numpy()))
+        batches.append({'image': img, 'valid_mask': vm, 'keypoints': km, 'is_optical': torch.ones(2, 1, dtype=torch.bool)})
+    precision, recall, prob, dist = U.compute_detector_metrics(net, batches, DEV, {'nms': 4, 'detection_threshold': 0.015})
+    tp = np.concatenate([m[0] for m in mine]); fp = np.concatenate([m[1] for m in mine])
+    p2, r2, prob2 = oracle.detector_precision_recall(tp, fp, np.concatenate([m[2] for m in mine]).astype(np.float64),
+                                                     sum(m[3] for m in mine))
+    assert 0 < tp.sum() < len(tp)
+    assert np.array_equal(prob, prob2) and np.array_equal(precision, p2) and np.array_equal(recall, r2)
+    assert np.array_equal(dist, np.concatenate([m[4] for m in mine]))
+    assert 0.0 < U.compute_mAP(precision, recall) <= 1.0
+    # nms = 0: the raw map times the valid mask
+    pr, rc, _, _ = U.compute_detector_metrics(net, batches[:1], DEV, {'nms': 0, 'detection_threshold': 0.015})
+    assert len(pr) == len(rc) and pr[0] >= pr[-1]

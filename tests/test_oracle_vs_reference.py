@@ -325,3 +325,75 @@ def test_oracle_homographic_adaptation_matches_reference_driver(oracle, ref, ref
         assert (got - want).abs().max().item() <= 1e-6, hc
     RH.homography_adaptation_default_config.clear()
     RH.homography_adaptation_default_config.update(pristine)
+
+
+def test_detector_metrics_against_reference(oracle, ref, monkeypatch):
+    """The reference's compute_tp_fp_dist (evaluation.py:56-97, pure torch/numpy: runs here unmodified) and its
+    compute_detector_metrics driver (:10-54, torchvision nms served by the oracle) against the oracle's restatement:
+    pins the true-positive rule, n_gt, the distance list and the precision/recall bookkeeping."""
+    models, utils = ref
+    import multipoint.utils.evaluation as ev
+    import multipoint.utils.utils as ru
+    rng = np.random.default_rng(3)
+    for case in range(6):
+        H, W = 40, 56
+        prob = np.zeros((H, W), np.float32)
+        n = [60, 200, 5, 0, 400, 1][case]
+        idx = rng.choice(H * W, n, replace=False)
+        prob.flat[idx] = rng.permutation(n).astype(np.float32) / max(n, 1) * 0.9 + 0.01        # distinct scores
+        km = np.zeros((H, W), bool)
+        g = [40, 150, 0, 10, 300, 1][case]
+        gi = np.concatenate([rng.choice(idx, min(g // 2, n), replace=False), rng.choice(H * W, g - min(g // 2, n), replace=False)]) if g else np.zeros(0, int)
+        km.flat[gi.astype(int)] = True
+        if case == 5:
+            km[:] = False; km.flat[idx[0]] = True
+        if n == 0:
+            continue                                     # the reference's indexing fails on an empty prediction list
+        r = ev.compute_tp_fp_dist(torch.from_numpy(prob), torch.from_numpy(km))
+        o = oracle.compute_tp_fp_dist(prob, km)
+        assert np.array_equal(r[0], o[0]) and np.array_equal(r[1], o[1]), case
+        assert np.array_equal(r[2], o[2]) and r[3] == o[3]
+        assert np.array_equal(np.asarray(r[4]), o[4]), case
+
+    # the driver on two batches
+    def nms(boxes, scores, iou):
+        keep = oracle.nms_greedy(boxes.numpy().astype(np.float32), scores.numpy().astype(np.float32), float(iou))
+        return torch.as_tensor(np.asarray(keep), dtype=torch.int64)
+
+    def batched_nms(boxes, scores, idxs, iou):
+        keep = []
+        for i in torch.unique(idxs):
+            sel = torch.nonzero(idxs == i)[:, 0]
+            keep.append(sel[nms(boxes[sel], scores[sel], iou)])
+        keep = torch.cat(keep) if keep else torch.zeros(0, dtype=torch.int64)
+        return keep[torch.argsort(scores[keep], descending=True, stable=True)]
+    monkeypatch.setattr(ru, 'nms', nms, raising=False); monkeypatch.setattr(ru, 'batched_nms', batched_nms, raising=False)
+    cfg = dict(oracle.SHIPPED_MODEL_CONFIG)
+    sd = oracle.make_weights(31, cfg)
+    net = models.MultiPoint(dict(cfg)).eval(); net.load_state_dict(sd)
+    H, W = 64, 96
+    batches, mine = [], []
+    for b in range(2):
+        img = oracle.make_images(50 + b, 2, H, W)
+        vm = torch.ones((2, 1, H, W), dtype=torch.bool); vm[:, :, :6] = False
+        with torch.no_grad():
+            pr = oracle.forward(sd, img, cfg)['prob'] * vm
+        pn = oracle.box_nms(pr.numpy(), 4, 0.015)
+        km = torch.zeros((2, H, W), dtype=torch.bool)
+        for i in range(2):
+            kept = np.argwhere(pn[i, 0] > 0.015)
+            sel = kept[rng.choice(len(kept), len(kept) // 2, replace=False)]
+            sel = np.clip(sel + rng.integers(-2, 3, sel.shape), 0, [H - 1, W - 1])       # jittered labels
+            km[i, sel[:, 0], sel[:, 1]] = True
+            mine.append(oracle.compute_tp_fp_dist(pn[i, 0], km[i].numpy()))
+        batches.append({'image': img, 'valid_mask': vm, 'keypoints': km, 'is_optical': torch.ones(2, 1, dtype=torch.bool)})
+    with torch.no_grad():
+        precision, recall, prob, dist = ev.compute_detector_metrics(net, batches, torch.device('cpu'),
+                                                                    {'nms': 4, 'detection_threshold': 0.015})
+    tp = np.concatenate([m[0] for m in mine]); fp = np.concatenate([m[1] for m in mine])
+    pp = np.concatenate([m[2] for m in mine]).astype(np.float64)
+    p2, r2, prob2 = oracle.detector_precision_recall(tp, fp, pp, sum(m[3] for m in mine))
+    assert 0 < tp.sum() < len(tp)
+    assert np.array_equal(prob, prob2) and np.allclose(precision, p2, atol=0, rtol=0) and np.allclose(recall, r2, atol=0, rtol=0)
+    assert np.array_equal(dist, np.concatenate([m[4] for m in mine]).astype(np.float64))
+    assert abs(ev.compute_mAP(precision, recall) - ev.compute_mAP(p2, r2)) == 0
