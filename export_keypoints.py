@@ -92,7 +92,7 @@ def main(argv=None):
     print('Predicting on device: {}'.format(device))
     dataset = getattr(datasets, config['dataset']['type'])(config['dataset'])
     loader_dataset = torch.utils.data.DataLoader(dataset, batch_size=config['prediction']['batchsize'],
-                                                 shuffle=False, num_workers=config['prediction']['num_worker'])
+                                                 shuffle=False, num_workers=datasets.loader_num_workers(dataset, config['prediction']['num_worker']))
     net = load_network(config, args.model_dir, args.version, device, 0)
     pred = config['prediction']
     n_samples = n_keypoints = 0

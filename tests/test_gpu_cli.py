@@ -25,7 +25,9 @@ def model_dir(tmp_path, oracle):
     cfg['dataset'].update({'num_samples': 4, 'height': 240, 'width': 320})
     cfg['prediction'].update({'topk': 300, 'batchsize': 2})
     assert cfg['dataset']['augmentation']['homographic']['enable'] is True        # as the reference's config
+    cfg['prediction']['num_worker'] = 4          # the reference's value: forced to 0 while the dataset uses the GPU
     (tmp_path / 'cfg_aug.yaml').write_text(yaml.safe_dump(cfg))
+    cfg['prediction']['num_worker'] = 0
     cfg['dataset']['augmentation']['homographic']['enable'] = False               # un-warped pairs: oracle comparison
     (tmp_path / 'cfg.yaml').write_text(yaml.safe_dump(cfg))
     return tmp_path

@@ -229,3 +229,10 @@ def test_image_pair_dataset_npz_schema(tmp_path):
                                'augmentation': {'homographic': {'enable': True, 'params': {}}}})
         with pytest.raises((RuntimeError, AssertionError)):
             da[0]
+
+
+def test_loader_workers_follow_gpu_use():
+    import multipoint_amd.datasets as d
+    aug = d.SyntheticPairs({'num_samples': 2, 'height': 64, 'width': 96, 'augmentation': {'homographic': {'enable': True}}})
+    assert d.loader_num_workers(aug, 4) == 0 and d.loader_num_workers(aug, 0) == 0
+    assert d.loader_num_workers(d.SyntheticPairs({}), 4) == 4
