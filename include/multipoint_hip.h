@@ -165,6 +165,21 @@ int mp_find_homography(mp_handle* h, const int* kp_yx, const int* kp_count, cons
                        double reproj_threshold, int max_iters, unsigned long long seed, double* homography,
                        unsigned char* inlier_mask, int* n_inliers, void* stream);
 
+/* the other modes of utils.get_matches (multipoint/utils/matching.py:4-33); same descriptor / count addressing as
+ * mp_match_mutual_nn, 1 <= D <= 256.
+ * mp_match_knn2 replaces cv2.BFMatcher(cv2.NORM_L2).knnMatch(d1, d2, 2) (:21, followed by Lowe's ratio test :23-27)
+ * and .match() without crossCheck (:7,31): nn_idx / nn_dist [P][K][2] = the two nearest train rows of every query
+ * row under ||a - b||_2 (ties: lower train index first), idx -1 where the pair has fewer than 1 / 2 train rows.
+ * mp_match_threshold replaces ThresholdMatcher.match (:81-99): every (i, j) with sqrt(2 - 2 clip(a.b, -1, 1)) <
+ * threshold is appended (arbitrary order) to list_ij [P][capacity][2] / list_dist [P][capacity]; list_count [P] is
+ * the number FOUND (may exceed capacity: the caller retries with a larger list). */
+int mp_match_knn2(mp_handle* h, const float* descA, const int* countA, const float* descB, const int* countB,
+                  long long pair_stride, int count_stride, int P, int K, int D, int* nn_idx, float* nn_dist,
+                  void* stream);
+int mp_match_threshold(mp_handle* h, const float* descA, const int* countA, const float* descB, const int* countB,
+                       long long pair_stride, int count_stride, int P, int K, int D, float threshold, int capacity,
+                       int* list_ij, float* list_dist, int* list_count, void* stream);
+
 /* ---- single-image detector metrics: multipoint/utils/evaluation.py:10-97 (predict_keypoints.py:88-104) ----
  * mp_detector_metrics replaces compute_tp_fp_dist (evaluation.py:56-97) for B heat maps at once:
  *   prob          fp32 [B][H][W]  detector map after valid mask / NMS (evaluation.py:19-25)

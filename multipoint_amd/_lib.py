@@ -48,6 +48,10 @@ SIGNATURES = {
                                       c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     'mp_match_mutual_nn': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_int, c_int,
                                    c_int, c_int, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+    'mp_match_knn2': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_int, c_int, c_int, c_int,
+                              c_void_p, c_void_p, c_void_p]),
+    'mp_match_threshold': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_ll, c_int, c_int, c_int, c_int,
+                                   c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     'mp_pair_metrics': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float,
                                 c_void_p, c_void_p, c_void_p]),
     'mp_repeatability': (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, ctypes.c_double,

@@ -944,6 +944,49 @@ int mp_match_mutual_nn(mp_handle* h, const float* descA, const int* countA, cons
     return MP_OK;
 }
 
+static int match_extra_check(mp_handle* h, const char* fn, const void* a, const void* b, const void* c, const void* d,
+                             int P, int K, int D)
+{
+    if (!a || !b || !c || !d) return fail(h, MP_EINVAL, std::string(fn) + ": NULL tensor");
+    if (P <= 0 || P > 65535 || K <= 0) return fail(h, MP_EINVAL, std::string(fn) + ": need 0 < P <= 65535, K > 0");
+    if (D <= 0 || D > 256) return fail(h, MP_EINVAL, std::string(fn) + ": D must be in [1, 256]");
+    return MP_OK;
+}
+
+int mp_match_knn2(mp_handle* h, const float* descA, const int* countA, const float* descB, const int* countB,
+                  long long pair_stride, int count_stride, int P, int K, int D, int* nn_idx, float* nn_dist,
+                  void* stream)
+{
+    if (!h) return MP_EINVAL;
+    int rc;
+    if ((rc = match_extra_check(h, "mp_match_knn2", descA, descB, countA, countB, P, K, D))) return rc;
+    if (!nn_idx || !nn_dist) return fail(h, MP_EINVAL, "mp_match_knn2: NULL output");
+    MP_HIP(hipSetDevice(h->device));
+    launch_match_knn2(descA, countA, descB, countB, pair_stride, count_stride, P, K, D, nn_idx, nn_dist,
+                      static_cast<hipStream_t>(stream));
+    MP_HIP(hipGetLastError());
+    return MP_OK;
+}
+
+int mp_match_threshold(mp_handle* h, const float* descA, const int* countA, const float* descB, const int* countB,
+                       long long pair_stride, int count_stride, int P, int K, int D, float threshold, int capacity,
+                       int* list_ij, float* list_dist, int* list_count, void* stream)
+{
+    if (!h) return MP_EINVAL;
+    int rc;
+    if ((rc = match_extra_check(h, "mp_match_threshold", descA, descB, countA, countB, P, K, D))) return rc;
+    if (!list_ij || !list_dist || !list_count) return fail(h, MP_EINVAL, "mp_match_threshold: NULL output");
+    if (capacity <= 0) return fail(h, MP_EINVAL, "mp_match_threshold: capacity must be positive");
+    if (!(threshold >= 0.f)) return fail(h, MP_EINVAL, "mp_match_threshold: threshold must be non-negative");
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    MP_HIP(hipSetDevice(h->device));
+    MP_HIP(hipMemsetAsync(list_count, 0, (size_t)P * sizeof(int), s));
+    launch_match_threshold(descA, countA, descB, countB, pair_stride, count_stride, P, K, D, threshold, capacity, list_ij,
+                           list_dist, list_count, s);
+    MP_HIP(hipGetLastError());
+    return MP_OK;
+}
+
 int mp_pair_metrics(mp_handle* h, const int* kp_yx, const int* kp_count, const int* match_idx, const double* homography,
                     int P, int K, int H, int W, float threshold_keypoints, int* metrics, unsigned char* tp,
                     void* stream)

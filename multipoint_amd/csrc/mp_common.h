@@ -140,6 +140,14 @@ void launch_match_impl(const float* dA, const int* nA, const float* dB, const in
                        unsigned long long* rowbest, unsigned long long* colbest, int* match_idx,
                        float* match_dist, int* match_count, hipStream_t s);
 
+// remaining get_matches modes (match_extra.hip): two nearest train rows per query (BFMatcher knnMatch / match without
+// crossCheck), idx/dist [P][K][2]; all pairs closer than thr (ThresholdMatcher), list_count [P] pre-set to 0
+void launch_match_knn2(const float* dA, const int* nA, const float* dB, const int* nB, long long pair_stride,
+                       int count_stride, int P, int K, int D, int* idx, float* dist, hipStream_t s);
+void launch_match_threshold(const float* dA, const int* nA, const float* dB, const int* nB, long long pair_stride,
+                            int count_stride, int P, int K, int D, float thr, int capacity, int* list_ij,
+                            float* list_dist, int* list_count, hipStream_t s);
+
 // GPU-resident pair metrics (evaluation.py:287-328): hom [2P][9] double (slot 2p: optical->thermal ground-truth
 // homography, 2p+1: its inverse), warped [2P][K][2] double scratch, inv_idx [P][K] scratch (pre-set to -1),
 // tp [2P][K] (pre-set to 0), metrics [P][8] (pre-set to 0): n_gt_o, n_gt_t, matched_o, matched_t, N_o, N_t, n_matches

@@ -532,6 +532,45 @@ def distance_matrix(desc1, desc2):
     return np.sqrt(2 - 2 * np.clip(np.dot(d1, d2.T), -1, 1))
 
 
+def threshold_match(desc1, desc2, threshold=0.4):
+    """ThresholdMatcher.match (matching.py:81-99): every (i, j) with sqrt(2 - 2 clip(d1.d2^T)) < threshold, in
+    np.argwhere (row-major) order.  Returns (query_idx, train_idx, distance)."""
+    d1 = np.asarray(desc1, dtype=np.float32); d2 = np.asarray(desc2, dtype=np.float32)
+    if d1.shape[0] == 0 or d2.shape[0] == 0:                              # :86-87
+        z = np.zeros(0, dtype=np.int64)
+        return z, z.copy(), np.zeros(0, dtype=np.float32)
+    dmat = np.sqrt(2 - 2 * np.clip(np.dot(d1, d2.T), -1, 1))             # :90-91
+    idx = np.argwhere(dmat < threshold)                                   # :94
+    return idx[:, 0].astype(np.int64), idx[:, 1].astype(np.int64), dmat[idx[:, 0], idx[:, 1]].astype(np.float32)
+
+
+def bf_knn(desc1, desc2, k=2):
+    """cv2.BFMatcher(cv2.NORM_L2).knnMatch(d1, d2, k) (matching.py:21; opencv-python==4.2.0.34, absent -> PARITY
+    UNPINNED, published semantics restated): per query row the k nearest train rows under ||a - b||_2, nearest first,
+    lower train index first on exact ties (a candidate displaces an entry only when strictly closer).
+    Returns (idx (N,k) int64 with -1 padding, dist (N,k) float32)."""
+    d1 = np.asarray(desc1, dtype=np.float32); d2 = np.asarray(desc2, dtype=np.float32)
+    N, M = d1.shape[0], d2.shape[0]
+    idx = np.full((N, k), -1, dtype=np.int64); dist = np.zeros((N, k), dtype=np.float32)
+    if N == 0 or M == 0:
+        return idx, dist
+    diff = d1[:, None, :] - d2[None, :, :]
+    dmat = np.sqrt((diff * diff).sum(-1, dtype=np.float32))
+    order = np.argsort(dmat, axis=1, kind='stable')[:, :k]
+    kk = order.shape[1]
+    idx[:, :kk] = order
+    dist[:, :kk] = np.take_along_axis(dmat, order, axis=1)
+    return idx, dist
+
+
+def bf_ratio_match(desc1, desc2, ratio_thresh=0.9):
+    """get_matches(..., 'bfmatcher', knn_matches=True) (matching.py:20-27): Lowe's ratio test on the two nearest."""
+    idx, dist = bf_knn(desc1, desc2, 2)
+    keep = (idx[:, 1] >= 0) & (dist[:, 0] < np.float32(ratio_thresh) * dist[:, 1].astype(np.float64))
+    q = np.nonzero(keep)[0]
+    return q.astype(np.int64), idx[q, 0], dist[q, 0]
+
+
 def bf_match_crosscheck(desc1, desc2):
     """cv2.BFMatcher(cv2.NORM_L2, crossCheck=True).match(d1, d2) (matching.py:7,31), restated from
     OpenCV's published BFMatcher::knnMatchImpl semantics (opencv-python==4.2.0.34 pinned in

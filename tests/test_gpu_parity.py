@@ -12,6 +12,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+DEV = 'cuda:0'
 
 DESC_TOL = 1e-4
 PROB_TOL = 1e-4
@@ -380,3 +381,72 @@ def test_full_size_properties(oracle, shipped, U):
         bwd = {(int(i), j) for j, i in enumerate(swapped[p].tolist()) if i >= 0}
         assert fwd == bwd and len(fwd) == int(res.match_count[p])
         assert len({j for _, j in fwd}) == len(fwd)                                       # one-to-one
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the remaining get_matches modes (mp_match_knn2, mp_match_threshold; multipoint/utils/matching.py:4-33, 74-99)
+# ----------------------------------------------------------------------------------------------------------------------
+def _unit_rows(rng, n, d):
+    x = rng.standard_normal((n, d)).astype(np.float32)
+    return x / np.linalg.norm(x, axis=1, keepdims=True)
+
+
+@pytest.mark.parametrize('N,M,D', [(300, 257, 64), (1000, 1000, 64), (130, 77, 128), (65, 400, 256), (5, 1, 64)])
+def test_bf_knn_and_ratio_test(oracle, N, M, D):
+    import multipoint_amd.utils as U
+    rng = np.random.default_rng(N + M + D)
+    d1 = _unit_rows(rng, N, D)
+    d2 = _unit_rows(rng, M, D)
+    k = min(N, M) // 2
+    d2[:k] = d1[:k] + 0.1 * rng.standard_normal((k, D)).astype(np.float32)         # true correspondences
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+    if M >= 3:
+        d2[2] = d2[1]                                                                 # an exact duplicate: index tie
+    idx, dist = oracle.bf_knn(d1, d2, 2)
+    nn = U.get_matches(torch.from_numpy(d1).to(DEV), d2, 'bfmatcher', crossCheck=False)
+    assert [m.queryIdx for m in nn] == list(range(N))
+    got = np.array([m.trainIdx for m in nn]); gd = np.array([m.distance for m in nn], np.float32)
+    diff = d1[:, None, :] - d2[None, :, :]
+    dm = np.sqrt((diff * diff).sum(-1))
+    # nearest: same index unless the oracle's own best two are within fp32 noise of each other
+    close = (np.partition(dm, 1, axis=1)[:, 1] - dm.min(1) < 1e-5) if M > 1 else np.zeros(N, bool)
+    assert np.array_equal(got[~close], idx[~close, 0]) and np.abs(gd - dm[np.arange(N), got]).max() < 1e-5
+    if M >= 3:
+        assert not (got == 2).any()                                                   # the duplicate never beats index 1
+    if M == 1:
+        with pytest.raises(ValueError):                                               # `for m, n in all_matches` of the reference
+            U.get_matches(d1, d2, 'bfmatcher', True)
+        return
+    m = U.get_matches(d1, d2, 'bfmatcher', True)
+    q, t, d = oracle.bf_ratio_match(d1, d2)
+    margin = np.abs(dist[:, 0] - 0.9 * dist[:, 1]) < 1e-5                              # ratio test on the fence
+    sg = {(x.queryIdx, x.trainIdx) for x in m if not margin[x.queryIdx] and not close[x.queryIdx]}
+    so = {(int(a), int(b)) for a, b in zip(q, t) if not margin[a] and not close[a]}
+    assert sg == so and len(so) >= (1 if k else 0)
+    assert [x.queryIdx for x in m] == sorted(x.queryIdx for x in m)
+
+
+@pytest.mark.parametrize('N,M,D,thr', [(300, 257, 64, 0.7), (1000, 1000, 64, 0.5), (130, 77, 128, 1.2), (40, 90, 256, 0.9)])
+def test_threshold_matcher(oracle, N, M, D, thr):
+    import multipoint_amd.utils as U
+    rng = np.random.default_rng(N * 7 + M)
+    d1 = _unit_rows(rng, N, D)
+    d2 = _unit_rows(rng, M, D)
+    k = min(N, M) // 2
+    d2[:k] = d1[:k] + 0.04 * rng.standard_normal((k, D)).astype(np.float32)
+    d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+    m = U.get_matches(d1, torch.from_numpy(d2).to(DEV), 'thresholdmatcher', threshold=thr)
+    q, t, d = oracle.threshold_match(d1, d2, thr)
+    dm = oracle.distance_matrix(d1, d2)
+    fence = np.abs(dm - thr) < 1e-5
+    sg = {(x.queryIdx, x.trainIdx) for x in m if not fence[x.queryIdx, x.trainIdx]}
+    so = {(int(a), int(b)) for a, b in zip(q, t) if not fence[a, b]}
+    assert sg == so and len(so) >= k // 2
+    pairs = [(x.queryIdx, x.trainIdx) for x in m]
+    assert pairs == sorted(pairs)                                                     # np.argwhere order
+    # sqrt(2 - 2ab) amplifies the fp32 noise of the dot product as 1/d near d = 0
+    assert max(abs(x.distance - dm[x.queryIdx, x.trainIdx]) * max(dm[x.queryIdx, x.trainIdx], 1e-3) for x in m) < 1e-6
+    # a list larger than the first capacity guess: threshold 2.1 keeps every pair
+    if N * M <= 40000:
+        allm = U.get_matches(d1, d2, 'thresholdmatcher', threshold=2.1)
+        assert len(allm) == N * M

@@ -124,8 +124,13 @@ def test_argument_errors_mirror_reference():
         U.get_matches(np.zeros((2, 64), np.float32), np.zeros((2, 64), np.float32), 'nnmatcher', threshold=-0.1)
     with pytest.raises(NotImplementedError):
         U.get_matches(np.zeros((2, 64), np.float32), np.zeros((2, 64), np.float32), 'flann')
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):          # OpenCV: crossCheck supports k = 1 only
         U.get_matches(np.zeros((2, 64), np.float32), np.zeros((2, 64), np.float32), 'bfmatcher', True, crossCheck=True)
+    with pytest.raises(AttributeError):      # NNMatcher has no knnMatch (matching.py:21)
+        U.get_matches(np.zeros((2, 64), np.float32), np.zeros((2, 64), np.float32), 'nnmatcher', True)
+    with pytest.raises(ValueError, match='non-negative'):
+        U.get_matches(np.zeros((2, 64), np.float32), np.zeros((2, 64), np.float32), 'thresholdmatcher', threshold=-1.0)
+    assert U.get_matches(np.zeros((0, 64), np.float32), np.zeros((2, 64), np.float32), 'thresholdmatcher') == []
     assert U.get_matches(np.zeros((0, 64), np.float32), np.zeros((2, 64), np.float32), 'nnmatcher') == []   # matching.py:46-47
 
 

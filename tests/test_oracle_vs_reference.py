@@ -397,3 +397,19 @@ def test_detector_metrics_against_reference(oracle, ref, monkeypatch):
     assert np.array_equal(prob, prob2) and np.allclose(precision, p2, atol=0, rtol=0) and np.allclose(recall, r2, atol=0, rtol=0)
     assert np.array_equal(dist, np.concatenate([m[4] for m in mine]).astype(np.float64))
     assert abs(ev.compute_mAP(precision, recall) - ev.compute_mAP(p2, r2)) == 0
+
+
+def test_threshold_matcher_against_reference(oracle, ref):
+    """ThresholdMatcher (matching.py:74-99) is in-repo numpy: the oracle restatement is pinned exactly."""
+    models, utils = ref
+    rng = np.random.default_rng(8)
+    d1 = rng.standard_normal((120, 64)).astype(np.float32); d1 /= np.linalg.norm(d1, axis=1, keepdims=True)
+    d2 = np.concatenate([d1[:60] + 0.05 * rng.standard_normal((60, 64)).astype(np.float32),
+                         rng.standard_normal((50, 64)).astype(np.float32)]); d2 /= np.linalg.norm(d2, axis=1, keepdims=True)
+    for thr in (0.4, 0.7, 1.3):
+        m = utils.get_matches(d1, d2, 'thresholdmatcher', threshold=thr)
+        q, t, d = oracle.threshold_match(d1, d2, thr)
+        assert [x.queryIdx for x in m] == list(q) and [x.trainIdx for x in m] == list(t) and len(q) > 0
+        assert np.array_equal(np.array([x.distance for x in m], np.float32), d)
+    with pytest.raises(ValueError):
+        utils.ThresholdMatcher(-0.5)
