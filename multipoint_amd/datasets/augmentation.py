@@ -12,7 +12,7 @@ import torch
 from .. import _lib
 from ..utils import homographies as hom
 
-__all__ = ['homographic_augmentation', 'homographic_augmentation_batch', 'dummy_valid_mask', 'cv_invert3',
+__all__ = ['homographic_augmentation', 'homographic_augmentation_batch', 'warp_perspective_cv', 'dummy_valid_mask', 'cv_invert3',
            'photometric_augmentation']
 
 
@@ -33,24 +33,36 @@ def cv_invert3(m):
                      [c02 * d, (s[0, 1] * s[2, 0] - s[0, 0] * s[2, 1]) * d, (s[0, 0] * s[1, 1] - s[0, 1] * s[1, 0]) * d]])
 
 
-def homographic_augmentation_batch(images, homographies, border_reflect=True, valid_border_margin=0,
-                                   mask_border=True):
-    """images (B,1,H,W) fp32 on the GPU, homographies (B,3,3) source -> destination pixel maps (host).
-    Returns the warped images (B,1,H,W) fp32 and the valid masks (B,1,H,W) bool, both on the GPU."""
+def warp_perspective_cv(images, homographies, border_reflect=False):
+    """cv2.warpPerspective(image, H, (W, H), borderMode=BORDER_CONSTANT | BORDER_REFLECT_101) with INTER_LINEAR for a
+    batch of fp32 images (B,1,H,W) on the GPU (mp_warp_perspective_cv); homographies (B,3,3) map source to destination
+    pixels.  Used by the dataset augmentation below and by predict_align_image_pair.py to warp the optical image onto
+    the thermal one with the estimated homography (reference predict_align_image_pair.py:218)."""
     if not torch.is_tensor(images) or images.dim() != 4 or images.shape[1] != 1:
-        raise ValueError('homographic_augmentation_batch: images must be a (B,1,H,W) tensor')
+        raise ValueError('warp_perspective_cv: images must be a (B,1,H,W) tensor')
     dev = _lib.require_cuda(images.device if images.device.type == 'cuda' else None)
     src = images.to(dev, torch.float32).contiguous()
     B, _, H, W = src.shape
     h_np = np.asarray(homographies, dtype=np.float64).reshape(-1, 3, 3)
     if h_np.shape[0] != B:
-        raise ValueError('homographic_augmentation_batch: one homography per image expected')
+        raise ValueError('warp_perspective_cv: one homography per image expected')
     inv_cv = torch.from_numpy(np.stack([cv_invert3(m) for m in h_np]).reshape(B, 9)).to(dev)
     out = torch.empty_like(src)
     h = _lib.get_handle(dev)
     with torch.cuda.device(dev):
         h.check(h.lib.mp_warp_perspective_cv(h.ptr, _lib.ptr(src), B, H, W, _lib.ptr(inv_cv),
                                              1 if border_reflect else 0, _lib.ptr(out), _lib.stream_ptr(dev)))
+    return out
+
+
+def homographic_augmentation_batch(images, homographies, border_reflect=True, valid_border_margin=0,
+                                   mask_border=True):
+    """images (B,1,H,W) fp32 on the GPU, homographies (B,3,3) source -> destination pixel maps (host).
+    Returns the warped images (B,1,H,W) fp32 and the valid masks (B,1,H,W) bool, both on the GPU."""
+    out = warp_perspective_cv(images, homographies, border_reflect)
+    dev = out.device
+    B, _, H, W = out.shape
+    h_np = np.asarray(homographies, dtype=np.float64).reshape(-1, 3, 3)
     # compute_valid_mask(image_shape, homography, valid_border_margin * 2, mask_border)  (augmentation.py:38-40)
     mask = hom._valid_masks(np.linalg.inv(h_np), (H, W), int(valid_border_margin) * 2, mask_border, dev)
     return out, mask.view(B, 1, H, W).bool()

@@ -167,12 +167,23 @@ def main(argv=None):
             print('Ground Truth Homography:')
             print(H_gt)
             print('--------------------------------------------------------')
+            # the aligned image: optical warped onto the thermal frame by the estimate (reference :218,
+            # cv2.warpPerspective(im_optical, H_est, size, borderMode=cv2.BORDER_CONSTANT)), on the GPU
+            from multipoint_amd.datasets.augmentation import warp_perspective_cv
+            warped_image = warp_perspective_cv(data['optical']['image'][:1], H_est[None], border_reflect=False)
+            inside = warp_perspective_cv(torch.ones_like(data['optical']['image'][:1]), H_est[None]) > 0.999
+            if bool(inside.any()):
+                resid = (warped_image - data['thermal']['image'][:1]).abs()[inside].mean().item()
+                print('Aligned optical vs thermal: mean |diff| {:.4f} over {:.1f} % of the frame'.format(
+                    resid, 100.0 * inside.float().mean().item()))
             if args.save_npz:
                 np.savez_compressed(args.save_npz, kp_optical=pred_optical.cpu().numpy(), kp_thermal=pred_thermal.cpu().numpy(),
                                     desc_optical=desc_optical.cpu().numpy(), desc_thermal=desc_thermal.cpu().numpy(),
                                     match_query=np.array([m.queryIdx for m in matches]),
                                     match_train=np.array([m.trainIdx for m in matches]),
-                                    match_distance=np.array([m.distance for m in matches], dtype=np.float32))
+                                    match_distance=np.array([m.distance for m in matches], dtype=np.float32),
+                                    homography_estimated=H_est, homography_ground_truth=H_gt,
+                                    warped_optical=warped_image[0, 0].cpu().numpy())
 
 
 if __name__ == "__main__":

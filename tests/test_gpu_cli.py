@@ -53,6 +53,11 @@ def test_predict_align_image_pair_cli(model_dir, oracle):
     assert np.abs(g['desc_optical'] - ref['desc_optical']).max() <= 1e-4
     assert len(set(zip(g['match_query'], g['match_train'])) ^ set(zip(ref['match_query'], ref['match_train']))) <= 2
     assert os.listdir(model_dir / 'multipoint' / 'descriptor_evaluation')
+    # the aligned image: cv2.warpPerspective(optical, H_est, BORDER_CONSTANT) restated (reference :218)
+    from oracle import ha_oracle as HA
+    assert 'Aligned optical vs thermal' in out.stdout
+    want = HA.cv2_warp_perspective_linear(o[0], g['homography_estimated'], (320, 240), 'constant')
+    assert np.array_equal(g['warped_optical'], want)
 
 
 def test_predict_keypoints_cli(model_dir):
