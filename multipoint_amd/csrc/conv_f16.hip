@@ -504,7 +504,7 @@ void launch_h(const ConvParamsH& p, hipStream_t s)
 
 // ---- first encoder block, fp16 flavour: image (fp32 in HBM, rounded to fp16 as autocast casts the conv input)
 //      -> 64 fp16 channels.  HBM-write bound: thread = (pixel, 8 channels), one 16-byte store.
-constexpr int FTH = 16, FTW = 64, FLW = FTW + 2, FLH = FTH + 2;
+constexpr int FTH = 32, FTW = 64, FLW = FTW + 2, FLH = FTH + 2;
 
 __global__ __launch_bounds__(256) void conv_first_f16_kernel(const Conv1ParamsH p)
 {
@@ -531,14 +531,21 @@ __global__ __launch_bounds__(256) void conv_first_f16_kernel(const Conv1ParamsH 
         }
         tile[f] = round_h(v);
     }
+    // channel pairs in f32x2 registers: the 72 multiply-adds and the activation of a pixel's 8 channels are packed
+    // instructions (v_pk_fma_f32 with the pixel value broadcast, act_h2) -- the kernel is otherwise VALU-bound
+    // (~180 scalar VALU instructions per 16-byte store against ~116 clocks of HBM time per KiB and CU)
     const int c8 = (tid & 7) * 8;
-    float w[9][8], bia[8], scl[8], sft[8];
+    f32x2 w[9][4], bia[4], scl[4], sft[4];
 #pragma unroll
     for (int k = 0; k < 9; ++k)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) w[k][e] = p.w[k * 64 + c8 + e];
+        for (int e = 0; e < 4; ++e) w[k][e] = f32x2{p.w[k * 64 + c8 + 2 * e], p.w[k * 64 + c8 + 2 * e + 1]};
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { bia[e] = p.bias[c8 + e]; scl[e] = p.scale[c8 + e]; sft[e] = p.shift[c8 + e]; }
+    for (int e = 0; e < 4; ++e) {
+        bia[e] = f32x2{p.bias[c8 + 2 * e], p.bias[c8 + 2 * e + 1]};
+        scl[e] = f32x2{p.scale[c8 + 2 * e], p.scale[c8 + 2 * e + 1]};
+        sft[e] = f32x2{p.shift[c8 + 2 * e], p.shift[c8 + 2 * e + 1]};
+    }
     __syncthreads();
     _Float16* out = p.out + (long long)img * p.H * p.W * 64;
     const int psub = tid >> 3;                    // 32 pixels per pass
@@ -553,12 +560,13 @@ __global__ __launch_bounds__(256) void conv_first_f16_kernel(const Conv1ParamsH 
             for (int kw = 0; kw < 3; ++kw) x[kh * 3 + kw] = tile[(py + kh) * FLW + px + kw];
         h8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            float a = 0.f;
+        for (int e = 0; e < 4; ++e) {
+            f32x2 a = {0.f, 0.f};
 #pragma unroll
-            for (int k = 0; k < 9; ++k) a = fmaf(x[k], w[k][e], a);
-            o[e] = (_Float16)(p.bn_first ? act_h<true, true>(a, bia[e], scl[e], sft[e])
-                                         : act_h<true, false>(a, bia[e], scl[e], sft[e]));
+            for (int k = 0; k < 9; ++k) a = __builtin_elementwise_fma(f32x2{x[k], x[k]}, w[k][e], a);
+            const h2 r = p.bn_first ? act_h2<true, true>(a[0], a[1], bia[e], scl[e], sft[e])
+                                    : act_h2<true, false>(a[0], a[1], bia[e], scl[e], sft[e]);
+            o[2 * e] = r[0]; o[2 * e + 1] = r[1];
         }
         const int oy = y0 + py, ox = x0 + px;
         if (oy < p.H && ox < p.W) *reinterpret_cast<h8*>(out + ((long long)oy * p.W + ox) * 64 + c8) = o;
