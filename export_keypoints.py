@@ -33,7 +33,8 @@ def build_parser():
 
 
 class _NpzStore:
-    """{name: keypoints} archive used when h5py is unavailable."""
+    """'<sample>/keypoints' arrays in a numpy archive: the group / dataset layout of the HDF5 label file, readable by
+    multipoint_amd.datasets.ImagePairDataset(keypoints_filename=...); used when h5py is unavailable."""
 
     def __init__(self, path):
         self.path = path
@@ -43,10 +44,10 @@ class _NpzStore:
                 self.data = {k: f[k] for k in f.files}
 
     def keys(self):
-        return self.data.keys()
+        return [k.rpartition('/')[0] for k in self.data if k.endswith('/keypoints')]
 
     def put(self, name, keypoints):
-        self.data[name] = keypoints
+        self.data[name + '/keypoints'] = keypoints
 
     def close(self):
         np.savez_compressed(self.path, **self.data)

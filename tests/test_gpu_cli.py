@@ -114,3 +114,37 @@ def test_predict_keypoints_single_image_evaluation(model_dir, tmp_path):
     m = float(out.stdout.split('mAP:')[1].split()[0])
     assert 0.0 <= m <= 1.0
     assert 'image keypoints per image:' in out.stdout
+
+
+def test_label_round_trip(model_dir, tmp_path):
+    """export_keypoints.py over an .npz pair archive -> label archive -> ImagePairDataset(keypoints_filename) ->
+    predict_keypoints.py -e (detector mAP against the exported labels): the reference's labelling workflow
+    (export_keypoints.py:100-103 -> ImagePairDataset.py:100-105 -> predict_keypoints.py:88-104) end to end."""
+    rng = np.random.default_rng(1)
+    arrays = {}
+    for i in range(3):
+        arrays['s%d/optical' % i] = rng.random((64, 96), dtype=np.float32)
+        arrays['s%d/thermal' % i] = rng.random((64, 96), dtype=np.float32)
+    np.savez(str(tmp_path / 'pairs.npz'), **arrays)
+    cfg = yaml.safe_load(open(os.path.join(ROOT, 'configs', 'config_export_keypoints.yaml')))
+    cfg['dataset'] = {'type': 'ImagePairDataset', 'filename': str(tmp_path / 'pairs.npz'), 'single_image': False}
+    cfg['prediction']['homographic_adaptation'].update({'num': 4, 'min_count': 2})
+    (tmp_path / 'export.yaml').write_text(yaml.safe_dump(cfg))
+    labels = tmp_path / 'labels.npz'
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'export_keypoints.py'), '-y', str(tmp_path / 'export.yaml'),
+                          '-o', str(labels), '-m', str(model_dir / 'multipoint'), '-v', 'latest', '-s', '3'],
+                         capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 'of 3 samples' in out.stdout
+    from multipoint_amd.datasets import ImagePairDataset
+    ds = ImagePairDataset({'filename': str(tmp_path / 'pairs.npz'), 'keypoints_filename': str(labels), 'single_image': False})
+    s = ds[2]
+    assert s['optical']['keypoints'].shape == (64, 96) and s['optical']['keypoints'].sum() > 0
+    ev = yaml.safe_load(open(model_dir / 'cfg.yaml'))
+    ev['dataset'] = {'type': 'ImagePairDataset', 'filename': str(tmp_path / 'pairs.npz'),
+                     'keypoints_filename': str(labels), 'single_image': True}
+    (tmp_path / 'eval.yaml').write_text(yaml.safe_dump(ev))
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'predict_keypoints.py'), '-y', str(tmp_path / 'eval.yaml'),
+                          '-m', str(model_dir / 'multipoint'), '-e'], capture_output=True, text=True, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert 0.0 <= float(out.stdout.split('mAP:')[1].split()[0]) <= 1.0

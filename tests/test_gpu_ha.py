@@ -186,7 +186,7 @@ def test_export_keypoints_cli(tmp_path, oracle):
     assert out.returncode == 0, out.stderr[-2000:]
     assert 'of 3 samples' in out.stdout
     got = np.load(out_file)
-    assert sorted(got.files) == ['synthetic_%06d' % i for i in range(3)]
+    assert sorted(got.files) == ['synthetic_%06d/keypoints' % i for i in range(3)]
     # sample 0+1 (first batch) through the oracle with the homographies the seeded sampler draws
     from multipoint_amd.datasets import SyntheticPairs
     hc = cfg['prediction']['homographic_adaptation']
@@ -198,7 +198,7 @@ def test_export_keypoints_cli(tmp_path, oracle):
     ref, _ = HA.homographic_adaptation([opt, thr], fwd, hc, homs, aggregation='prod')
     ref_nms = oracle.box_nms(ref.numpy(), cfg['prediction']['nms'], cfg['prediction']['detection_threshold'])
     for i in range(2):
-        k = got['synthetic_%06d' % i]
+        k = got['synthetic_%06d/keypoints' % i]
         assert k.dtype == np.int64 and k.ndim == 2 and k.shape[1] == 2
         want = set(map(tuple, oracle.keypoints_from_map(ref_nms[i, 0], cfg['prediction']['detection_threshold']).tolist()))
         have = set(map(tuple, k.tolist()))
