@@ -383,6 +383,26 @@ def test_full_size_properties(oracle, shipped, U):
         assert len({j for _, j in fwd}) == len(fwd)                                       # one-to-one
 
 
+@pytest.mark.parametrize('mixed', [False, True])
+def test_large_batch_index_range(oracle, mixed):
+    """40 images 1024x1280: the 64-channel activation tensors hold 3.4e9 elements (> 2^31), so every kernel's
+    addressing is exercised beyond 32 bits; images are independent, so the outputs of the last and the first image
+    must equal the outputs of the same images run as a batch of two -- bit for bit."""
+    cfg = dict(oracle.SHIPPED_MODEL_CONFIG); cfg['mixed_precision'] = mixed
+    net, _ = _net(oracle, cfg)
+    B = 40
+    g = torch.Generator(device='cpu').manual_seed(9)
+    two = torch.rand((2, 1, 1024, 1280), generator=g)
+    images = torch.rand((B, 1, 1024, 1280), generator=g)
+    images[0], images[B - 1] = two[0], two[1]
+    ref = net({'image': two.cuda()})
+    ref_prob, ref_desc = ref['prob'].clone(), ref['desc'].clone()
+    out = net({'image': images.cuda()})
+    assert torch.equal(out['prob'][0], ref_prob[0]) and torch.equal(out['prob'][B - 1], ref_prob[1])
+    assert torch.equal(out['desc'][0], ref_desc[0]) and torch.equal(out['desc'][B - 1], ref_desc[1])
+    assert torch.isfinite(out['prob']).all() and torch.isfinite(out['desc']).all()
+
+
 # ----------------------------------------------------------------------------------------------------------------------
 # the remaining get_matches modes (mp_match_knn2, mp_match_threshold; multipoint/utils/matching.py:4-33, 74-99)
 # ----------------------------------------------------------------------------------------------------------------------
