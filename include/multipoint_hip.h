@@ -90,8 +90,9 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
  * multiply of its callers (predict_align_image_pair.py:128,133).
  *   valid_mask  uint8 [B][H][W] or NULL
  *   prob_nms    [B][H][W] dense output (zeros except kept pixels, which keep their score)
- *   max_rounds  0: run until converged (synchronises `stream`); >0: enqueue exactly that many
- *               fixed-point rounds asynchronously, check with mp_nms_unresolved() after a sync.
+ *   max_rounds  0: run until converged (groups of 8 rounds, one 4-byte host read per group: synchronises
+ *               `stream`; at most 4096 rounds); >0: enqueue exactly that many (<= 64) fixed-point rounds
+ *               asynchronously, check with mp_nms_unresolved() after a sync.
  * Tie-break (stated rule): priority = (score descending, row-major index ascending). */
 int mp_box_nms(mp_handle* h, const float* prob, const unsigned char* valid_mask, int B, int H, int W,
                float size, float min_prob, float iou, int keep_top_k, float* prob_nms,

@@ -613,12 +613,18 @@ int nms_common(mp_handle* h, const float* prob, const unsigned char* mask, int B
     int* remaining = static_cast<int*>(h->nms_state.p);
     MP_HIP(hipMemsetAsync(remaining, 0, 64 * 4, s));
     launch_nms_init(prob, mask, min_prob, work, n, s);
+    // Rounds: a fixed number without any host read (max_rounds > 0, at most 64), or groups of 8 with one 4-byte read
+    // of the undecided count after each group until it is zero (max_rounds == 0).  A round settles every chain of
+    // dependent decisions inside a 32 x 32 tile, so the count of rounds is the longest chain measured in tiles: a
+    // handful for detector maps, W / 32 for a monotone ramp across the frame -- hence the generous cap.
     int round = 0;
-    const int per = max_rounds > 0 ? max_rounds : 8;
+    const int per = max_rounds > 0 ? (max_rounds < 64 ? max_rounds : 64) : 8;
+    const int cap = max_rounds > 0 ? per : 4096;
     for (;;) {
-        for (int r = 0; r < per && round < 64; ++r, ++round) launch_nms_round(work, B, H, W, fp, remaining, round, s);
-        if (max_rounds > 0 || round >= 64) break;
-        MP_HIP(hipMemcpyAsync(h->pinned, remaining + (round - 1), 4, hipMemcpyDeviceToHost, s));
+        if (round >= 64) MP_HIP(hipMemsetAsync(remaining + (round & 63), 0, 8 * 4, s));      // recycle 8 counter slots
+        for (int r = 0; r < per && round < cap; ++r, ++round) launch_nms_round(work, B, H, W, fp, remaining, round, s);
+        if (max_rounds > 0 || round >= cap) break;
+        MP_HIP(hipMemcpyAsync(h->pinned, remaining + ((round - 1) & 63), 4, hipMemcpyDeviceToHost, s));
         MP_HIP(hipStreamSynchronize(s));
         if (h->pinned[0] == 0) break;
     }
@@ -627,14 +633,14 @@ int nms_common(mp_handle* h, const float* prob, const unsigned char* mask, int B
         MP_HIP(hipMalloc(reinterpret_cast<void**>(&h->nms_total), 4));
         MP_HIP(hipMemsetAsync(h->nms_total, 0, 4, s));
     }
-    launch_nms_accumulate(remaining + (round - 1), h->nms_total, s);
+    launch_nms_accumulate(remaining + ((round - 1) & 63), h->nms_total, s);
     launch_select_keypoints(work, B, H, W, topk, K, list_idx, list_score, H * W, kp_yx, kp_score, kp_count,
                             prob_nms, s);
     MP_HIP(hipGetLastError());
-    if (max_rounds == 0 && round >= 64) {
-        MP_HIP(hipMemcpyAsync(h->pinned, remaining + 63, 4, hipMemcpyDeviceToHost, s));
+    if (max_rounds == 0 && round >= cap) {
+        MP_HIP(hipMemcpyAsync(h->pinned, remaining + ((round - 1) & 63), 4, hipMemcpyDeviceToHost, s));
         MP_HIP(hipStreamSynchronize(s));
-        if (h->pinned[0] != 0) return fail(h, MP_ESTATE, "box_nms did not converge within 64 rounds");
+        if (h->pinned[0] != 0) return fail(h, MP_ESTATE, "box_nms did not converge within 4096 rounds");
     }
     return MP_OK;
 }

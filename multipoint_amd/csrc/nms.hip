@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void nms_init_kernel(const float* __restrict__
     reinterpret_cast<f32x4*>(work)[i] = v;
 }
 
-// flags: [2][B*tiles] ping-pong "tile still has undecided pixels"; remaining[round] = #undecided.
+// flags: [2][B*tiles] ping-pong "tile still has undecided pixels"; remaining[round & 63] = #undecided.
 // Work inside a tile is list driven: the undecided pixels are kept as a compact LDS list, one thread
 // per list entry, so an iteration costs O(#undecided) instead of O(tile) -- candidates are sparse
 // (a few % of the pixels) and most of them are decided after two or three iterations.
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work
     if (tid == 0) {
         const int und = cnt[cur];
         fout[tile_id] = und > 0;
-        if (und) atomicAdd(&remaining[round], und);
+        if (und) atomicAdd(&remaining[round & 63], und);      // 64 counter slots, recycled by the host after a sync
     }
 }
 

@@ -112,12 +112,13 @@ class PairPipeline:
             res.done.record(post)
         return res
 
-    def _post(self, out, valid_mask, dev, B, H, W):
+    def _post(self, out, valid_mask, dev, B, H, W, nms_rounds=None):
         prob = out['prob']
         if self.nms > 0:
             K = self.capacity or (self.topk if self.topk > 0 else 4096)
             kp, sc, cnt = U.detect_keypoints(prob, self.nms, self.thr, keep_top_k=self.topk, capacity=K,
-                                             valid_mask=valid_mask, max_rounds=self.nms_rounds)
+                                             valid_mask=valid_mask,
+                                             max_rounds=self.nms_rounds if nms_rounds is None else nms_rounds)
         else:
             if valid_mask is not None:
                 prob = prob * valid_mask.to(prob.dtype)
@@ -144,9 +145,27 @@ class PairPipeline:
             ones = torch.ones_like(optical, dtype=torch.bool)
             mask = self.interleave(mask_optical if mask_optical is not None else ones,
                                    mask_thermal if mask_thermal is not None else ones)
-        # convenience entry: results are ordered behind the caller's stream (run_interleaved() is the
-        # high-throughput entry that leaves them on the side stream)
-        return self.run_interleaved(images, mask).wait()
+        # convenience entry of the dataset drivers: results are ordered behind the caller's stream and the NMS is
+        # exact whatever the heat map looks like (run_interleaved() is the high-throughput entry that leaves the
+        # results on the side stream and reports non-convergence through check_converged())
+        return self.run_converged(images, mask)
+
+    def run_converged(self, images, valid_mask=None, is_optical=None):
+        """One batch with a guaranteed-exact NMS, for the dataset drivers (evaluation loops): the fixed number of
+        asynchronous rounds first; if that left candidates undecided (chains of dependent decisions longer than
+        `nms_rounds` tiles -- smooth ramps across the frame), the post-processing of THIS batch is redone with the
+        synchronising NMS that iterates until nothing is undecided.  Results are ordered behind the caller's stream."""
+        dev = images.device
+        B, _, H, W = images.shape
+        if B % 2:
+            raise ValueError('interleaved batch must hold an even number of images')
+        if is_optical is None:
+            is_optical = (torch.arange(B) % 2 == 0).reshape(B, 1)
+        out = self.net({'image': images, 'is_optical': is_optical})
+        res = self._post(out, valid_mask, dev, B, H, W)
+        if self.nms > 0 and U.nms_unresolved(dev):
+            res = self._post(out, valid_mask, dev, B, H, W, nms_rounds=0)
+        return res
 
     def check_converged(self, device=None):
         """Synchronises; raises if the fixed number of asynchronous NMS rounds was not enough."""

@@ -241,6 +241,48 @@ def test_box_nms_async_rounds_and_overflow(oracle, U):
     assert int(cnt3[0]) == len(ref)
 
 
+def test_box_nms_more_than_64_rounds(oracle, U):
+    """A strictly increasing ramp along a 4096-pixel row is one chain of dependent decisions across 128 tiles: the
+    synchronising NMS keeps iterating (counter slots recycled after 64 rounds) and still equals the greedy algorithm."""
+    W = 4096
+    ramp = np.broadcast_to(np.linspace(0.02, 0.9, W, dtype=np.float32), (8, W)).copy()
+    ramp += (np.arange(8, dtype=np.float32) * 1e-4)[:, None]
+    got = U.box_nms(torch.from_numpy(ramp).cuda(), 4, 0.015).cpu().numpy()
+    assert np.array_equal(got, oracle.box_nms(ramp, 4, 0.015)) and (got > 0).sum() > W // 8
+    kp, sc, cnt = U.detect_keypoints(torch.from_numpy(ramp[None, None]).cuda(), 4, 0.015, capacity=8192, max_rounds=64)
+    assert U.nms_unresolved() > 0                              # 64 fixed rounds are not enough here ...
+    kp, sc, cnt = U.detect_keypoints(torch.from_numpy(ramp[None, None]).cuda(), 4, 0.015, capacity=8192)
+    assert U.nms_unresolved() == 0                             # ... the converging form is
+    ref = oracle.keypoints_from_map(got, 0.015)
+    assert int(cnt[0]) == len(ref) and np.array_equal(kp[0, :len(ref)].cpu().numpy(), ref)
+
+
+def test_pipeline_falls_back_to_converging_nms(oracle, shipped):
+    """PairPipeline.__call__ (the entry of the evaluation drivers) stays exact when the fixed asynchronous rounds are
+    too few: same keypoints and matches as a pipeline with plenty of rounds."""
+    from multipoint_amd.pipeline import PairPipeline
+    net, sd = shipped
+    img = oracle.make_images(3, 4, 120, 160).cuda()
+    pred = {'nms': 4, 'detection_threshold': 0.0005, 'topk': 0,
+            'matching': {'method': 'bfmatcher', 'method_kwargs': {'crossCheck': True}, 'knn_matches': False}}
+    few = PairPipeline(net, pred, capacity=4096, nms_rounds=1)
+    many = PairPipeline(net, pred, capacity=4096, nms_rounds=32)
+    a = few(img[0::2], img[1::2])
+    few.check_converged()
+    b = many(img[0::2], img[1::2])
+    many.check_converged()
+    assert torch.equal(a.kp_count, b.kp_count) and torch.equal(a.match_count, b.match_count)
+    for i in range(4):
+        n = int(a.kp_count[i])
+        assert n > 100 and torch.equal(a.kp_yx[i, :n], b.kp_yx[i, :n])
+    for p in range(2):
+        n = int(a.kp_count[2 * p])
+        assert torch.equal(a.match_idx[p, :n], b.match_idx[p, :n])
+    r = few.run_interleaved(PairPipeline.interleave(img[0::2], img[1::2]))
+    with pytest.raises(RuntimeError, match='undecided'):        # the throughput entry reports instead of repeating
+        few.check_converged()
+
+
 # ------------------------------------------------------------------------------- sampling / matching
 def test_interpolate_descriptors(oracle, U, golden_dir):
     g = np.load(os.path.join(golden_dir, 'sampling.npz'))                     # rows from the reference itself
