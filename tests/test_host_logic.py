@@ -241,3 +241,18 @@ def test_loader_workers_follow_gpu_use():
     aug = d.SyntheticPairs({'num_samples': 2, 'height': 64, 'width': 96, 'augmentation': {'homographic': {'enable': True}}})
     assert d.loader_num_workers(aug, 4) == 0 and d.loader_num_workers(aug, 0) == 0
     assert d.loader_num_workers(d.SyntheticPairs({}), 4) == 4
+
+
+def test_c_host_demo_compiles_against_the_header(tmp_path):
+    """examples/c_host_demo.c is plain C99 over include/multipoint_hip.h: it must compile (-Wall -Werror) and link
+    against the in-tree library without any Python / torch header (run on the GPU box by tests/test_gpu_c_abi.py)."""
+    lib = os.path.join(ROOT, 'multipoint_amd', 'libmultipoint_hip.so')
+    if not os.path.exists(lib):
+        pytest.skip('library not built')
+    out = subprocess.run(['gcc', '-std=c99', '-O2', '-Wall', '-Werror', '-D__HIP_PLATFORM_AMD__', '-I/opt/rocm/include',
+                          '-I' + os.path.join(ROOT, 'include'), os.path.join(ROOT, 'examples', 'c_host_demo.c'),
+                          '-L' + os.path.join(ROOT, 'multipoint_amd'), '-lmultipoint_hip', '-L/opt/rocm/lib', '-lamdhip64',
+                          '-o', str(tmp_path / 'demo')], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-3000:]
+    src = open(os.path.join(ROOT, 'examples', 'c_host_demo.c')).read()
+    assert 'torch' not in src.lower().replace('pytorch in the process', '').replace('no python, no pytorch', '')
