@@ -62,6 +62,7 @@ struct mp_handle {
     DevBuf ws3;                     // matching arg-min arrays
     DevBuf ws4;                     // pair metrics: warped keypoints + inverse match map
     DevBuf nms_state;               // 64 round counters + tile flags
+    DevBuf kp_scratch;              // segment counts + list totals of the keypoint compaction
     int* nms_total = nullptr;       // device: undecided candidates summed over all calls since the last read
     int last_nms_rounds = 0;
     int head_channels = 256;        // width of each 3x3 head convolution (MultiPoint.py:38-53)
@@ -607,6 +608,7 @@ int nms_common(mp_handle* h, const float* prob, const unsigned char* mask, int B
     int rc;
     if ((rc = ensure(h, h->ws2, bytes))) return rc;
     if ((rc = ensure(h, h->nms_state, (size_t)(64 + 2 * ntiles) * 4))) return rc;
+    if ((rc = ensure(h, h->kp_scratch, keypoint_scratch_ints(B, H, W) * 4))) return rc;
     float* work = static_cast<float*>(h->ws2.p);
     int* list_idx = reinterpret_cast<int*>(work + n);
     float* list_score = work + 2 * n;
@@ -635,7 +637,7 @@ int nms_common(mp_handle* h, const float* prob, const unsigned char* mask, int B
     }
     launch_nms_accumulate(remaining + ((round - 1) & 63), h->nms_total, s);
     launch_select_keypoints(work, B, H, W, topk, K, list_idx, list_score, H * W, kp_yx, kp_score, kp_count,
-                            prob_nms, s);
+                            prob_nms, static_cast<int*>(h->kp_scratch.p), s);
     MP_HIP(hipGetLastError());
     if (max_rounds == 0 && round >= cap) {
         MP_HIP(hipMemcpyAsync(h->pinned, remaining + ((round - 1) & 63), 4, hipMemcpyDeviceToHost, s));
@@ -694,6 +696,7 @@ void mp_destroy(mp_handle* h)
     if (h->ws3.p) (void)hipFree(h->ws3.p);
     if (h->ws4.p) (void)hipFree(h->ws4.p);
     if (h->nms_state.p) (void)hipFree(h->nms_state.p);
+    if (h->kp_scratch.p) (void)hipFree(h->kp_scratch.p);
     if (h->nms_total) (void)hipFree(h->nms_total);
     if (h->dummy) (void)hipFree(h->dummy);
     if (h->pinned) (void)hipHostFree(h->pinned);
@@ -909,7 +912,10 @@ int mp_extract_keypoints(mp_handle* h, const float* map, int B, int H, int W, fl
     if (!map || !kp_yx || !kp_count || K <= 0 || B <= 0 || ((long long)H * W) % 4 != 0)
         return fail(h, MP_EINVAL, "mp_extract_keypoints: bad argument (H*W must be a multiple of 4)");
     MP_HIP(hipSetDevice(h->device));
-    launch_extract_threshold(map, B, H, W, thr, K, kp_yx, kp_score, kp_count, static_cast<hipStream_t>(stream));
+    int rc;
+    if ((rc = ensure(h, h->kp_scratch, keypoint_scratch_ints(B, H, W) * 4))) return rc;
+    launch_extract_threshold(map, B, H, W, thr, K, kp_yx, kp_score, kp_count, static_cast<int*>(h->kp_scratch.p),
+                             static_cast<hipStream_t>(stream));
     MP_HIP(hipGetLastError());
     return MP_OK;
 }

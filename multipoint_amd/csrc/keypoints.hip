@@ -6,10 +6,12 @@
 //   * scatter into zeros_like(prob)        multipoint/utils/utils.py:119-120
 //   * torch.nonzero(prob > thr)            predict_align_image_pair.py:170-171, evaluation.py:262-263
 //     -> (N,2) (y,x) rows in row-major order
-// One 1024-thread workgroup per image: ballot/shuffle prefix scans give every kept pixel its
-// row-major rank without atomics (so the output order is deterministic and equals nonzero()),
-// and a 4-pass 8-bit radix select over the fp32 score bits finds the exact k-th score; ties at
-// the threshold are admitted in row-major order.
+// Ballot/shuffle prefix scans give every kept pixel its row-major rank without atomics (so the output order is
+// deterministic and equals nonzero()).  The dense map is compacted by MANY workgroups per image in two passes over
+// 16 Ki-pixel segments -- count, then ordered write at the segment's prefix (a single workgroup per image streams a
+// 1024x1280 map at only ~260 GB/s) -- and one 1024-thread workgroup per image then works on the short list only:
+// a 4-pass 8-bit radix select over the fp32 score bits finds the exact k-th score; ties at the threshold are
+// admitted in row-major order.
 #include "mp_common.h"
 
 namespace {
@@ -45,22 +47,60 @@ __device__ __forceinline__ int block_excl_scan(int c, int* s_wave, int* total)
     return base + inc - c;
 }
 
+constexpr int SEG = 16384;                    // pixels per segment (a multiple of BT * 4)
+
 // MODE 0: kept pixels of an NMS work map (v < 0, score = -v) -> list
 // MODE 1: v > thr -> direct keypoint output (torch.nonzero semantics)
 template <int MODE>
-__device__ int compact_image(const float* __restrict__ img, int n, float thr, int W, int cap,
-                             int* __restrict__ o_idx, float* __restrict__ o_score,
-                             int* __restrict__ o_yx, int* s_wave)
+__device__ __forceinline__ bool keep_px(float v, float thr) { return MODE == 0 ? (v < 0.f) : (v > thr); }
+
+// pass 1: survivors per segment (and zeros_like(prob) for the dense NMS output, utils.py:119)
+template <int MODE>
+__global__ __launch_bounds__(BT) void count_segments_kernel(const float* __restrict__ map, int n, float thr, int nseg,
+                                                            int* __restrict__ seg_count, float* __restrict__ zero_fill)
 {
+    __shared__ int s_wave[BT / 64];
+    const int b = blockIdx.y, sg = blockIdx.x;
+    const float* img = map + (long long)b * n;
+    const int lo = sg * SEG, hi = min(n, lo + SEG);
+    int c = 0;
+    for (int i = lo + threadIdx.x * 4; i < hi; i += BT * 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(img + i);          // n % 4 == 0
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c += keep_px<MODE>(v[e], thr);
+        if (zero_fill) *reinterpret_cast<f32x4*>(zero_fill + (long long)b * n + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    int tot;
+    block_excl_scan(c, s_wave, &tot);
+    if (threadIdx.x == 0) seg_count[b * nseg + sg] = tot;
+}
+
+// pass 2: ordered write of the segment's survivors at the prefix of the segments before it
+template <int MODE>
+__global__ __launch_bounds__(BT) void compact_segments_kernel(const float* __restrict__ map, int n, float thr, int W,
+                                                              int nseg, const int* __restrict__ seg_count, int cap,
+                                                              long long out_stride, int* __restrict__ o_idx,
+                                                              float* __restrict__ o_score, int* __restrict__ o_yx,
+                                                              int* __restrict__ total)
+{
+    __shared__ int s_wave[BT / 64];
+    const int b = blockIdx.y, sg = blockIdx.x;
+    const float* img = map + (long long)b * n;
     int base = 0;
-    for (int start = 0; start < n; start += BT * 4) {
+    for (int i = 0; i < sg; ++i) base += seg_count[b * nseg + i];           // nseg <= ~100: uniform, cached
+    if (total && sg == nseg - 1 && threadIdx.x == 0) total[b] = base + seg_count[b * nseg + sg];
+    if (seg_count[b * nseg + sg] == 0) return;
+    if (MODE == 0) { o_idx += (long long)b * out_stride; o_score += (long long)b * out_stride; }
+    else { o_yx += (long long)b * out_stride * 2; if (o_score) o_score += (long long)b * out_stride; }
+    const int lo = sg * SEG, hi = min(n, lo + SEG);
+    for (int start = lo; start < hi; start += BT * 4) {
         const int i = start + threadIdx.x * 4;
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (i < n) v = *reinterpret_cast<const f32x4*>(img + i);       // n % 4 == 0
+        if (i < hi) v = *reinterpret_cast<const f32x4*>(img + i);
         bool k[4];
         int c = 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { k[e] = MODE == 0 ? (v[e] < 0.f) : (v[e] > thr); c += k[e]; }
+        for (int e = 0; e < 4; ++e) { k[e] = (i < hi) && keep_px<MODE>(v[e], thr); c += k[e]; }
         int tot;
         int pos = base + block_excl_scan(c, s_wave, &tot);
 #pragma unroll
@@ -78,13 +118,12 @@ __device__ int compact_image(const float* __restrict__ img, int n, float thr, in
             }
         base += tot;
     }
-    return base;
 }
 
 __global__ __launch_bounds__(BT) void select_keypoints_kernel(
     const float* __restrict__ work, int H, int W, int topk, int K, int* __restrict__ list_idx,
     float* __restrict__ list_score, int list_cap, int* __restrict__ kp_yx, float* __restrict__ kp_score,
-    int* __restrict__ kp_count, float* __restrict__ prob_nms)
+    int* __restrict__ kp_count, float* __restrict__ prob_nms, const int* __restrict__ list_count)
 {
     __shared__ int s_wave[BT / 64];
     __shared__ unsigned s_hist[256];
@@ -95,14 +134,8 @@ __global__ __launch_bounds__(BT) void select_keypoints_kernel(
     int* lidx = list_idx + (long long)b * list_cap;
     float* lsc = list_score + (long long)b * list_cap;
 
-    if (prob_nms) {   // zeros_like(prob), utils.py:119
-        f32x4* o = reinterpret_cast<f32x4*>(prob_nms + (long long)b * n);
-        for (int i = tid; i < n / 4; i += BT) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-
-    int nk = compact_image<0>(img, n, 0.f, W, list_cap, lidx, lsc, nullptr, s_wave);
-    nk = min(nk, list_cap);
-    __syncthreads();
+    // the list (row-major survivors of image b) was written by compact_segments_kernel<0>; prob_nms is already zero
+    const int nk = min(list_count[b], list_cap);
 
     const int k = (topk > 0) ? topk : 0x7fffffff;      // list outputs are clipped to K below
     unsigned T = 0;          // admit score bits > T, plus the first `need` entries == T
@@ -171,36 +204,35 @@ __global__ __launch_bounds__(BT) void select_keypoints_kernel(
     if (tid == 0 && kp_count) kp_count[b] = out_base;      // may exceed K when topk == 0: overflow
 }
 
-__global__ __launch_bounds__(BT) void extract_threshold_kernel(const float* __restrict__ map, int H,
-                                                              int W, float thr, int K,
-                                                              int* __restrict__ kp_yx,
-                                                              float* __restrict__ kp_score,
-                                                              int* __restrict__ kp_count)
-{
-    __shared__ int s_wave[BT / 64];
-    const int b = blockIdx.x;
-    const int n = H * W;
-    const int nk = compact_image<1>(map + (long long)b * n, n, thr, W, K, nullptr,
-                                    kp_score ? kp_score + (long long)b * K : nullptr,
-                                    kp_yx + (long long)b * K * 2, s_wave);
-    if (threadIdx.x == 0) kp_count[b] = nk;
-}
-
 }  // namespace
 
+// scratch layout behind `seg_scratch`: [B * nseg] segment counts, then [B] list totals
 void launch_select_keypoints(const float* work, int B, int H, int W, int topk, int K, int* list_idx,
                              float* list_score, int list_cap, int* kp_yx, float* kp_score,
-                             int* kp_count, float* prob_nms, hipStream_t s)
+                             int* kp_count, float* prob_nms, int* seg_scratch, hipStream_t s)
 {
     if (B <= 0) return;
+    const int n = H * W, nseg = (n + SEG - 1) / SEG;
+    int* seg_count = seg_scratch;
+    int* list_count = seg_scratch + (size_t)B * nseg;
+    const dim3 g(nseg, B);
+    hipLaunchKernelGGL(count_segments_kernel<0>, g, dim3(BT), 0, s, work, n, 0.f, nseg, seg_count, prob_nms);
+    hipLaunchKernelGGL(compact_segments_kernel<0>, g, dim3(BT), 0, s, work, n, 0.f, W, nseg, seg_count, list_cap,
+                       (long long)list_cap, list_idx, list_score, (int*)nullptr, list_count);
     hipLaunchKernelGGL(select_keypoints_kernel, dim3(B), dim3(BT), 0, s, work, H, W, topk, K, list_idx,
-                       list_score, list_cap, kp_yx, kp_score, kp_count, prob_nms);
+                       list_score, list_cap, kp_yx, kp_score, kp_count, prob_nms, list_count);
 }
 
 void launch_extract_threshold(const float* map, int B, int H, int W, float thr, int K, int* kp_yx,
-                              float* kp_score, int* kp_count, hipStream_t s)
+                              float* kp_score, int* kp_count, int* seg_scratch, hipStream_t s)
 {
     if (B <= 0) return;
-    hipLaunchKernelGGL(extract_threshold_kernel, dim3(B), dim3(BT), 0, s, map, H, W, thr, K, kp_yx,
-                       kp_score, kp_count);
+    const int n = H * W, nseg = (n + SEG - 1) / SEG;
+    const dim3 g(nseg, B);
+    hipLaunchKernelGGL(count_segments_kernel<1>, g, dim3(BT), 0, s, map, n, thr, nseg, seg_scratch, (float*)nullptr);
+    hipLaunchKernelGGL(compact_segments_kernel<1>, g, dim3(BT), 0, s, map, n, thr, W, nseg, seg_scratch, K, (long long)K,
+                       (int*)nullptr, kp_score, kp_yx, kp_count);
 }
+
+// ints of scratch the two launchers above need
+size_t keypoint_scratch_ints(int B, int H, int W) { return (size_t)B * ((H * W + SEG - 1) / SEG) + (size_t)B; }

@@ -124,10 +124,12 @@ void launch_nms_accumulate(const int* remaining_last, int* total, hipStream_t s)
 // outputs kp_yx [B][K][2] int32, kp_score [B][K], kp_count [B]; optional dense map prob_nms
 void launch_select_keypoints(const float* work, int B, int H, int W, int topk, int K,
                              int* list_idx, float* list_score, int list_cap, int* kp_yx,
-                             float* kp_score, int* kp_count, float* prob_nms, hipStream_t s);
+                             float* kp_score, int* kp_count, float* prob_nms, int* seg_scratch, hipStream_t s);
+// ints of device scratch (segment counts + list totals) launch_select_keypoints / launch_extract_threshold need
+size_t keypoint_scratch_ints(int B, int H, int W);
 // plain threshold extraction: (map > thr) -> row-major list (torch.nonzero semantics)
 void launch_extract_threshold(const float* map, int B, int H, int W, float thr, int K, int* kp_yx,
-                              float* kp_score, int* kp_count, hipStream_t s);
+                              float* kp_score, int* kp_count, int* seg_scratch, hipStream_t s);
 
 // bilinear sampling (grid_sample align_corners=True, zeros) + L2 normalise.
 // desc [B][Hc][Wc][D] channels-last; kp_yx [B][K][2]; out [B][K][D]
