@@ -16,7 +16,10 @@
 
 namespace {
 
-constexpr int BT = 1024;                      // threads per workgroup (16 waves)
+// 256 threads and < 64 VGPRs: a workgroup of these kernels fits on a CU NEXT TO a resident Winograd convolution
+// workgroup (408 of 512 registers per lane, 127 of 160 KiB LDS), so the post-processing stream really overlaps the
+// next batch's convolutions instead of waiting for a CU to drain
+constexpr int BT = 256;                       // threads per workgroup (4 waves)
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane)
 {

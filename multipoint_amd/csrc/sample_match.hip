@@ -64,8 +64,9 @@ __global__ __launch_bounds__(256) void sample_desc_kernel(const float* __restric
 
 // best[x] = min over y of (dist(x,y) bits << 32 | y), X rows against all Y rows.
 // grid: (row-block groups, pairs, 2 directions); each wave owns one 32-row block of X.
+// (D = 64: at most 96 registers per lane so that a wave fits beside a resident Winograd convolution wave, see keypoints.hip)
 template <int D>
-__global__ __launch_bounds__(256) void nn_rows_kernel(const float* __restrict__ dA, const int* __restrict__ nA,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 64 ? 5 : 1, D == 64 ? 5 : 8))) void nn_rows_kernel(const float* __restrict__ dA, const int* __restrict__ nA,
                                                      const float* __restrict__ dB, const int* __restrict__ nB,
                                                      long long pair_stride, int count_stride, int K,
                                                      unsigned long long* __restrict__ bestA,
