@@ -257,3 +257,23 @@ def test_c_host_demo_compiles_against_the_header(tmp_path):
     src = open(os.path.join(ROOT, 'examples', 'c_host_demo.c')).read()
     includes = [l for l in src.splitlines() if l.startswith('#include')]
     assert includes and not any('torch' in l or 'Python' in l or 'pybind' in l for l in includes)
+
+
+def test_committed_bench_line_follows_the_contract():
+    """profiles/r01_bench_n1.json is the line `python bench.py` printed on the GPU box: the fields the driver parses."""
+    import json
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_bench_n1.json')))
+    base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
+    assert d['metric'].split(' @')[0] == base['metric'].split(' @')[0] and '480x640' in d['metric']
+    assert d['unit'] == 'image-pairs/s' and d['higher_is_better'] is True and d['scaling'] == 'weak'
+    assert d['n_gpus'] == 1 and d['steps'] > 0 and d['warmup'] >= 0 and d['vs_baseline'] is None
+    assert d['dtype'] == 'f32' and d['data'] == 'synthetic' and 'workload' in d['config'] and 'model' not in d['config']
+    assert abs(d['value'] - 32 * 1e3 / d['ms_per_step']) / d['value'] < 1e-3          # pairs per step / time per step
+    r = d['roofline']
+    assert r['bound'] in ('hbm', 'mfma') and r['unit'] in ('GB/s', 'TFLOP/s') and r['peak'] == 157.3
+    assert abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3
+    assert abs(r['achieved'] - r['flop_per_launch'] / (r['ms_per_launch'] * 1e-3) / 1e12) < 0.05
+    assert r['traffic'] is None or r['traffic'] > 0
+    c = d['cpu_baseline']
+    assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == d['unit'] and c['sample']
+    assert d['parity']['desc_max_abs_err'] <= 1e-4
