@@ -78,6 +78,9 @@ def find_homography(res, reproj_threshold=3.0, max_iters=2000, seed=0):
     return Hm, mask, nin
 
 
+MAX_RANSAC_MATCHES = 3200        # mp_find_homography keeps a pair's correspondences in LDS
+
+
 def find_homography_points(optical_pts, thermal_pts, reproj_threshold=3.0, max_iters=2000, seed=0, device=None):
     """cv2.findHomography(optical_pts, thermal_pts, cv2.RANSAC, reproj_threshold) for ONE set of corresponding (x, y)
     points (integer pixel positions, as keypoints are).  Returns (H 3x3 float64 numpy or None, mask (N,) uint8)."""
@@ -86,6 +89,9 @@ def find_homography_points(optical_pts, thermal_pts, reproj_threshold=3.0, max_i
     n = len(a)
     if n < 4:
         return None, np.zeros(n, np.uint8)
+    if n > MAX_RANSAC_MATCHES:
+        raise ValueError('find_homography_points: at most %d correspondences per call (the pair\'s matches live in LDS); '
+                         'got %d -- keep the closest ones' % (MAX_RANSAC_MATCHES, n))
     dev = _lib.require_cuda(device)
     kp = torch.zeros((2, n, 2), dtype=torch.int32)
     kp[0] = torch.from_numpy(np.ascontiguousarray(a[:, ::-1]).astype(np.int32)); kp[1] = torch.from_numpy(np.ascontiguousarray(b[:, ::-1]).astype(np.int32))
@@ -109,7 +115,15 @@ def compute_descriptor_metrics(net, dataloader, device, config, threshold_keypoi
     """Same signature and result keys as the reference function (evaluation.py:209)."""
     from ..pipeline import PairPipeline
     from .utils import data_to_device
-    pipe = PairPipeline(net, config)
+    from .matching import get_matches
+    # The metrics are ALWAYS computed on cv2.BFMatcher(crossCheck=True) matches, whatever the config says -- the
+    # reference hard-codes that matcher for matches_optical / matches_thermal (evaluation.py:273-282) and uses
+    # config['matching'] only for the matches the homography is estimated from (:332-336).
+    metric_matching = {'method': 'bfmatcher', 'method_kwargs': {'crossCheck': True}, 'knn_matches': False}
+    mcfg = config.get('matching', metric_matching)
+    same_matcher = (mcfg.get('method', 'bfmatcher') == 'bfmatcher' and not mcfg.get('knn_matches', False)
+                    and dict(mcfg.get('method_kwargs', {})) == {'crossCheck': True})
+    pipe = PairPipeline(net, dict(config, matching=metric_matching))
     tp_o, tp_t, dist_o, dist_t, ms_o, ms_t, pts_dist = [], [], [], [], [], [], []
     n_gt_o = n_gt_t = 0
     for data in dataloader:
@@ -122,9 +136,30 @@ def compute_descriptor_metrics(net, dataloader, device, config, threshold_keypoi
         res = pipe(opt['image'], th['image'], opt.get('valid_mask'), th.get('valid_mask'))
         gth = ground_truth_homographies(ho, ht)
         metrics, tp = pair_metrics(res, gth, threshold_keypoints)
-        h_est, _, n_in = find_homography(res, config.get('reprojection_threshold', 3))
         pipe.check_converged()
-        h_est = h_est.cpu().numpy(); n_in = n_in.cpu().numpy()
+        if same_matcher:
+            h_est, _, n_in = find_homography(res, config.get('reprojection_threshold', 3))
+            h_est = h_est.cpu().numpy(); n_in = n_in.cpu().numpy()
+        else:
+            # another matcher for the homography estimate: per pair through get_matches (GPU), like the reference
+            h_est = np.zeros((B, 3, 3)); n_in = np.zeros(B, dtype=np.int64)
+            kp_all = res.kp_yx.cpu().numpy(); cnt_all = res.kp_count.cpu().numpy()
+            Kc = kp_all.shape[1]
+            for p in range(B):
+                no, nt = min(int(cnt_all[2 * p]), Kc), min(int(cnt_all[2 * p + 1]), Kc)
+                if no == 0 or nt == 0:
+                    continue
+                matches = get_matches(res.desc[2 * p, :no], res.desc[2 * p + 1, :nt], mcfg['method'],
+                                      mcfg.get('knn_matches', False), **mcfg.get('method_kwargs', {}))
+                if len(matches) < 4:
+                    continue
+                if len(matches) > MAX_RANSAC_MATCHES:           # one-to-many matchers (thresholdmatcher): closest first
+                    matches = sorted(matches, key=lambda mm: mm.distance)[:MAX_RANSAC_MATCHES]
+                opts = np.array([kp_all[2 * p, mm.queryIdx][::-1] for mm in matches])
+                tpts = np.array([kp_all[2 * p + 1, mm.trainIdx][::-1] for mm in matches])
+                hp, mask = find_homography_points(opts, tpts, config.get('reprojection_threshold', 3), device=device)
+                if hp is not None:
+                    h_est[p] = hp; n_in[p] = int(mask.sum())
         H_o, W_o = opt['image'].shape[2:]
         m = metrics.cpu().numpy(); tp = tp.cpu().numpy()
         midx = res.match_idx.cpu().numpy(); mdist = res.match_dist.cpu().numpy()
