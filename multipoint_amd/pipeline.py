@@ -64,16 +64,23 @@ class PairPipeline:
         self.nms_rounds = nms_rounds
         m = config.get('matching', {'method': 'bfmatcher', 'method_kwargs': {'crossCheck': True},
                                     'knn_matches': False})
+        # the batched pipeline keeps ONE match per optical keypoint (match_idx [P][K]): the mutual-NN matchers.  The other
+        # get_matches modes (ratio test, one-directional nearest, thresholdmatcher) run per pair through
+        # utils.get_matches (mp_match_knn2 / mp_match_threshold), as utils.compute_descriptor_metrics does.
         if m.get('knn_matches', False):
-            raise NotImplementedError('knn_matches is outside the accelerated hot path')
+            raise NotImplementedError('PairPipeline batches the mutual-NN matchers only; use utils.get_matches for knn_matches')
         if m['method'] == 'bfmatcher':
             if not m.get('method_kwargs', {}).get('crossCheck', False):
-                raise NotImplementedError('bfmatcher needs crossCheck: True')
+                raise NotImplementedError('PairPipeline batches the mutual-NN matchers only; use utils.get_matches for '
+                                          'bfmatcher without crossCheck')
             self.match_threshold = -1.0
         elif m['method'] == 'nnmatcher':
             self.match_threshold = float(m.get('method_kwargs', {}).get('threshold', 0.7))
             if self.match_threshold < 0:
                 raise ValueError('\'threshold\' should be non-negative')
+        elif m['method'] in ('thresholdmatcher', 'flann'):
+            raise NotImplementedError("PairPipeline batches the mutual-NN matchers only; use utils.get_matches for '%s'"
+                                      % m['method'])
         else:
             raise ValueError('unknown matching method')
 
