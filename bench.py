@@ -229,6 +229,7 @@ def main():
     roof = None
     wino = os.environ.get('MP_NO_WINOGRAD') != '1' and not c5
     dom = by_name.get('enc.conv1+2') or by_name.get('enc.conv2')
+    n_launch = 1
     if dom:
         # the dominant layer may run as several launches per step (sub-batches pipelined against the first block):
         # flop and time are summed over the launches of a step, launches_per_step says how many there were
@@ -236,31 +237,38 @@ def main():
         ms = float(np.sum([m for m, _ in dom])) / args.steps / n_launch
         flop = float(np.sum([f for _, f in dom])) / args.steps / n_launch
         ach = flop / (ms * 1e-3) / 1e12
+        conv2_flop = 2.0 * 9 * 64 * 64 * H * W * 2 * P          # the MFMA part of a fused conv1+conv2 launch
         if c5:
             roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP16_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(ach / PEAK_FP16_MFMA_TFLOPS, 4), 'traffic': None,
                     'kernel': 'conv_f16_kernel<9,32,true,false> (enc.conv2 64->64 @1024x1280 on v_mfma_f32_32x32x16_f16 '
                               '+ bias/ReLU/BN + 2x2 max-pool)',
-                    'launches_per_step': 1, 'ms_per_launch': round(ms, 4), 'flop_per_launch': flop}
-        elif 'enc.conv1+2' in by_name or not wino:
+                    'launches_per_step': n_launch, 'ms_per_launch': round(ms, 4), 'flop_per_launch': flop}
+        elif not wino:
             roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(),
+                    'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': None,
                     'kernel': 'conv_mfma_kernel<9,32,true,true,false> (encoder conv1 fused into conv2 64->64 @480x640, direct '
                               'convolution + bias/ReLU/BN + 2x2 max-pool)' if 'enc.conv1+2' in by_name
                               else 'conv_mfma_persist_kernel<9,32,true,false> (enc.conv2, direct convolution)',
-                    'launches_per_step': 1, 'ms_per_launch': round(ms, 4), 'flop_per_launch': flop}
+                    'launches_per_step': n_launch, 'ms_per_launch': round(ms, 4), 'flop_per_launch': flop}
         else:
+            fused = 'enc.conv1+2' in by_name
+            mfma_flop = (conv2_flop if fused else flop) / 2.25
             roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
                     'frac': round(ach / PEAK_FP32_MFMA_TFLOPS, 4), 'traffic': pmc_traffic(),
-                    'kernel': 'conv_wino_kernel<true,false> (enc.conv2 64->64 @480x640 by Winograd F(2x2,3x3) on '
-                              'v_mfma_f32_32x32x2_f32 + bias/ReLU/BN + 2x2 max-pool)',
+                    'kernel': ('conv_wino_kernel<true,false,true> (encoder conv1 -- Cin = 1, computed on the vector pipe inside '
+                               'the loader -- fused into enc.conv2 64->64 @480x640 by Winograd F(2x2,3x3) on '
+                               'v_mfma_f32_32x32x2_f32 + bias/ReLU/BN + 2x2 max-pool)') if fused else
+                              ('conv_wino_kernel<true,false,false> (enc.conv2 64->64 @480x640 by Winograd F(2x2,3x3) on '
+                               'v_mfma_f32_32x32x2_f32 + bias/ReLU/BN + 2x2 max-pool)'),
                     'launches_per_step': n_launch, 'ms_per_launch': round(ms, 4), 'flop_per_launch': flop,
-                    'mfma_flop_executed_per_launch': flop / 2.25,
-                    'mfma_executed_frac': round(ach / 2.25 / PEAK_FP32_MFMA_TFLOPS, 4),
-                    'note': 'achieved/frac use the ALGORITHMIC direct-convolution FLOPs (contract); Winograd F(2x2,3x3) issues '
-                            '2.25x fewer MFMA FLOPs for the same fp32 result (within the unchanged parity tolerances), so '
-                            'frac > 1 is expected; mfma_executed_frac is the matrix-pipe utilisation.  Timed while the '
-                            'previous batch\'s NMS/top-k/sampling/matching kernels run on the side stream.'}
+                    'mfma_flop_executed_per_launch': mfma_flop,
+                    'mfma_executed_frac': round(mfma_flop / (ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4),
+                    'note': 'achieved/frac use the ALGORITHMIC direct-convolution FLOPs of the launch (contract): '
+                            + ('conv1 2*9*1*64 + conv2 2*9*64*64 per pixel; ' if fused else '') +
+                            'Winograd F(2x2,3x3) issues 2.25x fewer MFMA FLOPs for the same fp32 result (within the unchanged '
+                            'parity tolerances), so frac > 1 is expected; mfma_executed_frac is the matrix-pipe utilisation.  '
+                            'Timed while the previous batch\'s NMS/top-k/sampling/matching kernels run on the side stream.'}
     conv_ms = sum(float(np.sum([m for m, _ in v])) / args.steps for k, v in by_name.items())
     conv_flop = sum(float(np.sum([f for _, f in v])) / args.steps for v in by_name.values())
     layers = {k: round(float(np.sum([m for m, _ in v])) / args.steps, 4) for k, v in by_name.items()}

@@ -71,6 +71,7 @@ struct mp_handle {
     int persist = 8;                // persistent conv workgroups for launches with >= this many items per CU
                                     // (MP_NO_PERSIST=1: never; MP_PERSIST_MIN_ITEMS=n overrides the threshold)
     bool fuse_first = true;         // fuse the Cin=1 block into the second convolution (MP_NO_FUSE=1 disables)
+    bool wino_fuse = true;          // ... also on the Winograd path (MP_NO_WINO_FUSE=1: standalone first block + Winograd conv2)
     int* pinned = nullptr;          // small pinned host scratch (img lists, counters)
     bool prof = false;
     std::vector<ProfEntry> prof_entries;
@@ -473,9 +474,9 @@ void run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride,
     prof_begin(h, fuse ? "enc.conv1+2" : L.name,
                2.0 * L.taps * L.cin * L.cout * (double)B * H * W + (fuse ? 2.0 * 9 * 64 * (double)B * H * W : 0.0), s);
     if (fuse) { p.img = images; p.w1 = fuse->w; p.b1 = fuse->bias; p.s1 = fuse->scale; p.t1 = fuse->shift; }
-    if (L.taps == 9 && !fuse && L.upack && h->wino) {
+    if (L.taps == 9 && L.upack && h->wino && (!fuse || (L.pool && L.cin == 64))) {
         p.wpack = L.upack;
-        launch_conv_wino(p, L.pool, s);
+        launch_conv_wino(p, L.pool, fuse != nullptr, s);
     } else {
         launch_conv_mfma(p, L.taps, mbw, L.pool, fuse != nullptr, s);
     }
@@ -676,6 +677,7 @@ int mp_create(mp_handle** out, int device)
     hh->device = device;
     { const char* e = getenv("MP_NO_FUSE"); hh->fuse_first = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_NO_WINOGRAD"); hh->wino = !(e && e[0] == '1'); }
+    { const char* e = getenv("MP_NO_WINO_FUSE"); hh->wino_fuse = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_PERSIST_MIN_ITEMS"); if (e && atoi(e) > 0) hh->persist = atoi(e); }
     { const char* e = getenv("MP_NO_PERSIST"); if (e && e[0] == '1') hh->persist = 0; }
     if (hipHostMalloc(reinterpret_cast<void**>(&hh->pinned), 4096) != hipSuccess) {
@@ -835,7 +837,7 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
         c1.channels = E.first.channels;
         // the fused loader is a 64-channel direct-convolution kernel; with Winograd on, the standalone first block +
         // Winograd second convolution is faster than the fused direct kernel
-        const bool fuse1 = h->fuse_first && h->cfg.channel_version == 0 && !h->wino;
+        const bool fuse1 = h->fuse_first && h->cfg.channel_version == 0 && (!h->wino || h->wino_fuse);
         if (!fuse1) {
             prof_begin(h, "enc.conv1", 2.0 * 9 * 64 * (double)nb * H * W, s);
             launch_conv_first(c1, s);

@@ -13,6 +13,12 @@
 // K is walked in units of 8 input channels, software-pipelined three deep through double-buffered LDS:
 //   while unit n is multiplied,  unit n+1 is transformed (raw patch -> V, 32 packed adds per thread),
 //   the raw 18x18x8 patch of unit n+2 goes VGPR -> LDS, and the patch of unit n+3 is fetched global -> VGPR.
+//
+// FUSE (encoder conv2 only): the input of this convolution is the first encoder block (ReflectionPad -> Conv2d(1,64,3)
+// -> ReLU -> BN, Cin = 1).  Instead of reading its 64-channel output from HBM, the raw patch of a unit (18x18 pixels x
+// 8 channels) is computed from a 20x20 image patch in LDS: per thread and unit three 4-channel vectors = 54 packed
+// multiply-adds + 27 LDS reads, spread over the MFMA slots of the unit.  This removes the first block's launch and its
+// 78.6 MB per image round trip through HBM (the same k-ordered fmaf chain as conv_first_kernel).
 #include "mp_common.h"
 
 #include <algorithm>
@@ -47,6 +53,8 @@ constexpr int RS = 12;                       // raw patch pixel stride in floats
                                              // reads of 8 neighbouring tiles then hit 64 distinct banks)
 constexpr int RAWBUF = NPX * RS;             // floats per raw buffer (15552 B)
 constexpr int NRAW = (NPX * 2 + 255) / 256;  // raw 16-byte vectors per thread (3)
+constexpr int IT = WT + 4;                   // image patch edge of the fused first block (20)
+constexpr int NPL = (IT * IT + 255) / 256;   // image patch pixels per thread (2)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -68,12 +76,16 @@ __device__ __forceinline__ float acc_read(float a)
     return x;
 }
 
-template <bool POOL, bool BNF>
+template <bool POOL, bool BNF, bool FUSE>
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
 {
+    static_assert(!FUSE || POOL, "the fused first block feeds the pooled second encoder convolution");
     __shared__ __attribute__((aligned(16))) float Vs[2 * VBUF];
     __shared__ __attribute__((aligned(16))) float raw[2 * RAWBUF];
     __shared__ __attribute__((aligned(16))) float prm[3 * 64];
+    __shared__ __attribute__((aligned(16))) float its[FUSE ? 2 * IT * IT : 4];     // image patches of two items
+    __shared__ __attribute__((aligned(16))) float w1s[FUSE ? 9 * 64 : 4];          // first-block weights [tap][channel]
+    __shared__ __attribute__((aligned(16))) float p1s[FUSE ? 3 * 64 : 4];          // its bias | BN scale | BN shift
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -116,7 +128,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                 for (int j = 0; j < NRAW; ++j) {
                     const int f = tid + j * 256, q = f >> 1;
                     const int py = q / PW, px = q - py * PW;
-                    roff[j] = (f < NPX * 2) ? (py * p.W + px) * p.in_cstride + (f & 1) * 4 : 0;
+                    if constexpr (FUSE) roff[j] = (f < NPX * 2) ? (py + 1) * IT + (px + 1) : IT + 1;   // window centre in the image patch
+                    else roff[j] = (f < NPX * 2) ? (py * p.W + px) * p.in_cstride + (f & 1) * 4 : 0;
                 }
                 roff_rel = true;
             }
@@ -137,7 +150,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                 } else {
                     gy = reflect_clamp_w(gy, p.H); gx = reflect_clamp_w(gx, p.W);
                 }
-                if (!zero) off = (gy * p.W + gx) * p.in_cstride + (f & 1) * 4;
+                if constexpr (FUSE) {
+                    // centre of the first-block window inside the image patch (patch origin = tile - 2); pixels of partial
+                    // tiles far outside the image are clamped (their outputs are never stored)
+                    const int qy = min(max(gy, w.y0 - 1), w.y0 + WT), qx = min(max(gx, w.x0 - 1), w.x0 + WT);
+                    if (!zero) off = (qy - w.y0 + 2) * IT + (qx - w.x0 + 2);
+                } else {
+                    if (!zero) off = (gy * p.W + gx) * p.in_cstride + (f & 1) * 4;
+                }
             }
             roff[j] = off;
         }
@@ -164,6 +184,82 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                 if ((rzero >> j) & 1u) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 *reinterpret_cast<f32x4*>(&raw[buf * RAWBUF + (f >> 1) * RS + (f & 1) * 4]) = v;
             }
+        }
+    };
+
+    // ---- fused first block (FUSE): raw vector j of the cursor's unit computed from the image patch ----
+    f32x4 wreg[FUSE ? 9 : 1], pb4, ps4, pt4;      // weights / bias / scale / shift of this thread's channel quad
+    f32x2 fa[FUSE ? NRAW : 1][2];
+    float pl[NPL];
+    int ld_pb = 0;                                 // image patch buffer of the item the load cursor is in
+    auto patch_load = [&](const Where& w) __attribute__((always_inline)) {
+        const float* image = p.img + (long long)w.img * p.H * p.W;
+#pragma unroll
+        for (int u = 0; u < NPL; ++u) {
+            const int f = tid + u * 256;
+            const int r = f / IT, c = f - r * IT;
+            int gy = w.y0 - 2 + r, gx = w.x0 - 2 + c;
+            float v = 0.f;
+            if (f < IT * IT) {
+                if (p.pad_zero) {
+                    const bool zero = (gy < 0) | (gy >= p.H) | (gx < 0) | (gx >= p.W);
+                    gy = min(max(gy, 0), p.H - 1); gx = min(max(gx, 0), p.W - 1);
+                    v = image[gy * p.W + gx];
+                    if (zero) v = 0.f;
+                } else {
+                    v = image[reflect_clamp_w(gy, p.H) * p.W + reflect_clamp_w(gx, p.W)];
+                }
+            }
+            pl[u] = v;
+        }
+    };
+    auto patch_put = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < NPL; ++u) {
+            const int f = tid + u * 256;
+            if (f < IT * IT) its[buf * IT * IT + f] = pl[u];
+        }
+    };
+    auto f_weights = [&](int chunk, int part) __attribute__((always_inline)) {
+        const int c4 = chunk * UC + (tid & 1) * 4;
+        if (part == 0) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) wreg[k] = *reinterpret_cast<const f32x4*>(&w1s[k * 64 + c4]);
+        } else {
+#pragma unroll
+            for (int k = 5; k < 9; ++k) wreg[k] = *reinterpret_cast<const f32x4*>(&w1s[k * 64 + c4]);
+            pb4 = *reinterpret_cast<const f32x4*>(&p1s[c4]);
+            ps4 = *reinterpret_cast<const f32x4*>(&p1s[64 + c4]);
+            pt4 = *reinterpret_cast<const f32x4*>(&p1s[128 + c4]);
+        }
+    };
+    // Row kh of vector j's 3x3 window: three LDS reads + 12 multiply-adds (k order 0..8 as in conv_first_kernel).
+    // The reads are placed in the MFMA slots of the unit; the arithmetic is written there too, but LLVM sinks it towards
+    // its use (the LDS write of the next unit) into one block behind the unit's MFMAs -- which is also the fastest
+    // arrangement measured: pinned into the slots the same instructions cost 0.5 ms more per launch (every vector
+    // instruction issued into an fp32 MFMA stream stalls it), and hand-packed v_pk_fma_f32 with op_sel broadcasts was
+    // slower than the scalar FMAs the compiler picks (7.2-7.6 against 7.06 ms).
+    auto f_row = [&](int j, int kh) __attribute__((always_inline)) {
+        const int o = ld_pb * IT * IT + (roff[j] >= 0 ? roff[j] : IT + 1) + (kh - 1) * IT;
+        const float x[3] = {its[o - 1], its[o], its[o + 1]};
+        if (kh == 0) { fa[j][0] = f32x2{0.f, 0.f}; fa[j][1] = f32x2{0.f, 0.f}; }
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const f32x4 wv = wreg[kh * 3 + kw];
+            fa[j][0] = __builtin_elementwise_fma(f32x2{x[kw], x[kw]}, f32x2{wv[0], wv[1]}, fa[j][0]);
+            fa[j][1] = __builtin_elementwise_fma(f32x2{x[kw], x[kw]}, f32x2{wv[2], wv[3]}, fa[j][1]);
+        }
+    };
+    auto f_act = [&](int j) __attribute__((always_inline)) {
+        f32x2 v0 = fa[j][0] + f32x2{pb4[0], pb4[1]}, v1 = fa[j][1] + f32x2{pb4[2], pb4[3]};
+        const f32x2 s0 = {ps4[0], ps4[1]}, s1 = {ps4[2], ps4[3]}, t0 = {pt4[0], pt4[1]}, t1 = {pt4[2], pt4[3]};
+        if (BNF) {
+            v0 = v0 * s0 + t0; v1 = v1 * s1 + t1;
+            rreg[j] = f32x4{relu_w(v0[0]), relu_w(v0[1]), relu_w(v1[0]), relu_w(v1[1])};
+        } else {
+            v0 = f32x2{relu_w(v0[0]), relu_w(v0[1])} * s0 + t0;
+            v1 = f32x2{relu_w(v1[0]), relu_w(v1[1])} * s1 + t1;
+            rreg[j] = f32x4{v0[0], v0[1], v1[0], v1[1]};
         }
     };
 
@@ -225,14 +321,37 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                 ld_item = decode(ld_next_item);
                 rbase = raw_offsets(ld_item);
                 ld_next_item += stride;
+                ld_pb ^= 1;                               // FUSE: that item's image patch was staged during units 0-1
             } else {
                 ld_has_item = false;                      // past the end: dummy re-reads of the last item
             }
         }
     };
-    raw_mark(); raw_load(rbase, ld_chunk); ld_advance();          // raw(0)
+    auto raw_make = [&]() __attribute__((always_inline)) {        // the cursor's raw unit -> rreg (not interleaved)
+        raw_mark();
+        if constexpr (FUSE) {
+            f_weights(ld_chunk, 0); f_weights(ld_chunk, 1);
+#pragma unroll
+            for (int j = 0; j < NRAW; ++j) {
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) f_row(j, kh);
+                f_act(j);
+            }
+        } else {
+            raw_load(rbase, ld_chunk);
+        }
+        ld_advance();
+    };
+    if constexpr (FUSE) {
+        for (int f = tid; f < 9 * 64; f += 256) w1s[f] = p.w1[f];
+        if (tid < 64) { p1s[tid] = p.b1[tid]; p1s[64 + tid] = p.s1[tid]; p1s[128 + tid] = p.t1[tid]; }
+        patch_load(cur);
+        patch_put(0);
+        __syncthreads();
+    }
+    raw_make();                                                   // raw(0)
     raw_put(0);
-    raw_mark(); raw_load(rbase, ld_chunk); ld_advance();          // raw(1)
+    raw_make();                                                   // raw(1)
     load_prm(cur.slice);
     __syncthreads();
 #pragma unroll
@@ -241,7 +360,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
 #pragma unroll
     for (int e = 0; e < 16; ++e) tf_write(0, e);
     raw_put(1);
-    raw_mark(); raw_load(rbase, ld_chunk); ld_advance();          // raw(2): written during unit 0
+    raw_make();                                                   // raw(2): written during unit 0
     const f32x4* up = u_ptr(cur.slice);
 #pragma unroll
     for (int s = 0; s < PFW; ++s) bfr[s] = up[s * 64];
@@ -249,6 +368,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
 
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int n = 0;                                            // unit counter (parity selects the LDS buffers)
+    int cur_pb = 0;                                       // FUSE: image patch buffer of the item being multiplied
 #ifdef MP_TIMING
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool t_on = ((POOL ? p.H : -p.H) == g_timing_w_sel);      // select a pooled launch by +H, an un-pooled one by -H
@@ -261,6 +381,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
         const int next_slice = has_next ? (int)(item_next - (int)udiv((unsigned)item_next, p.magic_slices, (unsigned)p.nslices) * p.nslices)
                                         : cur.slice;
         const f32x4* unext = u_ptr(next_slice);
+        Where nxt_w = cur;
+        if constexpr (FUSE) { if (has_next) nxt_w = decode(item_next); }
 
         auto unit_body = [&](const int c, auto first_tag) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_tag)::value;
@@ -296,8 +418,24 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                     } else {
                         // raw(n+2): VGPR -> raw[vb] (its previous content was transformed during unit n-1), then the
                         // loads of raw(n+3) reuse the registers
-                        if (s == 1) raw_put(vb);
-                        else if (s == 3) { raw_mark(); raw_load(rbase, ld_chunk); ld_advance(); }
+                        if constexpr (FUSE) {
+                            // raw(n+3) is COMPUTED from the image patch: see f_row
+                            if (s == 0) f_weights(ld_chunk, 0);
+                            else if (s == 1) raw_put(vb);
+                            else if (s == 2) f_weights(ld_chunk, 1);
+                            else if (s < 12) f_row((s - 3) / 3, (s - 3) % 3);
+                            else if (s < 15) { if (s == 12) raw_mark(); f_act(s - 12); }
+                            else {
+                                ld_advance();
+                                // the next item's image patch: fetched during unit 0, staged during unit 1 -- the load
+                                // cursor enters that item in unit NC-4
+                                if (c == 0 && has_next) patch_load(nxt_w);
+                                else if (c == 1 && has_next) patch_put(cur_pb ^ 1);
+                            }
+                        } else {
+                            if (s == 1) raw_put(vb);
+                            else if (s == 3) { raw_mark(); raw_load(rbase, ld_chunk); ld_advance(); }
+                        }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
@@ -423,10 +561,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
         item = item_next;
         cur = decode(item);
         up = unext;
+        cur_pb ^= 1;
     }
 }
 
-template <bool POOL>
+template <bool POOL, bool FUSE>
 void launch_w(const ConvParams& p, hipStream_t s)
 {
     ConvParams q = p;
@@ -440,14 +579,17 @@ void launch_w(const ConvParams& p, hipStream_t s)
     q.nitems = (int)nitems;
     const unsigned grid = (unsigned)std::min<long long>(256, ((nitems + 7) / 8) * 8);
     const ConvParams& pp = q;
-    if (p.bn_first) hipLaunchKernelGGL((conv_wino_kernel<POOL, true>), dim3(grid), dim3(256), 0, s, pp);
-    else hipLaunchKernelGGL((conv_wino_kernel<POOL, false>), dim3(grid), dim3(256), 0, s, pp);
+    if (p.bn_first) hipLaunchKernelGGL((conv_wino_kernel<POOL, true, FUSE>), dim3(grid), dim3(256), 0, s, pp);
+    else hipLaunchKernelGGL((conv_wino_kernel<POOL, false, FUSE>), dim3(grid), dim3(256), 0, s, pp);
 }
 
 }  // namespace
 
 // p.wpack must point at the Winograd-domain weights packed by pack_wino_weights() (api.hip)
-void launch_conv_wino(const ConvParams& p, bool pool, hipStream_t s)
+// fuse1: p.img / p.w1 / p.b1 / p.s1 / p.t1 describe the first encoder block, p.in is not read (pooled, cin == 64 only)
+void launch_conv_wino(const ConvParams& p, bool pool, bool fuse1, hipStream_t s)
 {
-    if (pool) launch_w<true>(p, s); else launch_w<false>(p, s);
+    if (fuse1) launch_w<true, true>(p, s);
+    else if (pool) launch_w<true, false>(p, s);
+    else launch_w<false, false>(p, s);
 }

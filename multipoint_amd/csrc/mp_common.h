@@ -56,7 +56,7 @@ struct Conv1Params {
 void launch_conv_mfma(const ConvParams& p, int taps, int mbw, bool pool, bool fuse1, hipStream_t s);
 void launch_conv_first(const Conv1Params& p, hipStream_t s);
 // Winograd F(2x2,3x3) flavour of the 3x3 layers (conv_wino.hip); p.wpack = weights packed by pack_wino_weights()
-void launch_conv_wino(const ConvParams& p, bool pool, hipStream_t s);
+void launch_conv_wino(const ConvParams& p, bool pool, bool fuse1, hipStream_t s);
 
 // fp16 path (mixed_precision: activations and packed weights fp16, fp32 accumulate; conv_f16.hip).
 // Same tiling as ConvParams; a chunk is 64 input channels, so cin must be a multiple of 64.

@@ -35,7 +35,8 @@ def counters(prefix):
 
 shutil.copy(os.path.join(src, 'stats_kernel_stats.csv'), os.path.join(dst, tag + '_bench_kernel_stats.csv'))
 
-DOMINANT = 'conv_wino_kernel<true, false>'      # encoder conv2 (Winograd) @480x640: the largest-grid launch of this kernel
+# encoder conv1+conv2 (first block fused into the Winograd conv2) @480x640: one launch per step of this instantiation
+DOMINANT = 'conv_wino_kernel<true, false, true>'
 
 fetch, write = counters('fetch'), counters('write')
 kernels = []
@@ -51,9 +52,8 @@ out = {'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, 
                'launch; fetch_bytes_corrected = 2 x FETCH_SIZE (gfx950 reports half of a wide 16 B/lane coalesced '
                'stream, MI355X_MICROARCH.md section HBM); WRITE_SIZE uncalibrated',
        'kernels': kernels, 'dominant_kernel': DOMINANT}
-# the pooled Winograd kernel is launched three times per step with the same grid (conv2, conv4, conv6, in this order):
-# separate them by launch position and report conv2 (the dominant launch)
-NPER = 3
+# the fused instantiation is launched once per step (conv4 / conv6 use conv_wino_kernel<true, false, false>)
+NPER = 1
 key = (DOMINANT, [k for k in fetch if k[0] == DOMINANT][0][1]) if any(k[0] == DOMINANT for k in fetch) else None
 if key:
     f = fetch[key]['FETCH_SIZE']; w = write.get(key, {}).get('WRITE_SIZE', [])
