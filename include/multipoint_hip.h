@@ -110,9 +110,10 @@ int mp_detect_keypoints(mp_handle* h, const float* prob, const unsigned char* va
  * the previous mp_nms_unresolved (0 = every result exact); resets the counter.  Synchronises `stream`. */
 int mp_nms_unresolved(mp_handle* h, int* unresolved, void* stream);
 
-/* replaces torch.nonzero(map > thr) on an arbitrary dense map. */
-int mp_extract_keypoints(mp_handle* h, const float* map, int B, int H, int W, float thr, int K,
-                         int* kp_yx, float* kp_score, int* kp_count, void* stream);
+/* replaces torch.nonzero(map > thr) on an arbitrary dense map; with valid_mask (uint8 [B][H][W] or NULL) it is
+ * torch.nonzero((map > thr) * valid_mask) (multipoint/utils/evaluation.py:156-157, predict_keypoints.py:176-178). */
+int mp_extract_keypoints(mp_handle* h, const float* map, const unsigned char* valid_mask, int B, int H, int W, float thr,
+                         int K, int* kp_yx, float* kp_score, int* kp_count, void* stream);
 
 /* replaces utils.interpolate_descriptors (multipoint/utils/utils.py:159-167).
  *   desc [B][Hc][Wc][D] channels-last, out [B][K][D]; rows k >= kp_count[b] are left untouched. */

@@ -42,7 +42,7 @@ SIGNATURES = {
     'mp_detect_keypoints': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float,
                                     c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'mp_nms_unresolved': (c_int, [c_void_p, ctypes.POINTER(c_int), c_void_p]),
-    'mp_extract_keypoints': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p,
+    'mp_extract_keypoints': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p,
                                      c_void_p, c_void_p, c_void_p]),
     'mp_sample_descriptors': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
                                       c_void_p, c_void_p, c_int, c_void_p, c_void_p]),

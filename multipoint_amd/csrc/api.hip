@@ -907,8 +907,8 @@ int mp_nms_unresolved(mp_handle* h, int* unresolved, void* stream)
     return MP_OK;
 }
 
-int mp_extract_keypoints(mp_handle* h, const float* map, int B, int H, int W, float thr, int K, int* kp_yx,
-                         float* kp_score, int* kp_count, void* stream)
+int mp_extract_keypoints(mp_handle* h, const float* map, const unsigned char* valid_mask, int B, int H, int W, float thr,
+                         int K, int* kp_yx, float* kp_score, int* kp_count, void* stream)
 {
     if (!h) return MP_EINVAL;
     if (!map || !kp_yx || !kp_count || K <= 0 || B <= 0 || ((long long)H * W) % 4 != 0)
@@ -916,7 +916,7 @@ int mp_extract_keypoints(mp_handle* h, const float* map, int B, int H, int W, fl
     MP_HIP(hipSetDevice(h->device));
     int rc;
     if ((rc = ensure(h, h->kp_scratch, keypoint_scratch_ints(B, H, W) * 4))) return rc;
-    launch_extract_threshold(map, B, H, W, thr, K, kp_yx, kp_score, kp_count, static_cast<int*>(h->kp_scratch.p),
+    launch_extract_threshold(map, valid_mask, B, H, W, thr, K, kp_yx, kp_score, kp_count, static_cast<int*>(h->kp_scratch.p),
                              static_cast<hipStream_t>(stream));
     MP_HIP(hipGetLastError());
     return MP_OK;

@@ -60,7 +60,8 @@ __device__ __forceinline__ bool keep_px(float v, float thr) { return MODE == 0 ?
 // pass 1: survivors per segment (and zeros_like(prob) for the dense NMS output, utils.py:119)
 template <int MODE>
 __global__ __launch_bounds__(BT) void count_segments_kernel(const float* __restrict__ map, int n, float thr, int nseg,
-                                                            int* __restrict__ seg_count, float* __restrict__ zero_fill)
+                                                            int* __restrict__ seg_count, float* __restrict__ zero_fill,
+                                                            const unsigned char* __restrict__ mask)
 {
     __shared__ int s_wave[BT / 64];
     const int b = blockIdx.y, sg = blockIdx.x;
@@ -69,8 +70,10 @@ __global__ __launch_bounds__(BT) void count_segments_kernel(const float* __restr
     int c = 0;
     for (int i = lo + threadIdx.x * 4; i < hi; i += BT * 4) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(img + i);          // n % 4 == 0
+        const uchar4 m = mask ? *reinterpret_cast<const uchar4*>(mask + (long long)b * n + i) : make_uchar4(1, 1, 1, 1);
+        const bool mk[4] = {m.x != 0, m.y != 0, m.z != 0, m.w != 0};      // (prob > thr) * valid_mask, evaluation.py:156-157
 #pragma unroll
-        for (int e = 0; e < 4; ++e) c += keep_px<MODE>(v[e], thr);
+        for (int e = 0; e < 4; ++e) c += keep_px<MODE>(v[e], thr) && mk[e];
         if (zero_fill) *reinterpret_cast<f32x4*>(zero_fill + (long long)b * n + i) = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     int tot;
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(BT) void compact_segments_kernel(const float* __res
                                                               int nseg, const int* __restrict__ seg_count, int cap,
                                                               long long out_stride, int* __restrict__ o_idx,
                                                               float* __restrict__ o_score, int* __restrict__ o_yx,
-                                                              int* __restrict__ total)
+                                                              int* __restrict__ total, const unsigned char* __restrict__ mask)
 {
     __shared__ int s_wave[BT / 64];
     const int b = blockIdx.y, sg = blockIdx.x;
@@ -99,11 +102,16 @@ __global__ __launch_bounds__(BT) void compact_segments_kernel(const float* __res
     for (int start = lo; start < hi; start += BT * 4) {
         const int i = start + threadIdx.x * 4;
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (i < hi) v = *reinterpret_cast<const f32x4*>(img + i);
+        uchar4 m = make_uchar4(1, 1, 1, 1);
+        if (i < hi) {
+            v = *reinterpret_cast<const f32x4*>(img + i);
+            if (mask) m = *reinterpret_cast<const uchar4*>(mask + (long long)b * n + i);
+        }
+        const bool mk[4] = {m.x != 0, m.y != 0, m.z != 0, m.w != 0};
         bool k[4];
         int c = 0;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) { k[e] = (i < hi) && keep_px<MODE>(v[e], thr); c += k[e]; }
+        for (int e = 0; e < 4; ++e) { k[e] = (i < hi) && keep_px<MODE>(v[e], thr) && mk[e]; c += k[e]; }
         int tot;
         int pos = base + block_excl_scan(c, s_wave, &tot);
 #pragma unroll
@@ -219,22 +227,23 @@ void launch_select_keypoints(const float* work, int B, int H, int W, int topk, i
     int* seg_count = seg_scratch;
     int* list_count = seg_scratch + (size_t)B * nseg;
     const dim3 g(nseg, B);
-    hipLaunchKernelGGL(count_segments_kernel<0>, g, dim3(BT), 0, s, work, n, 0.f, nseg, seg_count, prob_nms);
+    hipLaunchKernelGGL(count_segments_kernel<0>, g, dim3(BT), 0, s, work, n, 0.f, nseg, seg_count, prob_nms,
+                       (const unsigned char*)nullptr);
     hipLaunchKernelGGL(compact_segments_kernel<0>, g, dim3(BT), 0, s, work, n, 0.f, W, nseg, seg_count, list_cap,
-                       (long long)list_cap, list_idx, list_score, (int*)nullptr, list_count);
+                       (long long)list_cap, list_idx, list_score, (int*)nullptr, list_count, (const unsigned char*)nullptr);
     hipLaunchKernelGGL(select_keypoints_kernel, dim3(B), dim3(BT), 0, s, work, H, W, topk, K, list_idx,
                        list_score, list_cap, kp_yx, kp_score, kp_count, prob_nms, list_count);
 }
 
-void launch_extract_threshold(const float* map, int B, int H, int W, float thr, int K, int* kp_yx,
+void launch_extract_threshold(const float* map, const unsigned char* mask, int B, int H, int W, float thr, int K, int* kp_yx,
                               float* kp_score, int* kp_count, int* seg_scratch, hipStream_t s)
 {
     if (B <= 0) return;
     const int n = H * W, nseg = (n + SEG - 1) / SEG;
     const dim3 g(nseg, B);
-    hipLaunchKernelGGL(count_segments_kernel<1>, g, dim3(BT), 0, s, map, n, thr, nseg, seg_scratch, (float*)nullptr);
+    hipLaunchKernelGGL(count_segments_kernel<1>, g, dim3(BT), 0, s, map, n, thr, nseg, seg_scratch, (float*)nullptr, mask);
     hipLaunchKernelGGL(compact_segments_kernel<1>, g, dim3(BT), 0, s, map, n, thr, W, nseg, seg_scratch, K, (long long)K,
-                       (int*)nullptr, kp_score, kp_yx, kp_count);
+                       (int*)nullptr, kp_score, kp_yx, kp_count, mask);
 }
 
 // ints of scratch the two launchers above need

@@ -128,7 +128,7 @@ void launch_select_keypoints(const float* work, int B, int H, int W, int topk, i
 // ints of device scratch (segment counts + list totals) launch_select_keypoints / launch_extract_threshold need
 size_t keypoint_scratch_ints(int B, int H, int W);
 // plain threshold extraction: (map > thr) -> row-major list (torch.nonzero semantics)
-void launch_extract_threshold(const float* map, int B, int H, int W, float thr, int K, int* kp_yx,
+void launch_extract_threshold(const float* map, const unsigned char* mask, int B, int H, int W, float thr, int K, int* kp_yx,
                               float* kp_score, int* kp_count, int* seg_scratch, hipStream_t s);
 
 // bilinear sampling (grid_sample align_corners=True, zeros) + L2 normalise.

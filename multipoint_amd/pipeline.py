@@ -127,9 +127,7 @@ class PairPipeline:
                                              valid_mask=valid_mask,
                                              max_rounds=self.nms_rounds if nms_rounds is None else nms_rounds)
         else:
-            if valid_mask is not None:
-                prob = prob * valid_mask.to(prob.dtype)
-            kp, sc, cnt = U.extract_keypoints(prob, self.thr, capacity=self.capacity or 4096)
+            kp, sc, cnt = U.extract_keypoints(prob, self.thr, capacity=self.capacity or 4096, valid_mask=valid_mask)
         K = kp.shape[1]
         desc = U.interpolate_descriptors_batched(kp, cnt, out['desc'], H, W)        # [B,K,D]
         D = desc.shape[2]

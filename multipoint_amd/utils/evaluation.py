@@ -267,8 +267,7 @@ def compute_repeatability_multispectral(net, dataloader, device, config, distanc
         if pred['nms'] > 0:
             prob = box_nms(prob, pred['nms'], thr, keep_top_k=pred['topk'], on_cpu=pred.get('cpu_nms', False))
         # keypoints: nonzero((prob > thr) * mask)  (:156-157) -- the mask is applied AFTER the NMS here
-        prob = prob * mask.to(prob.dtype)
-        kp, _, cnt = extract_keypoints(prob, thr, cap)
+        kp, _, cnt = extract_keypoints(prob, thr, cap, valid_mask=mask)
         H, W = prob.shape[2:]
         c = repeatability_counts(kp, cnt, ho, ht, H, W, distance_thresh).cpu().numpy()
         cnt = cnt.cpu().numpy()

@@ -131,17 +131,18 @@ def nms_unresolved(device=None):
     return n.value
 
 
-def extract_keypoints(prob, thr, capacity=None):
-    """torch.nonzero((prob > thr)) on the GPU with deterministic row-major order.
+def extract_keypoints(prob, thr, capacity=None, valid_mask=None):
+    """torch.nonzero((prob > thr)) -- with `valid_mask`, torch.nonzero((prob > thr) * valid_mask) (evaluation.py:156-157)
+    -- on the GPU with deterministic row-major order.
     prob (H,W) or (B,1,H,W); returns (kp_yx [B,K,2] int32, score [B,K], count [B])."""
-    p, _, dev, B, H, W = _prep_prob(prob, None)
+    p, m, dev, B, H, W = _prep_prob(prob, valid_mask)
     K = int(capacity) if capacity else H * W
     kp = torch.empty((B, K, 2), dtype=torch.int32, device=dev)
     sc = torch.empty((B, K), dtype=torch.float32, device=dev)
     cnt = torch.empty((B,), dtype=torch.int32, device=dev)
     h = _lib.get_handle(dev)
     with torch.cuda.device(dev):
-        h.check(h.lib.mp_extract_keypoints(h.ptr, _lib.ptr(p), B, H, W, float(thr), K, _lib.ptr(kp),
+        h.check(h.lib.mp_extract_keypoints(h.ptr, _lib.ptr(p), _lib.ptr(m), B, H, W, float(thr), K, _lib.ptr(kp),
                                            _lib.ptr(sc), _lib.ptr(cnt), _lib.stream_ptr(dev)))
     return kp, sc, cnt
 

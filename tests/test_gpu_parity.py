@@ -243,6 +243,9 @@ def test_box_nms_edge_cases(oracle, U):
         U.box_nms(torch.rand(16, 24, device='cuda'), 40, 0.015)               # footprint radius unsupported
     m = U.extract_keypoints(torch.from_numpy(ramp).cuda(), 0.5)
     assert np.array_equal(m[0][0, :int(m[2][0])].cpu().numpy(), np.argwhere(ramp > 0.5))
+    vm = np.random.default_rng(0).random(ramp.shape) < 0.5                     # nonzero((prob > thr) * valid_mask)
+    m = U.extract_keypoints(torch.from_numpy(ramp).cuda(), 0.5, valid_mask=torch.from_numpy(vm).cuda())
+    assert np.array_equal(m[0][0, :int(m[2][0])].cpu().numpy(), np.argwhere((ramp > 0.5) & vm))
 
 
 def test_box_nms_async_rounds_and_overflow(oracle, U):
