@@ -448,7 +448,15 @@ void prof_end(mp_handle* h, hipStream_t s)
     ++h->prof_used;
 }
 
-void run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, int in_coff, float* out,
+// 0, or MP_EINVAL (with the handle's error text set) when the launch is beyond the kernels' 32-bit tile decode
+int too_large(mp_handle* h, const char* name, int B, int H, int W)
+{
+    return fail(h, MP_EINVAL, std::string("mp_forward: layer ") + name + " has too many work items for one launch (B=" +
+                                  std::to_string(B) + ", " + std::to_string(H) + "x" + std::to_string(W) +
+                                  "): split the batch");
+}
+
+int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, int in_coff, float* out,
               int out_cstride, int out_coff, int B, int H, int W, const int* img_list, hipStream_t s,
               const FirstLayer* fuse = nullptr, const float* images = nullptr)
 {
@@ -474,16 +482,18 @@ void run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride,
     prof_begin(h, fuse ? "enc.conv1+2" : L.name,
                2.0 * L.taps * L.cin * L.cout * (double)B * H * W + (fuse ? 2.0 * 9 * 64 * (double)B * H * W : 0.0), s);
     if (fuse) { p.img = images; p.w1 = fuse->w; p.b1 = fuse->bias; p.s1 = fuse->scale; p.t1 = fuse->shift; }
+    int big;
     if (L.taps == 9 && L.upack && h->wino && (!fuse || (L.pool && L.cin == 64))) {
         p.wpack = L.upack;
-        launch_conv_wino(p, L.pool, fuse != nullptr, s);
+        big = launch_conv_wino(p, L.pool, fuse != nullptr, s);
     } else {
-        launch_conv_mfma(p, L.taps, mbw, L.pool, fuse != nullptr, s);
+        big = launch_conv_mfma(p, L.taps, mbw, L.pool, fuse != nullptr, s);
     }
     prof_end(h, s);
+    return big ? too_large(h, L.name, B, H, W) : MP_OK;
 }
 
-void run_conv_h(mp_handle* h, const ConvLayer& L, const _Float16* in, int in_cstride, int in_coff, _Float16* out,
+int run_conv_h(mp_handle* h, const ConvLayer& L, const _Float16* in, int in_cstride, int in_coff, _Float16* out,
                 int out_cstride, int out_coff, int B, int H, int W, const int* img_list, hipStream_t s)
 {
     ConvParamsH p{};
@@ -505,8 +515,9 @@ void run_conv_h(mp_handle* h, const ConvLayer& L, const _Float16* in, int in_cst
         p.total_px = (long long)B * H * W;
     }
     prof_begin(h, L.name, 2.0 * L.taps * L.cin * L.cout * (double)B * H * W, s);
-    launch_conv_f16(p, L.taps, mbw, L.pool, s);
+    const int big = launch_conv_f16(p, L.taps, mbw, L.pool, s);
     prof_end(h, s);
+    return big ? too_large(h, L.name, B, H, W) : MP_OK;
 }
 
 // mixed_precision forward: fp16 activations end to end, fp32 softmax / descriptor normalisation
@@ -520,6 +531,7 @@ int forward_f16(mp_handle* h, const float* images, int B, int H, int W, int nset
     // same carve-up as the fp32 path (sizes in elements), element type fp16
     const size_t nP = (size_t)B * H * W * 64, nQ = (size_t)B * H * W * 16;
     const size_t nL = (size_t)npx * 128, nD = (size_t)npx * 128, nR = (size_t)npx * 256;
+    int rc;
     if (!h->dummy) MP_HIP(hipMalloc(&h->dummy, 4096));
     _Float16* P = static_cast<_Float16*>(h->ws.p);
     _Float16* Q = P + nP;
@@ -543,20 +555,20 @@ int forward_f16(mp_handle* h, const float* images, int B, int H, int W, int nset
         _Float16* dst = Q;
         for (int i = 0; i < 7; ++i) {
             const ConvLayer& L = E.conv[i];
-            run_conv_h(h, L, src, L.cin, 0, i == 6 ? X : dst, L.cout, 0, nb, hh, ww, lptr[e], s);
+            if ((rc = run_conv_h(h, L, src, L.cin, 0, i == 6 ? X : dst, L.cout, 0, nb, hh, ww, lptr[e], s))) return rc;
             if (L.pool) { hh /= 2; ww /= 2; }
             _Float16* t = src; src = dst; dst = t;
         }
     }
-    run_conv_h(h, h->heads3, X, 128, 0, P, headc, 0, B, Hc, Wc, nullptr, s);
-    run_conv_h(h, h->det1, P, headc, 0, Lg, 128, 0, B, Hc, Wc, nullptr, s);
+    if ((rc = run_conv_h(h, h->heads3, X, 128, 0, P, headc, 0, B, Hc, Wc, nullptr, s))) return rc;
+    if ((rc = run_conv_h(h, h->det1, P, headc, 0, Lg, 128, 0, B, Hc, Wc, nullptr, s))) return rc;
     if (prob || logits) {
         prof_begin(h, "det.softmax_shuffle", 0.0, s);
         launch_det_post_f16(Lg, 128, B, Hc, Wc, prob, logits, h->cfg.softmax_mode, s);
         prof_end(h, s);
     }
     if (desc) {
-        run_conv_h(h, h->desc1, P, headc, 256, R, D, 0, B, Hc, Wc, nullptr, s);
+        if ((rc = run_conv_h(h, h->desc1, P, headc, 256, R, D, 0, B, Hc, Wc, nullptr, s))) return rc;
         prof_begin(h, "desc.l2norm", 0.0, s);
         launch_desc_l2norm_f16(R, desc, npx, D, h->cfg.normalize_descriptors ? 1 : 0, s);
         prof_end(h, s);
@@ -848,22 +860,22 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
         float* dst = Q;
         for (int i = 0; i < 7; ++i) {
             const ConvLayer& L = E.conv[i];
-            run_conv(h, L, src, L.cin, 0, i == 6 ? X : dst, L.cout, 0, nb, hh, ww, lptr[e], s,
-                     (i == 0 && fuse1) ? &E.first : nullptr, images);
+            if ((rc = run_conv(h, L, src, L.cin, 0, i == 6 ? X : dst, L.cout, 0, nb, hh, ww, lptr[e], s,
+                     (i == 0 && fuse1) ? &E.first : nullptr, images))) return rc;
             if (L.pool) { hh /= 2; ww /= 2; }
             float* t = src; src = dst; dst = t;
         }
     }
     // heads
-    run_conv(h, h->heads3, X, h->heads3.cin, 0, P, headc, 0, B, Hc, Wc, nullptr, s);
-    run_conv(h, h->det1, P, headc, 0, Lg, 80, 0, B, Hc, Wc, nullptr, s);
+    if ((rc = run_conv(h, h->heads3, X, h->heads3.cin, 0, P, headc, 0, B, Hc, Wc, nullptr, s))) return rc;
+    if ((rc = run_conv(h, h->det1, P, headc, 0, Lg, 80, 0, B, Hc, Wc, nullptr, s))) return rc;
     if (prob || logits) {
         prof_begin(h, "det.softmax_shuffle", 0.0, s);
         launch_det_post(Lg, 80, B, Hc, Wc, prob, logits, h->cfg.softmax_mode, s);
         prof_end(h, s);
     }
     if (desc) {
-        run_conv(h, h->desc1, P, headc, hc, desc, D, 0, B, Hc, Wc, nullptr, s);
+        if ((rc = run_conv(h, h->desc1, P, headc, hc, desc, D, 0, B, Hc, Wc, nullptr, s))) return rc;
         prof_begin(h, "desc.l2norm", 0.0, s);
         if (h->cfg.normalize_descriptors) launch_desc_l2norm(desc, desc, npx, D, 1, s);
         prof_end(h, s);

@@ -480,18 +480,18 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvParamsH p)
 }
 
 template <int TAPS, int MBW, bool POOL>
-void launch_h(const ConvParamsH& p, hipStream_t s)
+int launch_h(const ConvParamsH& p, hipStream_t s)
 {
     long long ntiles;
     if (TAPS == 9) ntiles = (long long)p.B * p.tiles_x * p.tiles_y;
     else ntiles = (p.total_px + 255) / 256;
     const long long nitems = ntiles * p.nslices;
-    if (nitems <= 0) return;
+    if (nitems <= 0) return 0;
     ConvParamsH q = p;
     auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ull / (unsigned)d) + 1ull); };
     q.magic_slices = magic(p.nslices); q.magic_tx = magic(p.tiles_x); q.magic_ty = magic(p.tiles_y);
     const long long dmax = std::max(std::max(p.nslices, p.tiles_x), p.tiles_y);
-    if (nitems * dmax >= 0x100000000ll) return;
+    if (nitems * dmax >= 0x100000000ll) return 1;      // beyond the 32-bit tile decode: reported as MP_EINVAL
     q.nitems = (int)nitems;
     // persistent workgroups: two per CU (256 CUs), a multiple of the 8 XCDs
     const long long nblk = std::min<long long>(512, ((nitems + 7) / 8) * 8);
@@ -500,6 +500,7 @@ void launch_h(const ConvParamsH& p, hipStream_t s)
         hipLaunchKernelGGL((conv_f16_kernel<TAPS, MBW, POOL, true>), dim3((unsigned)nblk), dim3(256), 0, s, pp);
     else
         hipLaunchKernelGGL((conv_f16_kernel<TAPS, MBW, POOL, false>), dim3((unsigned)nblk), dim3(256), 0, s, pp);
+    return 0;
 }
 
 // ---- first encoder block, fp16 flavour: image (fp32 in HBM, rounded to fp16 as autocast casts the conv input)
@@ -575,12 +576,12 @@ __global__ __launch_bounds__(256) void conv_first_f16_kernel(const Conv1ParamsH 
 
 }  // namespace
 
-void launch_conv_f16(const ConvParamsH& p, int taps, int mbw, bool pool, hipStream_t s)
+int launch_conv_f16(const ConvParamsH& p, int taps, int mbw, bool pool, hipStream_t s)
 {
-    if (taps == 1) { launch_h<1, 32, false>(p, s); return; }
-    if (mbw == 32) { pool ? launch_h<9, 32, true>(p, s) : launch_h<9, 32, false>(p, s); }
-    else if (mbw == 16) { pool ? launch_h<9, 16, true>(p, s) : launch_h<9, 16, false>(p, s); }
-    else { pool ? launch_h<9, 8, true>(p, s) : launch_h<9, 8, false>(p, s); }
+    if (taps == 1) return launch_h<1, 32, false>(p, s);
+    if (mbw == 32) return pool ? launch_h<9, 32, true>(p, s) : launch_h<9, 32, false>(p, s);
+    if (mbw == 16) return pool ? launch_h<9, 16, true>(p, s) : launch_h<9, 16, false>(p, s);
+    return pool ? launch_h<9, 8, true>(p, s) : launch_h<9, 8, false>(p, s);
 }
 
 void launch_conv_first_f16(const Conv1ParamsH& p, hipStream_t s)

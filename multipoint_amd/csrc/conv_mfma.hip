@@ -879,19 +879,19 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_persist_kernel(const ConvPar
 }
 
 template <int TAPS, int MBW, bool POOL, bool FUSE1>
-void launch_t(const ConvParams& p, hipStream_t s)
+int launch_t(const ConvParams& p, hipStream_t s)
 {
     long long ntiles;
     if (TAPS == 9) ntiles = (long long)p.B * p.tiles_x * p.tiles_y;
     else ntiles = (p.total_px + 255) / 256;
     const long long nblk = ntiles * p.nslices;
-    if (nblk <= 0) return;
+    if (nblk <= 0) return 0;
     ConvParams q = p;
     // magic = floor(2^32 / d) + 1 gives floor(n / d) == umulhi(n, magic) for all n with n * d < 2^32
     auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ull / (unsigned)d) + 1ull); };
     q.magic_slices = magic(p.nslices); q.magic_tx = magic(p.tiles_x); q.magic_ty = magic(p.tiles_y);
     const long long dmax = std::max(std::max(p.nslices, p.tiles_x), p.tiles_y);
-    if (nblk * dmax >= 0x100000000ll) return;          // caller checks hipGetLastError/sizes; unreachable for sane shapes
+    if (nblk * dmax >= 0x100000000ll) return 1;        // beyond the 32-bit tile decode: reported as MP_EINVAL
     q.nitems = (int)nblk;
     const ConvParams& pp = q;
     if constexpr (!FUSE1) {
@@ -903,7 +903,7 @@ void launch_t(const ConvParams& p, hipStream_t s)
                     hipLaunchKernelGGL((conv_mfma_persist_kernel<TAPS, MBW, POOL, true>), dim3(256), dim3(256), 0, s, pp);
                 else
                     hipLaunchKernelGGL((conv_mfma_persist_kernel<TAPS, MBW, POOL, false>), dim3(256), dim3(256), 0, s, pp);
-                return;
+                return 0;
             }
         }
     }
@@ -911,20 +911,20 @@ void launch_t(const ConvParams& p, hipStream_t s)
         hipLaunchKernelGGL((conv_mfma_kernel<TAPS, MBW, POOL, FUSE1, true>), dim3((unsigned)nblk), dim3(256), 0, s, pp);
     else
         hipLaunchKernelGGL((conv_mfma_kernel<TAPS, MBW, POOL, FUSE1, false>), dim3((unsigned)nblk), dim3(256), 0, s, pp);
+    return 0;
 }
 
 }  // namespace
 
-void launch_conv_mfma(const ConvParams& p, int taps, int mbw, bool pool, bool fuse1, hipStream_t s)
+int launch_conv_mfma(const ConvParams& p, int taps, int mbw, bool pool, bool fuse1, hipStream_t s)
 {
-    if (taps == 1) { launch_t<1, 32, false, false>(p, s); return; }
+    if (taps == 1) return launch_t<1, 32, false, false>(p, s);
     if (fuse1) {            // always the pooled second encoder convolution
-        if (mbw == 32) launch_t<9, 32, true, true>(p, s);
-        else if (mbw == 16) launch_t<9, 16, true, true>(p, s);
-        else launch_t<9, 8, true, true>(p, s);
-        return;
+        if (mbw == 32) return launch_t<9, 32, true, true>(p, s);
+        if (mbw == 16) return launch_t<9, 16, true, true>(p, s);
+        return launch_t<9, 8, true, true>(p, s);
     }
-    if (mbw == 32) { pool ? launch_t<9, 32, true, false>(p, s) : launch_t<9, 32, false, false>(p, s); }
-    else if (mbw == 16) { pool ? launch_t<9, 16, true, false>(p, s) : launch_t<9, 16, false, false>(p, s); }
-    else { pool ? launch_t<9, 8, true, false>(p, s) : launch_t<9, 8, false, false>(p, s); }
+    if (mbw == 32) return pool ? launch_t<9, 32, true, false>(p, s) : launch_t<9, 32, false, false>(p, s);
+    if (mbw == 16) return pool ? launch_t<9, 16, true, false>(p, s) : launch_t<9, 16, false, false>(p, s);
+    return pool ? launch_t<9, 8, true, false>(p, s) : launch_t<9, 8, false, false>(p, s);
 }

@@ -567,30 +567,31 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
 }
 
 template <bool POOL, bool FUSE>
-void launch_w(const ConvParams& p, hipStream_t s)
+int launch_w(const ConvParams& p, hipStream_t s)
 {
     ConvParams q = p;
     q.tiles_x = (p.W + WT - 1) / WT; q.tiles_y = (p.H + WT - 1) / WT;
     const long long nitems = (long long)p.B * q.tiles_x * q.tiles_y * p.nslices;
-    if (nitems <= 0) return;
+    if (nitems <= 0) return 0;
     auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ull / (unsigned)d) + 1ull); };
     q.magic_slices = magic(p.nslices); q.magic_tx = magic(q.tiles_x); q.magic_ty = magic(q.tiles_y);
     const long long dmax = std::max(std::max(p.nslices, q.tiles_x), q.tiles_y);
-    if (nitems * dmax >= 0x100000000ll) return;
+    if (nitems * dmax >= 0x100000000ll) return 1;      // beyond the 32-bit tile decode: reported as MP_EINVAL
     q.nitems = (int)nitems;
     const unsigned grid = (unsigned)std::min<long long>(256, ((nitems + 7) / 8) * 8);
     const ConvParams& pp = q;
     if (p.bn_first) hipLaunchKernelGGL((conv_wino_kernel<POOL, true, FUSE>), dim3(grid), dim3(256), 0, s, pp);
     else hipLaunchKernelGGL((conv_wino_kernel<POOL, false, FUSE>), dim3(grid), dim3(256), 0, s, pp);
+    return 0;
 }
 
 }  // namespace
 
 // p.wpack must point at the Winograd-domain weights packed by pack_wino_weights() (api.hip)
 // fuse1: p.img / p.w1 / p.b1 / p.s1 / p.t1 describe the first encoder block, p.in is not read (pooled, cin == 64 only)
-void launch_conv_wino(const ConvParams& p, bool pool, bool fuse1, hipStream_t s)
+int launch_conv_wino(const ConvParams& p, bool pool, bool fuse1, hipStream_t s)
 {
-    if (fuse1) launch_w<true, true>(p, s);
-    else if (pool) launch_w<true, false>(p, s);
-    else launch_w<false, false>(p, s);
+    if (fuse1) return launch_w<true, true>(p, s);
+    if (pool) return launch_w<true, false>(p, s);
+    return launch_w<false, false>(p, s);
 }

@@ -53,10 +53,12 @@ struct Conv1Params {
     int channels;         // output channels incl. zero padding: 64 (channel_version 0) or 32
 };
 
-void launch_conv_mfma(const ConvParams& p, int taps, int mbw, bool pool, bool fuse1, hipStream_t s);
+// the conv launchers return 0, or 1 when the launch has more work items than the kernels' 32-bit magic-number tile decode
+// can address (items * max divisor >= 2^32): nothing is launched and the caller reports MP_EINVAL
+int launch_conv_mfma(const ConvParams& p, int taps, int mbw, bool pool, bool fuse1, hipStream_t s);
 void launch_conv_first(const Conv1Params& p, hipStream_t s);
 // Winograd F(2x2,3x3) flavour of the 3x3 layers (conv_wino.hip); p.wpack = weights packed by pack_wino_weights()
-void launch_conv_wino(const ConvParams& p, bool pool, bool fuse1, hipStream_t s);
+int launch_conv_wino(const ConvParams& p, bool pool, bool fuse1, hipStream_t s);
 
 // fp16 path (mixed_precision: activations and packed weights fp16, fp32 accumulate; conv_f16.hip).
 // Same tiling as ConvParams; a chunk is 64 input channels, so cin must be a multiple of 64.
@@ -87,7 +89,7 @@ struct Conv1ParamsH {
     int B, H, W;
     int pad_zero, bn_first;
 };
-void launch_conv_f16(const ConvParamsH& p, int taps, int mbw, bool pool, hipStream_t s);
+int launch_conv_f16(const ConvParamsH& p, int taps, int mbw, bool pool, hipStream_t s);
 void launch_conv_first_f16(const Conv1ParamsH& p, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------

@@ -15,3 +15,4 @@ def loader_num_workers(dataset, requested):
               'instead of {}'.format(requested))
         return 0
     return int(requested)
+from .synthetic_weights import make_weights, make_images, SHIPPED_MODEL_CONFIG  # noqa: F401,E402

@@ -57,6 +57,7 @@ class PairPipeline:
         self.net = net
         self.overlap_post = overlap_post
         self._post_stream = None
+        self._last = None           # results of the latest run_interleaved() (check_converged inspects their counts)
         self.nms = config.get('nms', 4)
         self.thr = config.get('detection_threshold', 0.015)
         self.topk = config.get('topk', 0)
@@ -117,17 +118,24 @@ class PairPipeline:
             res = self._post(out, valid_mask, dev, B, H, W)
             res.done = torch.cuda.Event()
             res.done.record(post)
+        self._last = res
         return res
 
-    def _post(self, out, valid_mask, dev, B, H, W, nms_rounds=None):
+    def _capacity_is_exact(self, K):
+        """A list of K slots holds every keypoint the reference would return iff top-k limits them to <= K."""
+        return self.nms > 0 and 0 < self.topk <= K
+
+    def _post(self, out, valid_mask, dev, B, H, W, nms_rounds=None, capacity=None):
         prob = out['prob']
         if self.nms > 0:
-            K = self.capacity or (self.topk if self.topk > 0 else 4096)
+            # `topk: 0` (the shipped configs, like the reference's) = unlimited: 4096 slots is a first guess that
+            # run_converged() grows on overflow and check_converged() reports (the reference keeps every keypoint)
+            K = capacity or self.capacity or (self.topk if self.topk > 0 else 4096)
             kp, sc, cnt = U.detect_keypoints(prob, self.nms, self.thr, keep_top_k=self.topk, capacity=K,
                                              valid_mask=valid_mask,
                                              max_rounds=self.nms_rounds if nms_rounds is None else nms_rounds)
         else:
-            kp, sc, cnt = U.extract_keypoints(prob, self.thr, capacity=self.capacity or 4096, valid_mask=valid_mask)
+            kp, sc, cnt = U.extract_keypoints(prob, self.thr, capacity=capacity or self.capacity or 4096, valid_mask=valid_mask)
         K = kp.shape[1]
         desc = U.interpolate_descriptors_batched(kp, cnt, out['desc'], H, W)        # [B,K,D]
         D = desc.shape[2]
@@ -168,8 +176,17 @@ class PairPipeline:
             is_optical = (torch.arange(B) % 2 == 0).reshape(B, 1)
         out = self.net({'image': images, 'is_optical': is_optical})
         res = self._post(out, valid_mask, dev, B, H, W)
-        if self.nms > 0 and U.nms_unresolved(dev):
-            res = self._post(out, valid_mask, dev, B, H, W, nms_rounds=0)
+        redo_nms = self.nms > 0 and U.nms_unresolved(dev)
+        K = res.kp_yx.shape[1]
+        need = int(res.kp_count.max()) if B else 0
+        overflow = need > K and not self._capacity_is_exact(K)
+        if redo_nms or overflow:
+            # lists that overflowed their capacity (topk == 0: the reference keeps EVERY keypoint, utils.py:109-116) are
+            # rebuilt with the exact size -- dropping the row-major tail would silently change nn_map / m_score
+            res = self._post(out, valid_mask, dev, B, H, W, nms_rounds=0 if redo_nms else None,
+                             capacity=((need + 255) // 256) * 256 if overflow else None)
+            if overflow and int(res.kp_count.max()) > res.kp_yx.shape[1]:
+                raise RuntimeError('keypoint lists still overflow after regrowing to %d slots' % res.kp_yx.shape[1])
         return res
 
     def check_converged(self, device=None):
@@ -183,3 +200,11 @@ class PairPipeline:
         if n:
             raise RuntimeError('box_nms: %d candidates undecided after %d rounds; raise nms_rounds'
                                % (n, self.nms_rounds))
+        last = self._last
+        if last is not None:
+            K = last.kp_yx.shape[1]
+            if not self._capacity_is_exact(K):
+                need = int(last.kp_count.max()) if last.kp_count.numel() else 0
+                if need > K:
+                    raise RuntimeError('keypoint lists overflowed: an image has %d keypoints but the lists hold %d; '
+                                       'pass capacity >= %d (or use run_converged(), which regrows them)' % (need, K, need))

@@ -150,49 +150,12 @@ def state_dict_spec(cfg=None):
 def make_weights(seed=0, cfg=None, sharpen=True):
     """Seeded synthetic state_dict in the reference key layout (the pretrained blob
     model_weights/multipoint/latest.model is listed in /root/reference/.MISSING_LARGE_BLOBS).
-
-    Conv weights ~ U(-b, b), b = sqrt(6 / fan_in) (keeps activations O(1) through ReLU);
-    BN: gamma in [0.5,1.5] with ~10 % negative entries (so BN must stay *before* the max-pool),
-    beta ~ N(0,0.1), running_mean ~ N(0.2,0.1), running_var in [0.5,1.5].
-    ``sharpen``: the final detector BatchNorm2d(65) gets a large gamma and the dustbin a positive
-    beta so that, like a trained net, a few thousand pixels exceed detection_threshold=0.015.
-    """
+    The value generator is shared data-generation code of the package (multipoint_amd/datasets/synthetic_weights.py,
+    which bench.py and the examples use without touching this test infrastructure); the KEY LAYOUT comes from this
+    file's own restatement of the reference module tree (state_dict_spec above), so a layout error on either side shows."""
+    from multipoint_amd.datasets.synthetic_weights import make_weights_from_spec
     cfg = full_config(cfg)
-    rng = np.random.default_rng(seed)
-    sd = collections.OrderedDict()
-    spec = state_dict_spec(cfg)
-    bn_prefixes = {k.rsplit('.', 1)[0] for k, _, _ in spec if k.endswith('.running_mean')}
-    for key, shape, dtype in spec:
-        prefix, leaf = key.rsplit('.', 1)
-        if dtype == torch.int64:
-            sd[key] = torch.tensor(1000, dtype=torch.int64)
-            continue
-        if len(shape) == 4:
-            fan_in = shape[1] * shape[2] * shape[3]
-            b = np.sqrt(6.0 / fan_in)
-            arr = rng.uniform(-b, b, size=shape)
-        elif leaf == 'bias' and prefix not in bn_prefixes:
-            arr = rng.normal(0.0, 0.05, size=shape)            # conv bias
-        elif leaf == 'weight':
-            arr = rng.uniform(0.5, 1.5, size=shape)
-            flip = rng.uniform(size=shape) < 0.1
-            arr = np.where(flip, -arr, arr)                    # some negative gammas
-        elif leaf == 'bias':
-            arr = rng.normal(0.0, 0.1, size=shape)
-        elif leaf == 'running_mean':
-            arr = rng.normal(0.2, 0.1, size=shape)
-        elif leaf == 'running_var':
-            arr = rng.uniform(0.5, 1.5, size=shape)
-        else:
-            raise AssertionError(key)
-        sd[key] = torch.from_numpy(arr.astype(np.float32))
-    if sharpen and cfg['final_batchnorm']:
-        g = sd['detector_head_convolutions.5.weight']
-        sd['detector_head_convolutions.5.weight'] = (g.abs() * 2.5).contiguous()
-        b = sd['detector_head_convolutions.5.bias'].clone()
-        b[64] = 11.0                                           # dustbin dominates most cells
-        sd['detector_head_convolutions.5.bias'] = b
-    return sd
+    return make_weights_from_spec(state_dict_spec(cfg), seed, sharpen, cfg['final_batchnorm'])
 
 
 def make_images(seed, B, H, W):

@@ -39,6 +39,43 @@ def test_shard_and_gather_world2(tmp_path):
         assert row == [p, 3 * p + 1, 7 * p % 5, p * p]      # identical to a single-rank run
 
 
+def _results_for(pair_ids, K=50):
+    """A PairResults with the tensor shapes/dtypes PairPipeline produces (pipeline.py: kp_yx [2P,K,2] i32, kp_count [2P] i32
+    -- may exceed the capacity K --, desc [2P,K,D], match_idx/dist [P,K], match_count [P]); contents depend on the pair id
+    only, so a sharded run must reproduce the single-rank rows."""
+    from multipoint_amd.pipeline import PairResults
+    P = len(pair_ids)
+    kp_count = torch.tensor([[(11 * p) % 70, (7 * p + 3) % 70] for p in pair_ids], dtype=torch.int32).reshape(-1)
+    match_count = torch.tensor([min((11 * p) % 70, (7 * p + 3) % 70, K) // 2 for p in pair_ids], dtype=torch.int32)
+    return PairResults(torch.zeros((2 * P, K, 2), dtype=torch.int32), torch.zeros((2 * P, K)), kp_count,
+                       torch.zeros((2 * P, K, 8)), torch.full((P, K), -1, dtype=torch.int32), torch.zeros((P, K)),
+                       match_count, 64, 64)
+
+
+def _worker_results(rank, world, port, n_pairs, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from multipoint_amd.dist import shard_pairs, gather_pair_metrics, pair_metric_records
+    mine = shard_pairs(n_pairs, rank, world)
+    allrec = gather_pair_metrics(pair_metric_records(_results_for(mine), mine))      # exactly bench.py's gather
+    torch.save(allrec, os.path.join(out_dir, 'rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_records_of_pair_results_world2(tmp_path):
+    """The record bench.py gathers, built from PairResults-shaped tensors by the product's own pair_metric_records()."""
+    from multipoint_amd.dist import pair_metric_records
+    n_pairs, world = 9, 2
+    mp.spawn(_worker_results, args=(world, _free_port(), n_pairs, str(tmp_path)), nprocs=world, join=True)
+    a = torch.load(tmp_path / 'rank0.pt'); b = torch.load(tmp_path / 'rank1.pt')
+    assert torch.equal(a, b) and a.dtype == torch.int32 and a.shape == (n_pairs, 4)
+    single = pair_metric_records(_results_for(list(range(n_pairs))), list(range(n_pairs)))
+    order = torch.argsort(a[:, 0])
+    assert torch.equal(a[order], single)                     # same rows as one rank processing every pair
+    assert int(a[:, 1].max()) <= 50 and int(a[:, 2].max()) <= 50      # counts clamped to the list capacity
+
+
 def test_shard_pairs_partition():
     from multipoint_amd.dist import shard_pairs, gather_pair_metrics
     for world in (1, 2, 4, 8):

@@ -1,0 +1,122 @@
+"""GPU (MI355X): END-TO-END keypoint parity at the headline configuration (BASELINE configs[2]: 480x640, box-NMS size 4,
+threshold 0.015, top-k 1000) -- the reference's contract is the index list torch.nonzero(box_nms(prob) > thr)
+(multipoint/utils/evaluation.py:234-263).  For BOTH images of every pair the keypoint list of the HIP pipeline is compared
+with the oracle's; every keypoint that differs must be explained by a measured fp32-noise flip (oracle/flip_accounting.py:
+threshold crossing, order flip with a footprint neighbour, cascade through a neighbour, or rank displacement at the top-k
+boundary), the HIP NMS / top-k on the GPU's own map must equal the oracle's bit for bit, and descriptors are compared on
+the intersection.  Run for the default path (Winograd F(2x2,3x3)), the direct-convolution path (MP_NO_WINOGRAD=1) and the
+fp16 MFMA path (mixed_precision)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+PRED = {'nms': 4, 'detection_threshold': 0.015, 'topk': 1000,
+        'matching': {'method': 'bfmatcher', 'method_kwargs': {'crossCheck': True}, 'knn_matches': False}}
+_cpu_cache = {}
+
+
+def _cpu_side(oracle, sd, cfg, P, H, W, mixed):
+    """Oracle forward of P synthetic pairs (cached per precision: the fp32 oracle serves both fp32 kernel variants)."""
+    key = (P, H, W, mixed)
+    if key not in _cpu_cache:
+        from multipoint_amd.datasets import SyntheticPairs
+        imgs = np.empty((2 * P, 1, H, W), dtype=np.float32)
+        for p in range(P):
+            imgs[2 * p], imgs[2 * p + 1] = SyntheticPairs.make_pair(0, p, H, W)
+        t = torch.from_numpy(imgs)
+        flags = (torch.arange(2 * P) % 2 == 0).reshape(-1, 1)
+        ref = oracle.forward(sd, t, cfg, is_optical=flags)
+        _cpu_cache[key] = (t, flags, ref['prob'].numpy(), ref['desc'].numpy())
+    return _cpu_cache[key]
+
+
+@pytest.mark.parametrize('variant,P,root_tol', [('winograd', 16, 2e-4), ('direct', 16, 2e-4), ('fp16', 4, None)])
+def test_e2e_keypoint_flip_accounting(oracle, monkeypatch, variant, P, root_tol):
+    import multipoint_amd.models as M
+    from multipoint_amd.pipeline import PairPipeline
+    from oracle import flip_accounting as FA
+    H, W = 480, 640
+    cfg = dict(oracle.SHIPPED_MODEL_CONFIG)
+    if variant == 'direct':
+        monkeypatch.setenv('MP_NO_WINOGRAD', '1')
+    if variant == 'fp16':
+        cfg['mixed_precision'] = True
+    sd = oracle.make_weights(0, cfg)
+    net = M.MultiPoint(dict(cfg)); net.load_state_dict(sd); net.to('cuda'); net.eval()        # new handle: reads the environment
+    images, flags, prob_cpu, desc_cpu = _cpu_side(oracle, sd, cfg, P, H, W, variant == 'fp16')
+
+    pipe = PairPipeline(net, PRED, capacity=PRED['topk'])
+    res = pipe.run_converged(images.cuda(), None, flags)
+    host = res.to_host()
+    out = net({'image': images.cuda(), 'is_optical': flags})
+    prob_gpu = out['prob'].cpu().numpy()
+
+    nms = lambda m: oracle.box_nms(m, PRED['nms'], PRED['detection_threshold'], keep_top_k=0)
+    summary, per = FA.account_batch(prob_cpu, prob_gpu, nms, PRED['nms'], PRED['detection_threshold'], 0.1, PRED['topk'])
+    print('\n[e2e %s] %s' % (variant, json.dumps(summary)))
+
+    desc_err = 0.0
+    for b in range(2 * P):
+        kp = host[b // 2]['kp_optical' if b % 2 == 0 else 'kp_thermal']
+        gd = host[b // 2]['desc_optical' if b % 2 == 0 else 'desc_thermal']
+        flat = (kp[:, 0] * W + kp[:, 1]).tolist()
+        # (1) the HIP NMS + top-k + compaction on the GPU's own map == the oracle's on that map, bit for bit, row-major
+        assert flat == sorted(per[b]['final_gpu']), 'image %d: HIP keypoints differ from oracle NMS/top-k of the same map' % b
+        # (2) descriptors on the keypoints both sides found
+        both = np.array([i for i, f in enumerate(flat) if f in per[b]['final_cpu']], dtype=np.int64)
+        if len(both):
+            ref_rows = oracle.interpolate_descriptors(kp[both], desc_cpu[b], H, W)
+            desc_err = max(desc_err, float(np.abs(ref_rows - gd[both]).max()))
+    # (3) every differing keypoint is a measured-noise flip
+    assert summary['unexplained'] == 0 and summary['max_unexplained_margin'] == 0.0, summary
+    assert summary['roots_within_measured_noise']
+    if variant == 'fp16':
+        # two correct fp16 implementations agree only to the fp16 noise floor: the lists overlap, they are not equal
+        assert summary['keypoints_differing'] <= 0.25 * summary['keypoints_total'], summary
+        assert desc_err <= 4e-3
+    else:
+        assert summary['max_prob_err'] <= 1e-4
+        assert summary['max_root_margin'] <= root_tol, summary
+        assert summary['keypoints_differing'] <= 0.002 * summary['keypoints_total'], summary
+        assert desc_err <= 1e-4
+    print('[e2e %s] desc max abs err on the intersection: %.3e' % (variant, desc_err))
+
+
+def test_unlimited_topk_lists_grow_instead_of_truncating(oracle):
+    """`topk: 0` (the shipped prediction configs, like the reference's) keeps EVERY keypoint (utils.py:109-116).  The device
+    lists have a fixed capacity: run_converged() must regrow them on overflow (same keypoints as the oracle, none dropped
+    from the bottom of the image) and the asynchronous entry must report the overflow instead of truncating silently."""
+    import multipoint_amd.models as M
+    from multipoint_amd.pipeline import PairPipeline
+    cfg = dict(oracle.SHIPPED_MODEL_CONFIG)
+    sd = oracle.make_weights(0, cfg)
+    net = M.MultiPoint(dict(cfg)); net.load_state_dict(sd); net.to('cuda'); net.eval()
+    img = oracle.make_images(5, 4, 240, 320)
+    pred = dict(PRED, topk=0)
+    small = PairPipeline(net, pred, capacity=64)                       # far fewer slots than keypoints
+    res = small(img[0::2].cuda(), img[1::2].cuda())                    # __call__ -> run_converged
+    host = res.to_host()
+    ref = oracle.process_pairs(sd, cfg, img[0::2], img[1::2], nms=4, detection_threshold=0.015, topk=0)
+    assert res.kp_yx.shape[1] > 64
+    for a, b in zip(ref, host):
+        assert len(a['kp_optical']) > 64
+        assert np.array_equal(a['kp_optical'], b['kp_optical']) and np.array_equal(a['kp_thermal'], b['kp_thermal'])
+    small.run_interleaved(PairPipeline.interleave(img[0::2].cuda(), img[1::2].cuda()))
+    with pytest.raises(RuntimeError, match='overflowed'):
+        small.check_converged('cuda:0')
+
+
+def test_launch_beyond_tile_decode_is_an_error(oracle):
+    """A layer with more work items than the kernels' 32-bit magic-number tile decode addresses (items x max divisor >= 2^32)
+    must fail with MP_EINVAL -- not return MP_OK with stale outputs: a 16 x 1048576 image has 65536 tile columns."""
+    import multipoint_amd.models as M
+    cfg = dict(oracle.SHIPPED_MODEL_CONFIG)
+    net = M.MultiPoint(dict(cfg)); net.load_state_dict(oracle.make_weights(0, cfg)); net.to('cuda'); net.eval()
+    with pytest.raises(RuntimeError, match='too many work items'):
+        net({'image': torch.zeros((1, 1, 16, 1 << 20), device='cuda')})
+    out = net({'image': torch.rand((1, 1, 16, 64), device='cuda')})              # the handle is still usable afterwards
+    assert torch.isfinite(out['prob']).all()

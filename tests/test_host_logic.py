@@ -277,3 +277,20 @@ def test_committed_bench_line_follows_the_contract():
     c = d['cpu_baseline']
     assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and c['value'] > 0 and c['unit'] == d['unit'] and c['sample']
     assert d['parity']['desc_max_abs_err'] <= 1e-4
+
+
+def test_bench_self_launches_ranks():
+    """`python bench.py --gpus 2` outside torchrun starts the two ranks itself (child torchrun job, 127.0.0.1 rendezvous)
+    and fails only because this container has no GPU -- in both ranks, not at a launcher check; a WORLD_SIZE that does
+    not match --gpus is an error."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')}
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert (r.stdout + r.stderr).count('bench.py needs an MI355X') == 2
+    env.update(WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '4'], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode != 0 and 'does not match WORLD_SIZE=2' in (r.stdout + r.stderr)
