@@ -10,16 +10,24 @@
 // output channels; wave w multiplies tile group w>>1 (32 tiles) by channel half w&1 (32 couts) for ALL 16
 // positions: 16 accumulator tiles = 256 registers, so the output transform is in-register and, for pooled layers,
 // the 2x2 max-pool is exactly one Winograd tile.
-// K is walked in units of 8 input channels, software-pipelined three deep through double-buffered LDS:
-//   while unit n is multiplied,  unit n+1 is transformed (raw patch -> V, 32 packed adds per thread),
-//   the raw 18x18x8 patch of unit n+2 goes VGPR -> LDS, and the patch of unit n+3 is fetched global -> VGPR.
+// K is walked in units of 8 input channels.  EVERY operand of the loop reaches the matrix pipe through LDS, and the
+// global->LDS traffic is LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write and -- the point -- no
+// per-load s_waitcnt: vector memory returns in order, so with register loads every wait for an L2-resident weight
+// fragment also waited for the HBM latency of the raw-patch loads issued before it: 10 % of a launch, tools/run_variants.sh):
+//   while unit n is multiplied (A fragments from V[n&1], B fragments from U[n&1]: two ds_read_b128 per 4 MFMAs),
+//   unit n+1 is transformed (raw[(n+1)&1] -> V[(n+1)&1], 32 packed adds per thread),
+//   the weights U(n+1) (32 KiB in fragment order) and the raw 18x18x8 patch of unit n+2 are DMA'd into U[(n+1)&1] and
+//   raw[n&1] during the first half of the unit; ONE s_waitcnt vmcnt(0) + barrier per unit publishes them.
+// Prices next to a wave streaming v_mfma_f32_32x32x2_f32 alone on its SIMD (tools/mfma_probe10.hip, tools/dma_probe.hip):
+// any VALU instruction 12 cycles alone in an MFMA gap, 8 + 4n in a cluster of n (8 + 5n packed); s_nop, ds_read_b32/64/128
+// and an LDS-DMA per 4 MFMAs free; ds_write_b64 free up to 2 per MFMA; global_load_dwordx4 into registers 10 cycles.
 //
 // FUSE (encoder conv2 only): the input of this convolution is the first encoder block (ReflectionPad -> Conv2d(1,64,3)
 // -> ReLU -> BN, Cin = 1).  Instead of reading its 64-channel output from HBM, the raw patch of a unit (18x18 pixels x
 // 8 channels) is computed from a 20x20 image patch in LDS: per thread and unit three 4-channel vectors = 27 LDS reads
 // (issued in the MFMA slots of the unit) + 54 packed multiply-adds and the activation (one block behind the unit's
-// MFMAs, see f_row).  This removes the first block's launch and its 78.6 MB per image round trip through HBM (the
-// same k-ordered fmaf chain as conv_first_kernel); 7.09 ms against 0.95 + 6.46 ms for 64 images 480x640.
+// MFMAs, see f_row), written to raw[] with ds_write_b128.  This removes the first block's launch and its 78.6 MB per
+// image round trip through HBM (the same k-ordered fmaf chain as conv_first_kernel).
 #include "mp_common.h"
 
 #include <algorithm>
@@ -47,13 +55,15 @@ constexpr int WT = 16;                       // output tile edge
 constexpr int PW = WT + 2;                   // raw patch edge (18)
 constexpr int NPX = PW * PW;                 // 324 patch pixels
 constexpr int UC = 8;                        // input channels per unit
-constexpr int TS = 12;                       // V tile stride in floats (8 channels + 4 pad: conflict-free b128 reads)
-constexpr int VPOS = 64 * TS;                // floats per position
-constexpr int VBUF = 16 * VPOS;              // floats per V buffer (49152 B)
-constexpr int RS = 12;                       // raw patch pixel stride in floats (8 channels + 4 pad: the 8-byte window
-                                             // reads of 8 neighbouring tiles then hit 64 distinct banks)
-constexpr int RAWBUF = NPX * RS;             // floats per raw buffer (15552 B)
-constexpr int NRAW = (NPX * 2 + 255) / 256;  // raw 16-byte vectors per thread (3)
+constexpr int TS = UC;                       // V tile stride in floats: unpadded; the two 16-byte halves of a tile are swapped
+                                             // for tiles 16-31 of a wave's group, which makes the A-fragment ds_read_b128
+                                             // conflict-free (its 16-lane groups then cover all 64 banks, see v_off)
+constexpr int VPOS = 64 * TS;                // floats per position (2 KiB)
+constexpr int VBUF = 16 * VPOS;              // floats per V buffer (32 KiB)
+constexpr int UBUF = 16 * 2 * 64 * 4;        // floats per U buffer: [pos][channel half][lane][4] = 32 KiB, MFMA B-fragment order
+constexpr int RS = UC;                       // raw patch pixel stride in floats: lane-linear 16-byte granules (LDS-DMA order)
+constexpr int NRAW = (NPX * 2 + 255) / 256;  // raw 16-byte granules per thread (3): granule f = tid + 256*j = pixel f>>1, quad f&1
+constexpr int RAWBUF = 11 * 64 * 4;          // floats per raw buffer: 11 wave-DMAs of 64 granules (648 used, 11264 B)
 constexpr int IT = WT + 4;                   // image patch edge of the fused first block (20)
 constexpr int NPL = (IT * IT + 255) / 256;   // image patch pixels per thread (2)
 
@@ -76,12 +86,24 @@ __device__ __forceinline__ float acc_read(float a)
     asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a));
     return x;
 }
+// LDS-DMA: 64 lanes x 16 bytes from (uniform base + per-lane byte offset) to LDS bytes [lds_byte + 16*lane, +16); inactive
+// lanes write nothing.  Invisible to hipcc's s_waitcnt bookkeeping: the unit loop waits with dma_wait() before its barrier.
+// M0 (the destination base) is saved and restored: the compiler reserves it.
+__device__ __forceinline__ void dma16(const float* sbase, unsigned voff_bytes, unsigned lds_byte)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff_bytes), "s"(sbase), "s"(lds_byte) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)p; }   // low 32 bits of a flat LDS address
 
 template <bool POOL, bool BNF, bool FUSE>
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
 {
     static_assert(!FUSE || POOL, "the fused first block feeds the pooled second encoder convolution");
     __shared__ __attribute__((aligned(16))) float Vs[2 * VBUF];
+    __shared__ __attribute__((aligned(16))) float Us[2 * UBUF];
     __shared__ __attribute__((aligned(16))) float raw[2 * RAWBUF];
     __shared__ __attribute__((aligned(16))) float prm[3 * 64];
     __shared__ __attribute__((aligned(16))) float its[FUSE ? 2 * IT * IT : 4];     // image patches of two items
@@ -120,7 +142,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
 
     // ---- raw patch staging: vector f = tid + 256*j covers patch pixel f>>1, channel quad f&1; its LDS slot is f*4 ----
     int roff[NRAW];
+    unsigned rvoff[NRAW];         // !FUSE: byte offset of the granule's source (clamped to 0 for padding / unused slots)
     bool roff_rel = false;        // roff holds the item-invariant offsets of interior items
+    bool ld_zero = false;         // the staging cursor's item has zero-padding slots (roff < 0): border item of a zero-pad model
     auto raw_offsets = [&](const Where& w) __attribute__((always_inline)) -> const float* {
         const bool interior = (w.y0 >= 1) && (w.y0 + WT < p.H) && (w.x0 >= 1) && (w.x0 + WT < p.W);
         if (interior) {
@@ -131,12 +155,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                     const int py = q / PW, px = q - py * PW;
                     if constexpr (FUSE) roff[j] = (f < NPX * 2) ? (py + 1) * IT + (px + 1) : IT + 1;   // window centre in the image patch
                     else roff[j] = (f < NPX * 2) ? (py * p.W + px) * p.in_cstride + (f & 1) * 4 : 0;
+                    rvoff[j] = (unsigned)roff[j] * 4u;
                 }
                 roff_rel = true;
             }
+            ld_zero = false;
             return w.in_base + (long long)((w.y0 - 1) * p.W + (w.x0 - 1)) * p.in_cstride;
         }
         roff_rel = false;
+        ld_zero = p.pad_zero != 0;
 #pragma unroll
         for (int j = 0; j < NRAW; ++j) {
             const int f = tid + j * 256, q = f >> 1;
@@ -161,14 +188,30 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                 }
             }
             roff[j] = off;
+            rvoff[j] = (unsigned)(off >= 0 ? off : 0) * 4u;
         }
         return w.in_base;
     };
-    f32x4 rreg[NRAW];
-    auto raw_load = [&](const float* base, int chunk) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < NRAW; ++j)
-            rreg[j] = *reinterpret_cast<const f32x4*>(base + chunk * UC + (roff[j] >= 0 ? roff[j] : 0));
+    f32x4 rreg[NRAW];                 // FUSE: the computed raw granules of a unit on their way to LDS
+    const unsigned raw_lds = lds_addr(raw), us_lds = lds_addr(Us);
+    // granule block j of this wave (64 granules = 1 KiB, block index wave + 4*j) of the staging cursor's unit -> raw[buf]
+    auto raw_dma = [&](const float* base, int chunk, int buf, int j) __attribute__((always_inline)) {
+        const int g = wave + 4 * j;
+        if (g >= RAWBUF / 256) return;
+        const float* sb = base + chunk * UC;
+        const unsigned dst = raw_lds + (unsigned)(buf * RAWBUF + g * 256) * 4u;
+        if (!ld_zero) {
+            dma16(sb, rvoff[j], dst);
+        } else {
+            // zero-padding slots are written by their own lanes; the DMA skips them (inactive lanes write nothing)
+            if (roff[j] >= 0) dma16(sb, rvoff[j], dst);
+            else *reinterpret_cast<f32x4*>(&raw[buf * RAWBUF + g * 256 + lane * 4]) = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // weight block i (0..7) of this wave: position wave*4 + (i>>1), channel half i&1 of the unit whose half-0 base is `ub`
+    auto u_dma = [&](const float* ub, int half_stride, int buf, int i) __attribute__((always_inline)) {
+        const int b = wave * 8 + i;
+        dma16(ub + (i & 1) * half_stride + (b >> 1) * 256, (unsigned)lane * 16u, us_lds + (unsigned)(buf * UBUF + b * 256) * 4u);
     };
     unsigned rzero = 0;           // bit j: vector j of rreg is a zero-padding slot (set when the loads are issued)
     auto raw_mark = [&]() __attribute__((always_inline)) {
@@ -176,14 +219,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
 #pragma unroll
         for (int j = 0; j < NRAW; ++j) rzero |= (roff[j] < 0 ? 1u : 0u) << j;
     };
-    auto raw_put = [&](int buf) __attribute__((always_inline)) {
+    auto raw_put = [&](int buf) __attribute__((always_inline)) {       // FUSE only
+        if constexpr (FUSE) {
 #pragma unroll
-        for (int j = 0; j < NRAW; ++j) {
-            const int f = tid + j * 256;
-            if (f < NPX * 2) {
-                f32x4 v = rreg[j];
-                if ((rzero >> j) & 1u) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4*>(&raw[buf * RAWBUF + (f >> 1) * RS + (f & 1) * 4]) = v;
+            for (int j = 0; j < NRAW; ++j) {
+                const int f = tid + j * 256;
+                if (f < NPX * 2) {
+                    f32x4 v = rreg[j];
+                    if ((rzero >> j) & 1u) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4*>(&raw[buf * RAWBUF + f * 4]) = v;
+                }
             }
         }
     };
@@ -267,7 +312,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
     // ---- input transform V = B^T d B of one unit: thread = (tile t, channel pair cg) ----
     const int t_tile = tid >> 2, t_cg = tid & 3;
     const int tr_base = (((t_tile >> 3) * 2) * PW + (t_tile & 7) * 2) * RS + t_cg * 2;     // top-left of the 4x4 window
-    const int tw_base = t_tile * TS + t_cg * 2;
+    // V[pos][tile][8]: tile t's 16-byte halves are swapped when bit 4 of t is set (conflict-free A-fragment reads)
+    const int tw_base = t_tile * TS + (((t_cg >> 1) ^ ((t_tile >> 4) & 1)) * 4) + (t_cg & 1) * 2;
     f32x2 dd[16];
     auto tf_read = [&](int buf, int k) __attribute__((always_inline)) {      // window elements 2k, 2k+1
 #pragma unroll
@@ -295,11 +341,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
     };
 
     // ---- GEMM operands ----
-    const int a_base = (tg * 32 + (lane & 31)) * TS + (lane >> 5) * 4;
-    constexpr int RBW = 8, PFW = 7;                     // U ring / prefetch distance in positions
-    f32x4 bfr[RBW], afr[3];
-    auto u_ptr = [&](int slice) __attribute__((always_inline)) -> const f32x4* {
-        return reinterpret_cast<const f32x4*>(p.wpack) + ((long long)(slice * 2 + chh) * NC) * (16 * 64) + lane;
+    const int a_base = (tg * 32 + (lane & 31)) * TS + (((lane >> 5) ^ ((lane >> 4) & 1)) * 4);
+    const int b_base = chh * 256 + lane * 4;            // B fragment of position s: Us[buf][(2*s + chh)*256 + lane*4]
+    f32x4 bfr[4], afr[4];                               // operand rings, slot = position & 3, fetched two positions ahead
+    const int u_half = NC * (16 * 64 * 4);              // floats between the two channel halves of a slice in wpack
+    auto u_ptr = [&](int slice) __attribute__((always_inline)) -> const float* {      // half 0, unit 0 of a slice
+        return p.wpack + (long long)slice * 2 * u_half;
     };
     auto load_prm = [&](int slice) __attribute__((always_inline)) {
         if (tid < 64) {
@@ -307,7 +354,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
         }
     };
 
-    // ---- prologue: V(0) transformed, raw(1) in LDS, raw(2) in flight ----
+    // ---- prologue: V(0) transformed, raw(1) and U(0) in LDS (FUSE: raw(2) computed, in registers) ----
     Where cur = decode(item);
     const float* rbase = raw_offsets(cur);               // base pointer the staging loads currently use
     Where ld_item = cur;                                  // item the staging loads currently target
@@ -328,9 +375,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
             }
         }
     };
-    auto raw_make = [&]() __attribute__((always_inline)) {        // the cursor's raw unit -> rreg (not interleaved)
-        raw_mark();
+    // the cursor's raw unit (not interleaved): FUSE -> rreg (raw_put() stores it), otherwise DMA -> raw[buf]
+    auto raw_make = [&](int buf) __attribute__((always_inline)) {
         if constexpr (FUSE) {
+            raw_mark();
             f_weights(ld_chunk, 0); f_weights(ld_chunk, 1);
 #pragma unroll
             for (int j = 0; j < NRAW; ++j) {
@@ -339,7 +387,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                 f_act(j);
             }
         } else {
-            raw_load(rbase, ld_chunk);
+#pragma unroll
+            for (int j = 0; j < NRAW; ++j) raw_dma(rbase, ld_chunk, buf, j);
         }
         ld_advance();
     };
@@ -350,10 +399,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
         patch_put(0);
         __syncthreads();
     }
-    raw_make();                                                   // raw(0)
+    const float* up = u_ptr(cur.slice);                           // weights of the item being multiplied (half 0, unit 0)
+    raw_make(0);                                                  // raw(0)
     raw_put(0);
-    raw_make();                                                   // raw(1)
+    raw_make(1);                                                  // raw(1)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) u_dma(up, u_half, 0, i);          // U(0)
     load_prm(cur.slice);
+    dma_wait();
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 8; ++k) tf_read(0, k);
@@ -361,11 +414,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
 #pragma unroll
     for (int e = 0; e < 16; ++e) tf_write(0, e);
     raw_put(1);
-    raw_make();                                                   // raw(2): written during unit 0
-    const f32x4* up = u_ptr(cur.slice);
-#pragma unroll
-    for (int s = 0; s < PFW; ++s) bfr[s] = up[s * 64];
+    if constexpr (FUSE) raw_make(0);                              // raw(2): in registers, written to raw[0] during unit 0
     __syncthreads();
+    afr[0] = *reinterpret_cast<const f32x4*>(&Vs[a_base]);
+    afr[1] = *reinterpret_cast<const f32x4*>(&Vs[a_base + VPOS]);
+    bfr[0] = *reinterpret_cast<const f32x4*>(&Us[b_base]);
+    bfr[1] = *reinterpret_cast<const f32x4*>(&Us[b_base + 512]);
 
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int n = 0;                                            // unit counter (parity selects the LDS buffers)
@@ -381,20 +435,23 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
         const bool has_next = item_next < item_end;
         const int next_slice = has_next ? (int)(item_next - (int)udiv((unsigned)item_next, p.magic_slices, (unsigned)p.nslices) * p.nslices)
                                         : cur.slice;
-        const f32x4* unext = u_ptr(next_slice);
+        const float* unext = u_ptr(next_slice);
         Where nxt_w = cur;
         if constexpr (FUSE) { if (has_next) nxt_w = decode(item_next); }
 
         auto unit_body = [&](const int c, auto first_tag) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_tag)::value;
             const bool last = c + 1 == NC;
-            const int vb = n & 1;                                     // V buffer of this unit; raw(n+1) is in raw[vb ^ 1]
+            const int vb = n & 1;                                     // V / U buffer of this unit; raw(n+1) is in raw[vb ^ 1]
             const float* const vr = Vs + vb * VBUF;
-            const f32x4* const uc = up + (long long)c * (16 * 64);
-            const f32x4* const ut = last ? unext : uc + 16 * 64;      // where the U prefetch continues
+            const float* const ur = Us + vb * UBUF + b_base;
+            const float* const un = last ? unext : up + (c + 1) * (16 * 64 * 4);     // U(n+1): half 0 of the next unit
+            const float* const vn = Vs + (vb ^ 1) * VBUF;             // next unit's operands (read after the unit barrier)
+            const float* const urn = Us + (vb ^ 1) * UBUF + b_base;
             MPW_T(t_u0);
-            afr[0] = *reinterpret_cast<const f32x4*>(&vr[a_base]);
-            afr[1] = *reinterpret_cast<const f32x4*>(&vr[a_base + VPOS]);
+#ifdef MP_TIMING
+            unsigned long long t_b0 = 0, t_b1 = 0;
+#endif
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
 #pragma unroll
@@ -402,25 +459,27 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                     // pooled: C rows = tiles, columns = output channels (lane = channel: the pool window is one tile = one
                     // register); otherwise the operands are swapped so that lane = tile and a register quad = 4 consecutive
                     // channels (16-byte stores)
-                    acc[s] = POOL ? __builtin_amdgcn_mfma_f32_32x32x2f32(afr[s % 3][e], bfr[s % RBW][e], (FIRST && e == 0) ? zero16 : acc[s], 0, 0, 0)
-                                  : __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[s % RBW][e], afr[s % 3][e], (FIRST && e == 0) ? zero16 : acc[s], 0, 0, 0);
+                    acc[s] = POOL ? __builtin_amdgcn_mfma_f32_32x32x2f32(afr[s & 3][e], bfr[s & 3][e], (FIRST && e == 0) ? zero16 : acc[s], 0, 0, 0)
+                                  : __builtin_amdgcn_mfma_f32_32x32x2f32(bfr[s & 3][e], afr[s & 3][e], (FIRST && e == 0) ? zero16 : acc[s], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (e == 0) {
-                        bfr[(s + PFW) % RBW] = (s + PFW < 16) ? uc[(s + PFW) * 64] : ut[(s + PFW - 16) * 64];
+                        // B fragment two positions ahead; positions 14, 15 fetch positions 0, 1 of the NEXT unit (the unit
+                        // barrier sits behind position 13, so an LDS latency is never exposed at a unit boundary)
+                        bfr[(s + 2) & 3] = *reinterpret_cast<const f32x4*>(s + 2 < 16 ? &ur[(s + 2) * 512] : &urn[(s - 14) * 512]);
+                        // the weights of unit n+1 -> U[vb^1] (read during unit n-1): this wave's 8 of the 32 KiB-blocks
+                        if (s < 8) u_dma(un, u_half, vb ^ 1, s);
                     } else if (e == 1) {
-                        if (s + 2 < 16) afr[(s + 2) % 3] = *reinterpret_cast<const f32x4*>(&vr[a_base + (s + 2) * VPOS]);
+                        afr[(s + 2) & 3] = *reinterpret_cast<const f32x4*>(s + 2 < 16 ? &vr[a_base + (s + 2) * VPOS] : &vn[a_base + (s - 14) * VPOS]);
                     } else if (e == 2) {
-                        // input transform of unit n+1: raw[vb^1] -> V[vb^1]
-                        if (s < 8) tf_read(vb ^ 1, s);
-                        else if (s == 8) tf_rows();
-                        else if (s == 9) tf_cols();
-                        else if (s < 15) { tf_write(vb ^ 1, 3 * (s - 10)); tf_write(vb ^ 1, 3 * (s - 10) + 1); tf_write(vb ^ 1, 3 * (s - 10) + 2); }
-                        else tf_write(vb ^ 1, 15);
+                        // input transform of unit n+1: raw[vb^1] -> V[vb^1], complete before the unit barrier
+                        if (s < 4) { tf_read(vb ^ 1, 2 * s); tf_read(vb ^ 1, 2 * s + 1); }
+                        else if (s == 4) tf_rows();
+                        else if (s == 5) tf_cols();
+                        else if (s < 14) { tf_write(vb ^ 1, 2 * (s - 6)); tf_write(vb ^ 1, 2 * (s - 6) + 1); }
                     } else {
-                        // raw(n+2): VGPR -> raw[vb] (its previous content was transformed during unit n-1), then the
-                        // loads of raw(n+3) reuse the registers
+                        // raw(n+2) -> raw[vb] (its previous content was transformed during unit n-1)
                         if constexpr (FUSE) {
-                            // raw(n+3) is COMPUTED from the image patch: see f_row
+                            // computed one unit ahead: raw(n+2) sits in rreg, raw(n+3) is COMPUTED from the image patch (f_row)
                             if (s == 0) f_weights(ld_chunk, 0);
                             else if (s == 1) raw_put(vb);
                             else if (s == 2) f_weights(ld_chunk, 1);
@@ -434,8 +493,21 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                                 else if (c == 1 && has_next) patch_put(cur_pb ^ 1);
                             }
                         } else {
-                            if (s == 1) raw_put(vb);
-                            else if (s == 3) { raw_mark(); raw_load(rbase, ld_chunk); ld_advance(); }
+                            if (s < NRAW) raw_dma(rbase, ld_chunk, vb, s);
+                            else if (s == NRAW) ld_advance();
+                        }
+                        if (s == 13) {
+                            // unit barrier: every V(n) / U(n) read has been issued (fragments are fetched two positions
+                            // ahead), V(n+1) is written, and the DMAs of the unit (issued before position 8) have had six
+                            // positions to land
+#ifdef MP_TIMING
+                            t_b0 = __builtin_amdgcn_s_memtime();
+#endif
+                            dma_wait();
+                            __syncthreads();
+#ifdef MP_TIMING
+                            t_b1 = __builtin_amdgcn_s_memtime();
+#endif
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -443,10 +515,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
             }
             ++n;
             MPW_T(t_u1);
-            MPW_ADD(0, t_u0, t_u1);                                   // MFMA steps of a unit
-            __syncthreads();                                          // V(n+1) and raw(n+2) complete, V(n) consumed
-            MPW_T(t_u2);
-            MPW_ADD(1, t_u1, t_u2);                                   // unit barrier
+            MPW_ADD(0, t_u0, t_u1);                                   // a unit incl. its barrier
+            MPW_ADD(1, t_b0, t_b1);                                   // the unit barrier alone
         };
         unit_body(0, std::true_type{});
         for (int c = 1; c < NC; ++c) unit_body(c, std::false_type{});
