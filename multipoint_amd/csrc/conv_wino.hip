@@ -49,6 +49,9 @@ extern "C" int mp_debug_read_timing_wino(unsigned long long* host, int n)
 #define MPW_ADD(slot, a, b) do { } while (0)
 #endif
 
+#ifndef MPX
+#define MPX 0      // developer elimination switches (timing only, results WRONG): 1 no transform adds, 2 no DMA, 4 no tf LDS traffic, 8 no B reads, 16 no epilogue, 32 no A reads
+#endif
 namespace {
 
 constexpr int WT = 16;                       // output tile edge
@@ -63,7 +66,8 @@ constexpr int VBUF = 16 * VPOS;              // floats per V buffer (32 KiB)
 constexpr int UBUF = 16 * 2 * 64 * 4;        // floats per U buffer: [pos][channel half][lane][4] = 32 KiB, MFMA B-fragment order
 constexpr int RS = UC;                       // raw patch pixel stride in floats: lane-linear 16-byte granules (LDS-DMA order)
 constexpr int NRAW = (NPX * 2 + 255) / 256;  // raw 16-byte granules per thread (3): granule f = tid + 256*j = pixel f>>1, quad f&1
-constexpr int RAWBUF = 11 * 64 * 4;          // floats per raw buffer: 11 wave-DMAs of 64 granules (648 used, 11264 B)
+constexpr int RAWBUF = 12 * 64 * 4;          // floats per raw buffer: 12 wave-DMAs of 64 granules (12 KiB): 648 granules used,
+                                             // block 11 is a dummy target (fourth wave's third DMA, zero-fill of unpadded slots)
 constexpr int IT = WT + 4;                   // image patch edge of the fused first block (20)
 constexpr int NPL = (IT * IT + 255) / 256;   // image patch pixels per thread (2)
 
@@ -91,17 +95,35 @@ __device__ __forceinline__ float acc_read(float a)
 // M0 (the destination base) is saved and restored: the compiler reserves it.
 __device__ __forceinline__ void dma16(const float* sbase, unsigned voff_bytes, unsigned lds_byte)
 {
+    if (MPX & 2) return;
+#ifdef MPV_M0
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
+                 :: "v"(voff_bytes), "s"(sbase), "s"(lds_byte) : "memory", "m0");
+#else
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff_bytes), "s"(sbase), "s"(lds_byte) : "memory");
+#endif
+}
+// the same for the lanes with keep >= 0 only (zero-padding slots are skipped: inactive lanes write nothing)
+__device__ __forceinline__ void dma16_masked(const float* sbase, unsigned voff_bytes, unsigned lds_byte, int keep_if_nonneg)
+{
+    if (MPX & 2) return;
+    unsigned keep;
+    unsigned long long save;
+    asm volatile("v_cmp_le_i32 vcc, 0, %4\n\ts_and_saveexec_b64 %1, vcc\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\t"
+                 "global_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0\n\ts_mov_b64 exec, %1"
+                 : "=&s"(keep), "=&s"(save) : "v"(voff_bytes), "s"(sbase), "v"(keep_if_nonneg), "s"(lds_byte) : "memory", "vcc");
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)p; }   // low 32 bits of a flat LDS address
 
-template <bool POOL, bool BNF, bool FUSE>
+// ZPAD: zero-padding model (ZeroPad2d(1): reflection_pad false, SuperPointMagicLeap); the FUSE variant reads p.pad_zero
+template <bool POOL, bool BNF, bool FUSE, bool ZPAD>
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
 {
     static_assert(!FUSE || POOL, "the fused first block feeds the pooled second encoder convolution");
+    static_assert(!(FUSE && ZPAD), "the fused variant handles both paddings at run time");
     __shared__ __attribute__((aligned(16))) float Vs[2 * VBUF];
     __shared__ __attribute__((aligned(16))) float Us[2 * UBUF];
     __shared__ __attribute__((aligned(16))) float raw[2 * RAWBUF];
@@ -144,7 +166,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
     int roff[NRAW];
     unsigned rvoff[NRAW];         // !FUSE: byte offset of the granule's source (clamped to 0 for padding / unused slots)
     bool roff_rel = false;        // roff holds the item-invariant offsets of interior items
-    bool ld_zero = false;         // the staging cursor's item has zero-padding slots (roff < 0): border item of a zero-pad model
     auto raw_offsets = [&](const Where& w) __attribute__((always_inline)) -> const float* {
         const bool interior = (w.y0 >= 1) && (w.y0 + WT < p.H) && (w.x0 >= 1) && (w.x0 + WT < p.W);
         if (interior) {
@@ -159,11 +180,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                 }
                 roff_rel = true;
             }
-            ld_zero = false;
             return w.in_base + (long long)((w.y0 - 1) * p.W + (w.x0 - 1)) * p.in_cstride;
         }
         roff_rel = false;
-        ld_zero = p.pad_zero != 0;
 #pragma unroll
         for (int j = 0; j < NRAW; ++j) {
             const int f = tid + j * 256, q = f >> 1;
@@ -195,22 +214,27 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
     f32x4 rreg[NRAW];                 // FUSE: the computed raw granules of a unit on their way to LDS
     const unsigned raw_lds = lds_addr(raw), us_lds = lds_addr(Us);
     // granule block j of this wave (64 granules = 1 KiB, block index wave + 4*j) of the staging cursor's unit -> raw[buf]
+    // There is no control flow in here on purpose: a branch inside the unit body splits it into basic blocks, and hipcc
+    // drains the LDS / memory counters at every block boundary (measured: 700 cycles per unit for four such blocks).
     auto raw_dma = [&](const float* base, int chunk, int buf, int j) __attribute__((always_inline)) {
-        const int g = wave + 4 * j;
-        if (g >= RAWBUF / 256) return;
+        if (MPX & 64) return;
+        const int g = wave + 4 * j;                          // block 11 (fourth wave, j = 2) is the dummy block
         const float* sb = base + chunk * UC;
         const unsigned dst = raw_lds + (unsigned)(buf * RAWBUF + g * 256) * 4u;
-        if (!ld_zero) {
+        if constexpr (!ZPAD) {
             dma16(sb, rvoff[j], dst);
         } else {
-            // zero-padding slots are written by their own lanes; the DMA skips them (inactive lanes write nothing)
-            if (roff[j] >= 0) dma16(sb, rvoff[j], dst);
-            else *reinterpret_cast<f32x4*>(&raw[buf * RAWBUF + g * 256 + lane * 4]) = f32x4{0.f, 0.f, 0.f, 0.f};
+            // zero-padding slots (roff < 0) are skipped by the DMA and zero-filled by their own lanes; every other lane
+            // writes its zeros into the dummy block instead (an unconditional store: no branch)
+            dma16_masked(sb, rvoff[j], dst, roff[j]);
+            const int slot = roff[j] < 0 ? g * 256 + lane * 4 : 11 * 256 + lane * 4;
+            *reinterpret_cast<f32x4*>(&raw[buf * RAWBUF + slot]) = f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     // weight block i (0..7) of this wave: position wave*4 + (i>>1), channel half i&1 of the unit whose half-0 base is `ub`
     auto u_dma = [&](const float* ub, int half_stride, int buf, int i) __attribute__((always_inline)) {
         const int b = wave * 8 + i;
+        if (MPX & 128) return;
         dma16(ub + (i & 1) * half_stride + (b >> 1) * 256, (unsigned)lane * 16u, us_lds + (unsigned)(buf * UBUF + b * 256) * 4u);
     };
     unsigned rzero = 0;           // bit j: vector j of rreg is a zero-padding slot (set when the loads are issued)
@@ -224,11 +248,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
 #pragma unroll
             for (int j = 0; j < NRAW; ++j) {
                 const int f = tid + j * 256;
-                if (f < NPX * 2) {
-                    f32x4 v = rreg[j];
-                    if ((rzero >> j) & 1u) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                    *reinterpret_cast<f32x4*>(&raw[buf * RAWBUF + f * 4]) = v;
-                }
+                f32x4 v = rreg[j];
+                if ((rzero >> j) & 1u) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                // unconditional store (no branch inside the unit body): granules beyond the patch go to the dummy block
+                *reinterpret_cast<f32x4*>(&raw[buf * RAWBUF + (f < NPX * 2 ? f * 4 : 11 * 256 + lane * 4)]) = v;
             }
         }
     };
@@ -316,6 +339,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
     const int tw_base = t_tile * TS + (((t_cg >> 1) ^ ((t_tile >> 4) & 1)) * 4) + (t_cg & 1) * 2;
     f32x2 dd[16];
     auto tf_read = [&](int buf, int k) __attribute__((always_inline)) {      // window elements 2k, 2k+1
+        if (MPX & 4) return;
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = 2 * k + u, i = e >> 2, j = e & 3;
@@ -323,6 +347,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
         }
     };
     auto tf_rows = [&]() __attribute__((always_inline)) {                    // dd <- B^T dd (over the row index)
+        if (MPX & 1) return;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const f32x2 d0 = dd[j], d1 = dd[4 + j], d2 = dd[8 + j], d3 = dd[12 + j];
@@ -330,6 +355,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
         }
     };
     auto tf_cols = [&]() __attribute__((always_inline)) {                    // dd <- dd B (over the column index)
+        if (MPX & 1) return;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const f32x2 d0 = dd[4 * i], d1 = dd[4 * i + 1], d2 = dd[4 * i + 2], d3 = dd[4 * i + 3];
@@ -337,13 +363,19 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
         }
     };
     auto tf_write = [&](int buf, int e) __attribute__((always_inline)) {     // position e = 4*i + j
+        if (MPX & 4) return;
         *reinterpret_cast<f32x2*>(&Vs[buf * VBUF + e * VPOS + tw_base]) = dd[e];
     };
 
     // ---- GEMM operands ----
     const int a_base = (tg * 32 + (lane & 31)) * TS + (((lane >> 5) ^ ((lane >> 4) & 1)) * 4);
     const int b_base = chh * 256 + lane * 4;            // B fragment of position s: Us[buf][(2*s + chh)*256 + lane*4]
-    f32x4 bfr[4], afr[4];                               // operand rings, slot = position & 3, fetched two positions ahead
+#ifdef MPV_PF3
+    constexpr int PF = 3;
+#else
+    constexpr int PF = 2;
+#endif
+    f32x4 bfr[4], afr[4];                               // operand rings, slot = position & 3, fetched PF positions ahead
     const int u_half = NC * (16 * 64 * 4);              // floats between the two channel halves of a slice in wpack
     auto u_ptr = [&](int slice) __attribute__((always_inline)) -> const float* {      // half 0, unit 0 of a slice
         return p.wpack + (long long)slice * 2 * u_half;
@@ -420,6 +452,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
     afr[1] = *reinterpret_cast<const f32x4*>(&Vs[a_base + VPOS]);
     bfr[0] = *reinterpret_cast<const f32x4*>(&Us[b_base]);
     bfr[1] = *reinterpret_cast<const f32x4*>(&Us[b_base + 512]);
+    if (PF == 3) {
+        afr[2] = *reinterpret_cast<const f32x4*>(&Vs[a_base + 2 * VPOS]);
+        bfr[2] = *reinterpret_cast<const f32x4*>(&Us[b_base + 1024]);
+    }
 
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int n = 0;                                            // unit counter (parity selects the LDS buffers)
@@ -439,6 +475,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
         Where nxt_w = cur;
         if constexpr (FUSE) { if (has_next) nxt_w = decode(item_next); }
 
+        // the 64 MFMAs of a unit and everything that rides in their shadow: ONE basic block (no control flow inside)
         auto unit_body = [&](const int c, auto first_tag) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_tag)::value;
             const bool last = c + 1 == NC;
@@ -465,17 +502,19 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                     if (e == 0) {
                         // B fragment two positions ahead; positions 14, 15 fetch positions 0, 1 of the NEXT unit (the unit
                         // barrier sits behind position 13, so an LDS latency is never exposed at a unit boundary)
-                        bfr[(s + 2) & 3] = *reinterpret_cast<const f32x4*>(s + 2 < 16 ? &ur[(s + 2) * 512] : &urn[(s - 14) * 512]);
+                        if (!(MPX & 8)) bfr[(s + PF) & 3] = *reinterpret_cast<const f32x4*>(s + PF < 16 ? &ur[(s + PF) * 512] : &urn[(s + PF - 16) * 512]);
                         // the weights of unit n+1 -> U[vb^1] (read during unit n-1): this wave's 8 of the 32 KiB-blocks
                         if (s < 8) u_dma(un, u_half, vb ^ 1, s);
                     } else if (e == 1) {
-                        afr[(s + 2) & 3] = *reinterpret_cast<const f32x4*>(s + 2 < 16 ? &vr[a_base + (s + 2) * VPOS] : &vn[a_base + (s - 14) * VPOS]);
+                        if (!(MPX & 32)) afr[(s + PF) & 3] = *reinterpret_cast<const f32x4*>(s + PF < 16 ? &vr[a_base + (s + PF) * VPOS] : &vn[a_base + (s + PF - 16) * VPOS]);
                     } else if (e == 2) {
                         // input transform of unit n+1: raw[vb^1] -> V[vb^1], complete before the unit barrier
                         if (s < 4) { tf_read(vb ^ 1, 2 * s); tf_read(vb ^ 1, 2 * s + 1); }
                         else if (s == 4) tf_rows();
                         else if (s == 5) tf_cols();
-                        else if (s < 14) { tf_write(vb ^ 1, 2 * (s - 6)); tf_write(vb ^ 1, 2 * (s - 6) + 1); }
+                        else if (PF == 2 && s < 14) { tf_write(vb ^ 1, 2 * (s - 6)); tf_write(vb ^ 1, 2 * (s - 6) + 1); }
+                        else if (PF == 3 && s < 11) { tf_write(vb ^ 1, 3 * (s - 6)); tf_write(vb ^ 1, 3 * (s - 6) + 1); tf_write(vb ^ 1, 3 * (s - 6) + 2); }
+                        else if (PF == 3 && s == 11) tf_write(vb ^ 1, 15);
                     } else {
                         // raw(n+2) -> raw[vb] (its previous content was transformed during unit n-1)
                         if constexpr (FUSE) {
@@ -485,18 +524,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                             else if (s == 2) f_weights(ld_chunk, 1);
                             else if (s < 12) f_row((s - 3) / 3, (s - 3) % 3);
                             else if (s < 15) { if (s == 12) raw_mark(); f_act(s - 12); }
-                            else {
-                                ld_advance();
-                                // the next item's image patch: fetched during unit 0, staged during unit 1 -- the load
-                                // cursor enters that item in unit NC-4
-                                if (c == 0 && has_next) patch_load(nxt_w);
-                                else if (c == 1 && has_next) patch_put(cur_pb ^ 1);
-                            }
                         } else {
                             if (s < NRAW) raw_dma(rbase, ld_chunk, vb, s);
-                            else if (s == NRAW) ld_advance();
                         }
-                        if (s == 13) {
+                        if (s == 15 - PF) {
                             // unit barrier: every V(n) / U(n) read has been issued (fragments are fetched two positions
                             // ahead), V(n+1) is written, and the DMAs of the unit (issued before position 8) have had six
                             // positions to land
@@ -518,13 +549,31 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
             MPW_ADD(0, t_u0, t_u1);                                   // a unit incl. its barrier
             MPW_ADD(1, t_b0, t_b1);                                   // the unit barrier alone
         };
-        unit_body(0, std::true_type{});
-        for (int c = 1; c < NC; ++c) unit_body(c, std::false_type{});
+        // a unit + the cursor bookkeeping behind it (all control flow lives here, between two units)
+        auto unit = [&](const int c, auto first_tag) __attribute__((always_inline)) {
+            unit_body(c, first_tag);
+            if constexpr (FUSE) {
+                ld_advance();
+                // the next item's image patch: fetched behind unit 0, staged behind unit 1 -- the load cursor enters that
+                // item in unit NC-4
+                if (c == 0 && has_next) patch_load(nxt_w);
+                else if (c == 1 && has_next) patch_put(cur_pb ^ 1);
+            } else {
+                ld_advance();
+            }
+        };
+        unit(0, std::true_type{});
+        for (int c = 1; c < NC; ++c) unit(c, std::false_type{});
 
         MPW_T(t_e0);
         MPW_ADD(3, t_item, t_e0);                                      // whole unit loop of the item
         // ---- output transform Y = A^T M A (in registers), bias / ReLU / BN, [2x2 max-pool], store ----
-        if constexpr (POOL) {
+        if constexpr ((MPX & 16) != 0) {
+            float sink = 0.f;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) sink += acc_read(acc[s][0]);
+            if (sink == 123.456f) p.out[tid] = sink;
+        } else if constexpr (POOL) {
             // lane = output channel, register r = tile (r&3) + 8*(r>>2) + 4*(lane>>5) of the wave's tile group, i.e.
             // tile row tg*4 + (r>>2), tile column (r&3) + 4*(lane>>5).  Two registers (= two tiles) at a time so that
             // the 24 additions of Y = A^T M A and the BN affine are packed instructions.
@@ -650,8 +699,13 @@ int launch_w(const ConvParams& p, hipStream_t s)
     q.nitems = (int)nitems;
     const unsigned grid = (unsigned)std::min<long long>(256, ((nitems + 7) / 8) * 8);
     const ConvParams& pp = q;
-    if (p.bn_first) hipLaunchKernelGGL((conv_wino_kernel<POOL, true, FUSE>), dim3(grid), dim3(256), 0, s, pp);
-    else hipLaunchKernelGGL((conv_wino_kernel<POOL, false, FUSE>), dim3(grid), dim3(256), 0, s, pp);
+    if (!FUSE && p.pad_zero) {
+        if (p.bn_first) hipLaunchKernelGGL((conv_wino_kernel<POOL, true, false, true>), dim3(grid), dim3(256), 0, s, pp);
+        else hipLaunchKernelGGL((conv_wino_kernel<POOL, false, false, true>), dim3(grid), dim3(256), 0, s, pp);
+    } else {
+        if (p.bn_first) hipLaunchKernelGGL((conv_wino_kernel<POOL, true, FUSE, false>), dim3(grid), dim3(256), 0, s, pp);
+        else hipLaunchKernelGGL((conv_wino_kernel<POOL, false, FUSE, false>), dim3(grid), dim3(256), 0, s, pp);
+    }
     return 0;
 }
 

@@ -51,14 +51,14 @@ def test_forward_matches_oracle(oracle, shipped, B, H, W):
 
 
 @pytest.mark.parametrize('env', [{'MP_PERSIST_MIN_ITEMS': '1'}, {'MP_NO_PERSIST': '1'}, {'MP_NO_FUSE': '1'},
-                                 {'MP_NO_WINO_FUSE': '1'}, {'MP_NO_WINOGRAD': '1'}, {'MP_NO_WINOGRAD': '1', 'MP_NO_FUSE': '1'}])
+                                 {'MP_WINO_FUSE': '1'}, {'MP_NO_WINOGRAD': '1'}, {'MP_NO_WINOGRAD': '1', 'MP_NO_FUSE': '1'}])
 @pytest.mark.parametrize('B,H,W', [(6, 120, 160), (3, 200, 328)])
 def test_forward_kernel_variants(oracle, monkeypatch, env, B, H, W):
     """Every convolution kernel variant against the oracle on the same inputs: the persistent one-workgroup-per-CU
     kernel forced onto small launches (all tile shapes, partial tiles at the right/bottom edge), the per-tile kernel
-    only, the unfused first block (in front of the Winograd and of the direct second convolution), the first block
-    fused into the direct kernel.  The default -- first block fused into the Winograd conv2 -- is what every other
-    test of this file runs."""
+    only, the first block fused into the Winograd conv2 loader, the unfused first block in front of the direct second
+    convolution, the first block fused into the direct kernel.  The default -- standalone first block + Winograd conv2
+    with LDS-DMA staging -- is what every other test of this file runs."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     net, sd = _net(oracle, oracle.SHIPPED_MODEL_CONFIG, seed=4)          # new handle: reads the environment
@@ -72,16 +72,17 @@ def test_forward_kernel_variants(oracle, monkeypatch, env, B, H, W):
 @pytest.mark.parametrize('upd', [{}, {'reflection_pad': False}, {'bn_first': True}, {'multispectral': True}])
 @pytest.mark.parametrize('B,H,W', [(4, 72, 104), (2, 16, 16), (3, 40, 264)])
 def test_fused_first_block_equals_unfused(oracle, monkeypatch, upd, B, H, W):
-    """The first block computed inside the Winograd conv2 loader (default) against the standalone first-block kernel
-    (MP_NO_WINO_FUSE=1) on the same inputs: border and partial tiles, zero padding, bn_first, two encoders -- the
-    same k-ordered multiply-add chain, so the outputs agree to the last bits of fp32 (and both match the oracle)."""
+    """The standalone first-block kernel in front of the Winograd conv2 (default) against the first block computed inside
+    the Winograd conv2 loader (MP_WINO_FUSE=1) on the same inputs: border and partial tiles, zero padding, bn_first, two
+    encoders -- the same k-ordered multiply-add chain, so the outputs agree to the last bits of fp32 (and both match the
+    oracle)."""
     cfg = dict(oracle.SHIPPED_MODEL_CONFIG); cfg.update(upd)
     img = oracle.make_images(17 + W, B, H, W)
     flags = torch.tensor([[i % 2 == 0] for i in range(B)])
     net, sd = _net(oracle, cfg, seed=2)
-    fused = net({'image': img.cuda(), 'is_optical': flags})
-    fp, fd = fused['prob'].cpu(), fused['desc'].cpu()
-    monkeypatch.setenv('MP_NO_WINO_FUSE', '1')
+    first = net({'image': img.cuda(), 'is_optical': flags})
+    fp, fd = first['prob'].cpu(), first['desc'].cpu()
+    monkeypatch.setenv('MP_WINO_FUSE', '1')
     net2, _ = _net(oracle, cfg, seed=2)
     plain = net2({'image': img.cuda(), 'is_optical': flags})
     ref = oracle.forward(sd, img, cfg, is_optical=flags)
