@@ -568,6 +568,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
         MPW_T(t_e0);
         MPW_ADD(3, t_item, t_e0);                                      // whole unit loop of the item
         // ---- output transform Y = A^T M A (in registers), bias / ReLU / BN, [2x2 max-pool], store ----
+        // FULL: the item lies inside the image and the slice inside cout -- stores are unconditional and the epilogue is
+        // one basic block (the bounds checks of the general form put every store behind its own exec-mask branch)
+        auto epilogue = [&](auto full_tag) __attribute__((always_inline)) {
+        constexpr bool FULL = decltype(full_tag)::value;
         if constexpr ((MPX & 16) != 0) {
             float sink = 0.f;
 #pragma unroll
@@ -608,7 +612,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                 for (int u = 0; u < 2; ++u) {
                     const float v = fmaxf(fmaxf(y00[u], y01[u]), fmaxf(y10[u], y11[u]));
                     const int dy = (r + u) >> 2, dx = (r + u) & 3;               // wave-uniform part of the tile position
-                    if (oy0 + dy < Ho && ox0 + dx < Wo && chok) obase[((long long)dy * Wo + dx) * cs + lane_off] = v;
+                    if (FULL || (oy0 + dy < Ho && ox0 + dx < Wo && chok)) obase[((long long)dy * Wo + dx) * cs + lane_off] = v;
                 }
             }
         } else {
@@ -649,11 +653,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                     y10[e] = a10[0]; y10[e + 1] = a10[1]; y11[e] = a11[0]; y11[e + 1] = a11[1];
                 }
                 const int ch0 = cur.slice * 64 + cl;
-                if (ch0 + 3 < p.cout) {
-                    if (ok00) *reinterpret_cast<f32x4*>(opix + cl) = y00;
-                    if (ok01) *reinterpret_cast<f32x4*>(opix + cs + cl) = y01;
-                    if (ok10) *reinterpret_cast<f32x4*>(opix + (long long)p.W * cs + cl) = y10;
-                    if (ok11) *reinterpret_cast<f32x4*>(opix + (long long)p.W * cs + cs + cl) = y11;
+                if (FULL || ch0 + 3 < p.cout) {
+                    if (FULL || ok00) *reinterpret_cast<f32x4*>(opix + cl) = y00;
+                    if (FULL || ok01) *reinterpret_cast<f32x4*>(opix + cs + cl) = y01;
+                    if (FULL || ok10) *reinterpret_cast<f32x4*>(opix + (long long)p.W * cs + cl) = y10;
+                    if (FULL || ok11) *reinterpret_cast<f32x4*>(opix + (long long)p.W * cs + cs + cl) = y11;
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -666,6 +670,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                 }
             }
         }
+        };
+        if (cur.y0 + WT <= p.H && cur.x0 + WT <= p.W && cur.slice * 64 + 64 <= p.cout) epilogue(std::true_type{});
+        else epilogue(std::false_type{});
         MPW_T(t_e1);
         MPW_ADD(2, t_e0, t_e1);                                        // epilogue
 #ifdef MP_TIMING
