@@ -5,6 +5,7 @@ samples with three cv2 matcher calls each; here both images of all pairs go thro
 interleaved batch (image 2p = optical, 2p+1 = thermal), keypoints stay on the device as fixed-capacity
 lists, and all pairs are matched by one launch.  Nothing synchronises until results are read."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -106,7 +107,7 @@ class PairPipeline:
         main = torch.cuda.current_stream(dev)
         if self.overlap_post:
             if self._post_stream is None or self._post_stream.device != dev:
-                self._post_stream = torch.cuda.Stream(device=dev)
+                self._post_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("MP_POST_PRIORITY", "0")))
             post = self._post_stream
             post.wait_stream(main)
             for t in (out['prob'], out['desc'], valid_mask):

@@ -124,3 +124,56 @@ def test_f16_full_path_config5_shape(oracle, f16):
         q, t = rec['match_query'], rec['match_train']
         best_row = dist.min(axis=1)[q]; best_col = dist.min(axis=0)[t]
         assert np.all(dist[q, t] <= best_row + 1e-5) and np.all(dist[q, t] <= best_col + 1e-5)
+
+
+def _ulp16(x):
+    """fp16 spacing at |x| (normal range; 2^-24 for subnormals)."""
+    a = np.maximum(np.abs(x.astype(np.float64)), 2.0 ** -14)
+    return 2.0 ** (np.floor(np.log2(a)) - 10)
+
+
+def test_f16_error_distribution_is_unbiased_noise(oracle, f16):
+    """Max-norm bounds cannot tell a correct fp16 kernel from one with a systematic bias (a half-ulp offset passes 2e-2).
+    Distribution of the error against the fp16 oracle, in units of the fp16 spacing of the quantity the network itself
+    rounds: detector logits (fp16 values on both sides) and the descriptor map, 2 x 480x640.  Two correct implementations
+    differ by rounding flips that compound through 12 layers: most elements agree to within a step, the tail is a few
+    steps, and the signed mean is a small fraction of the absolute mean (no bias)."""
+    net, sd, cfg = f16
+    img = oracle.make_images(321, 2, 480, 640)
+    net.set_force_return_logits(True)
+    try:
+        lg = net({'image': img.cuda()})['logits'].cpu().numpy()
+    finally:
+        net.set_force_return_logits(False)
+    out = net({'image': img.cuda()})
+    ref_l = oracle.forward(sd, img, cfg, return_logits=True)['logits'].numpy()
+    ref = oracle.forward(sd, img, cfg)
+    # logits are sums of O(10) terms that cancel (the dustbin sits near 11): their fp16 noise is absolute, one step = the
+    # spacing at magnitude 8..16 (2^-7), not the spacing of a logit that happens to be near zero
+    e = (lg.astype(np.float64) - ref_l) / _ulp16(np.maximum(np.abs(ref_l), 8.0))
+    ae = np.abs(e)
+    stats = dict(median=float(np.median(ae)), p999=float(np.percentile(ae, 99.9)), max=float(ae.max()),
+                 mean_signed=float(e.mean()), mean_abs=float(ae.mean()))
+    print('\n[f16 logits, fp16 steps] %s' % stats)
+    assert stats['median'] <= 1.0 and stats['p999'] <= 4.0, stats           # observed 0.25 / 2.0 (max 4)
+    assert abs(stats['mean_signed']) <= 0.02 * stats['mean_abs'], stats         # observed 4e-4 of the mean |error|
+    # descriptors: unit vectors in fp32 built from an fp16 map -> error in units of the fp16 step of each component
+    d, rd = out['desc'].cpu().numpy(), ref['desc'].numpy()
+    # one step = the fp16 spacing of the pixel's largest component (the raw map is rounded to fp16 BEFORE it is normalised,
+    # so the quantisation of a unit descriptor is set by its large components, not by a component that is near zero)
+    ed = (d.astype(np.float64) - rd) / _ulp16(np.abs(rd).max(axis=1, keepdims=True))
+    aed = np.abs(ed)
+    dstats = dict(median=float(np.median(aed)), p999=float(np.percentile(aed, 99.9)), max=float(aed.max()),
+                  mean_signed=float(ed.mean()), mean_abs=float(aed.mean()))
+    print('[f16 desc, fp16 steps] %s' % dstats)
+    assert dstats['median'] <= 1.0 and dstats['p999'] <= 4.0, dstats        # observed 0.26 / 1.97 (max 3.3)
+    assert abs(dstats['mean_signed']) <= 0.02 * dstats['mean_abs'], dstats
+    # prob: relative error on the pixels that matter (above the detection threshold), and its sign
+    p, rp = out['prob'].cpu().numpy().astype(np.float64), ref['prob'].numpy().astype(np.float64)
+    m = rp > 0.015
+    rel = (p[m] - rp[m]) / rp[m]
+    pstats = dict(n=int(m.sum()), median_abs_rel=float(np.median(np.abs(rel))), p999_abs_rel=float(np.percentile(np.abs(rel), 99.9)),
+                  mean_signed_rel=float(rel.mean()), mean_abs_rel=float(np.abs(rel).mean()))
+    print('[f16 prob > 0.015, relative] %s' % pstats)
+    assert pstats['median_abs_rel'] <= 1e-2 and pstats['p999_abs_rel'] <= 5e-2, pstats     # observed 4.9e-3 / 2.3e-2
+    assert abs(pstats['mean_signed_rel']) <= 0.05 * pstats['mean_abs_rel'], pstats          # observed 3e-3 of it
