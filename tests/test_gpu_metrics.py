@@ -334,3 +334,44 @@ def test_descriptor_metrics_matcher_config(oracle):
         assert np.array_equal(r['tp_optical'], ref['tp_optical'])
         assert len(r['pts_dist']) == 4 and r['h_correctness'] is not None
     assert (np.asarray(ref['pts_dist']) < 999).any()                   # at least one homography was estimated
+
+
+@pytest.mark.parametrize('outlier_frac,K', [(0.1, 300), (0.5, 800), (0.75, 1000)])
+def test_find_homography_against_opencv_semantics(outlier_frac, K):
+    """mp_find_homography against the INDEPENDENT restatement of cv2.findHomography(..., cv2.RANSAC, thr) (oracle/
+    cv_homography.py: adaptive iteration bound at confidence 0.995, refit on the consensus set, Levenberg-Marquardt polish)
+    -- the product's kernel is a different design (all hypotheses in parallel, DLT refit, no LM), so the comparison is the
+    one that matters to the reference's metrics (evaluation.py:330-356): corner error against the planted model, agreement
+    of the h_correctness decision (mean corner distance < 3 px), and overlap of the inlier sets."""
+    import multipoint_amd.utils as U
+    from oracle import cv_homography as CV
+    rng = np.random.default_rng(int(outlier_frac * 100) + K)
+    P, H, W, thr = 8, 480, 640, 3.0
+    res, kp, cnt, midx, planted = _planted(rng, P, K, H, W, outlier_frac)
+    Hm, mask, nin = U.find_homography(res, thr, max_iters=2000, seed=3)
+    Hm = Hm.cpu().numpy(); mask = mask.cpu().numpy().astype(bool)
+    corners = np.array([[0, 0, 1], [W, 0, 1], [0, H, 1], [W, H, 1]], dtype=np.float64)
+
+    def corner_err(Ha, Hb):
+        a = corners @ Ha.T; b = corners @ Hb.T
+        return np.linalg.norm(a[:, :2] / a[:, 2:3] - b[:, :2] / b[:, 2:3], axis=1).mean()
+    worst_delta, ious, agree = 0.0, [], 0
+    for p in range(P):
+        n = cnt[2 * p]
+        q = np.nonzero(midx[p, :n] >= 0)[0]; t = midx[p, q]
+        a = kp[2 * p, q][:, ::-1].astype(np.float64); b = kp[2 * p + 1, t][:, ::-1].astype(np.float64)
+        Hcv, mcv = CV.find_homography_ransac(a, b, thr, seed=p)
+        assert Hcv is not None and Hm[p].any()
+        hm, bad = planted[p]
+        e_gpu, e_cv = corner_err(Hm[p], hm), corner_err(Hcv, hm)
+        worst_delta = max(worst_delta, abs(e_gpu - e_cv))
+        agree += (e_gpu < 3.0) == (e_cv < 3.0)
+        mg = mask[p, q]; mc = mcv.astype(bool)
+        ious.append((mg & mc).sum() / max((mg | mc).sum(), 1))
+        # both recover the planted model to well under the 3 px correctness threshold
+        assert e_gpu < 1.5 and e_cv < 1.5, (p, e_gpu, e_cv)
+    print('\n[findHomography vs OpenCV semantics, outliers %.2f] max |corner error delta| %.3f px, min inlier IoU %.3f'
+          % (outlier_frac, worst_delta, min(ious)))
+    assert agree == P                       # the same h_correctness on every pair
+    assert worst_delta < 0.75               # LM polish vs DLT refit: sub-pixel differences only
+    assert min(ious) > 0.85
