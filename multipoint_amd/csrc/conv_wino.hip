@@ -115,6 +115,13 @@ __device__ __forceinline__ void dma16_masked(const float* sbase, unsigned voff_b
                  "global_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0\n\ts_mov_b64 exec, %1"
                  : "=&s"(keep), "=&s"(save) : "v"(voff_bytes), "s"(sbase), "v"(keep_if_nonneg), "s"(lds_byte) : "memory", "vcc");
 }
+#ifdef MPV_NT
+__device__ __forceinline__ void st1(float* q, float v) { __builtin_nontemporal_store(v, q); }
+__device__ __forceinline__ void st4(float* q, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(q)); }
+#else
+__device__ __forceinline__ void st1(float* q, float v) { *q = v; }
+__device__ __forceinline__ void st4(float* q, f32x4 v) { *reinterpret_cast<f32x4*>(q) = v; }
+#endif
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)p; }   // low 32 bits of a flat LDS address
 
@@ -458,7 +465,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
     }
 
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int n = 0;                                            // unit counter (parity selects the LDS buffers)
     int cur_pb = 0;                                       // FUSE: image patch buffer of the item being multiplied
 #ifdef MP_TIMING
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -476,10 +482,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
         if constexpr (FUSE) { if (has_next) nxt_w = decode(item_next); }
 
         // the 64 MFMAs of a unit and everything that rides in their shadow: ONE basic block (no control flow inside)
-        auto unit_body = [&](const int c, auto first_tag) __attribute__((always_inline)) {
+        // The buffer parity is a compile-time constant (units are unrolled in pairs; the number of units per item is even),
+        // so every LDS address of the body is a register + immediate: no address arithmetic rides in the MFMA shadow,
+        // where a lone VALU instruction costs 12 cycles.
+        auto unit_body = [&](const int c, auto first_tag, auto vb_tag) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_tag)::value;
+            constexpr int vb = decltype(vb_tag)::value;               // V / U buffer of this unit; raw(n+1) is in raw[vb ^ 1]
             const bool last = c + 1 == NC;
-            const int vb = n & 1;                                     // V / U buffer of this unit; raw(n+1) is in raw[vb ^ 1]
             const float* const vr = Vs + vb * VBUF;
             const float* const ur = Us + vb * UBUF + b_base;
             const float* const un = last ? unext : up + (c + 1) * (16 * 64 * 4);     // U(n+1): half 0 of the next unit
@@ -544,14 +553,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
-            ++n;
             MPW_T(t_u1);
             MPW_ADD(0, t_u0, t_u1);                                   // a unit incl. its barrier
             MPW_ADD(1, t_b0, t_b1);                                   // the unit barrier alone
         };
         // a unit + the cursor bookkeeping behind it (all control flow lives here, between two units)
-        auto unit = [&](const int c, auto first_tag) __attribute__((always_inline)) {
-            unit_body(c, first_tag);
+        auto unit = [&](const int c, auto first_tag, auto vb_tag) __attribute__((always_inline)) {
+            unit_body(c, first_tag, vb_tag);
             if constexpr (FUSE) {
                 ld_advance();
                 // the next item's image patch: fetched behind unit 0, staged behind unit 1 -- the load cursor enters that
@@ -562,8 +570,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                 ld_advance();
             }
         };
-        unit(0, std::true_type{});
-        for (int c = 1; c < NC; ++c) unit(c, std::false_type{});
+        using VB0 = std::integral_constant<int, 0>;
+        using VB1 = std::integral_constant<int, 1>;
+        unit(0, std::true_type{}, VB0{});
+        for (int c = 1; c + 1 < NC; c += 2) {
+            unit(c, std::false_type{}, VB1{});
+            unit(c + 1, std::false_type{}, VB0{});
+        }
+        unit(NC - 1, std::false_type{}, VB1{});
 
         MPW_T(t_e0);
         MPW_ADD(3, t_item, t_e0);                                      // whole unit loop of the item
@@ -612,7 +626,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                 for (int u = 0; u < 2; ++u) {
                     const float v = fmaxf(fmaxf(y00[u], y01[u]), fmaxf(y10[u], y11[u]));
                     const int dy = (r + u) >> 2, dx = (r + u) & 3;               // wave-uniform part of the tile position
-                    if (FULL || (oy0 + dy < Ho && ox0 + dx < Wo && chok)) obase[((long long)dy * Wo + dx) * cs + lane_off] = v;
+                    if (FULL || (oy0 + dy < Ho && ox0 + dx < Wo && chok)) st1(&obase[((long long)dy * Wo + dx) * cs + lane_off], v);
                 }
             }
         } else {
@@ -654,10 +668,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                 }
                 const int ch0 = cur.slice * 64 + cl;
                 if (FULL || ch0 + 3 < p.cout) {
-                    if (FULL || ok00) *reinterpret_cast<f32x4*>(opix + cl) = y00;
-                    if (FULL || ok01) *reinterpret_cast<f32x4*>(opix + cs + cl) = y01;
-                    if (FULL || ok10) *reinterpret_cast<f32x4*>(opix + (long long)p.W * cs + cl) = y10;
-                    if (FULL || ok11) *reinterpret_cast<f32x4*>(opix + (long long)p.W * cs + cs + cl) = y11;
+                    if (FULL || ok00) st4(opix + cl, y00);
+                    if (FULL || ok01) st4(opix + cs + cl, y01);
+                    if (FULL || ok10) st4(opix + (long long)p.W * cs + cl, y10);
+                    if (FULL || ok11) st4(opix + (long long)p.W * cs + cs + cl, y11);
                 } else {
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
@@ -699,6 +713,7 @@ int launch_w(const ConvParams& p, hipStream_t s)
     q.tiles_x = (p.W + WT - 1) / WT; q.tiles_y = (p.H + WT - 1) / WT;
     const long long nitems = (long long)p.B * q.tiles_x * q.tiles_y * p.nslices;
     if (nitems <= 0) return 0;
+    if (p.cin % (2 * UC) != 0) return 1;        // units are unrolled in pairs (api.hip pads cin to a multiple of 32)
     auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ull / (unsigned)d) + 1ull); };
     q.magic_slices = magic(p.nslices); q.magic_tx = magic(q.tiles_x); q.magic_ty = magic(q.tiles_y);
     const long long dmax = std::max(std::max(p.nslices, q.tiles_x), q.tiles_y);
