@@ -7,7 +7,9 @@ import multipoint_amd.models as models
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 H = int(sys.argv[2]) if len(sys.argv) > 2 else 480
 W = int(sys.argv[3]) if len(sys.argv) > 3 else 640
-cfg = O.SHIPPED_MODEL_CONFIG
+cfg = dict(O.SHIPPED_MODEL_CONFIG)
+if len(sys.argv) > 4 and sys.argv[4] == 'f16':
+    cfg['mixed_precision'] = True             # BASELINE configs[4]: fp16 MFMA path
 sd = O.make_weights(0, cfg)
 ZERO = os.environ.get('ZERO') == '1'
 if ZERO:

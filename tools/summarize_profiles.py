@@ -26,60 +26,86 @@ def short(name):
 def counters(prefix):
     """{(kernel, grid): {counter: [values per dispatch]}} in first-seen order."""
     agg = collections.OrderedDict()
-    with open(os.path.join(src, prefix + '_counter_collection.csv')) as f:
+    path = os.path.join(src, prefix + '_counter_collection.csv')
+    if not os.path.exists(path):
+        return agg
+    with open(path) as f:
         for r in csv.DictReader(f):
             key = (short(r['Kernel_Name']), int(r['Grid_Size']))
             agg.setdefault(key, collections.defaultdict(list))[r['Counter_Name']].append(float(r['Counter_Value']))
     return agg
 
 
-shutil.copy(os.path.join(src, 'stats_kernel_stats.csv'), os.path.join(dst, tag + '_bench_kernel_stats.csv'))
+def summarize(prefix, suffix, dominant, nper, bench_cmd, layers_cmd):
+    """prefix: '' (headline workload) or 'c5_'; dominant: the instantiation bench.py's roofline block is about; nper: how
+    many launches of that instantiation one forward makes (the largest one is the dominant launch)."""
+    stats = os.path.join(src, prefix + 'stats_kernel_stats.csv')
+    if os.path.exists(stats):
+        shutil.copy(stats, os.path.join(dst, tag + '_bench%s_kernel_stats.csv' % suffix))
+    fetch, write = counters(prefix + 'fetch'), counters(prefix + 'write')
+    kernels = []
+    for key, c in fetch.items():
+        f = c['FETCH_SIZE']
+        w = write.get(key, {}).get('WRITE_SIZE', [0.0])
+        fe = sum(f) / len(f) * 1024.0                           # rocprofv3 reports KB
+        wr = sum(w) / len(w) * 1024.0
+        kernels.append({'kernel': key[0], 'grid_threads': key[1], 'launches': len(f), 'fetch_size_bytes': fe,
+                        'fetch_bytes_corrected': 2 * fe, 'write_size_bytes': wr})
+    out = {'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only, '
+                   'tools/collect_profiles.sh) on `%s`; bytes per launch; fetch_bytes_corrected = 2 x FETCH_SIZE (gfx950 '
+                   'reports half of a wide 16 B/lane coalesced stream, MI355X_MICROARCH.md section HBM); WRITE_SIZE '
+                   'uncalibrated' % bench_cmd,
+           'kernels': kernels, 'dominant_kernel': dominant, 'dominant_kernel_launches_per_forward': nper}
+    keys = [k for k in fetch if k[0] == dominant]
+    if keys:
+        key = keys[0]
+        f = fetch[key]['FETCH_SIZE']; w = write.get(key, {}).get('WRITE_SIZE', [])
+        per = []
+        for i in range(nper):
+            fi = f[i::nper]; wi = w[i::nper] or [0.0]
+            per.append({'launch_position': i, 'fetch_size_bytes': sum(fi) / len(fi) * 1024.0,
+                        'fetch_bytes_corrected': 2 * sum(fi) / len(fi) * 1024.0, 'write_size_bytes': sum(wi) / len(wi) * 1024.0})
+        out['dominant_kernel_by_launch_position'] = per
+        d = max(per, key=lambda r: r['fetch_size_bytes'] + r['write_size_bytes'])
+        out['dominant_kernel_mean_traffic_bytes_per_launch'] = d['fetch_bytes_corrected'] + d['write_size_bytes']
+    if kernels:
+        json.dump(out, open(os.path.join(dst, tag + '_pmc_hbm_traffic%s.json' % suffix), 'w'), indent=1)
+    print(prefix or 'c3', 'dominant traffic', out.get('dominant_kernel_mean_traffic_bytes_per_launch'))
 
-# encoder conv1+conv2 (first block fused into the Winograd conv2) @480x640: one launch per step of this instantiation
-DOMINANT = 'conv_wino_kernel<true, false, true>'
+    mf = counters(prefix + 'mfma')
+    if not mf:
+        return
+    path = os.path.join(dst, tag + '_pmc_mfma_busy%s.csv' % suffix)
+    with open(path, 'w') as f:
+        f.write('# rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace '
+                '-- %s (mean over the profiled launches of each (kernel, launch size); mfma_busy = share of SIMD '
+                'cycles in which the matrix pipe is busy = issued MFMA FLOPs / peak at the clock the launch ran at)\n' % layers_cmd)
+        f.write('kernel,grid_threads,launches,gui_active_cycles,mfma_busy_cycles,mfma_busy_pct_of_simd_cycles\n')
+        # per (kernel, duration class): the same instantiation serves several layers with one grid size, so group the
+        # dispatches of a kernel by their position inside a forward pass (they repeat with the same period)
+        rows = collections.OrderedDict()
+        with open(os.path.join(src, prefix + 'mfma_counter_collection.csv')) as g:
+            disp = collections.OrderedDict()
+            for r in csv.DictReader(g):
+                d = disp.setdefault(int(r['Dispatch_Id']), {'name': short(r['Kernel_Name']), 'grid': int(r['Grid_Size'])})
+                d[r['Counter_Name']] = float(r['Counter_Value'])
+        for d in disp.values():
+            if 'conv' not in d['name'] or 'GRBM_GUI_ACTIVE' not in d:
+                continue
+            # duration class: round the active cycles to 2 significant digits of their log2 bucket
+            cls = int(round(2 * __import__('math').log2(max(d['GRBM_GUI_ACTIVE'], 1.0))))
+            rows.setdefault((d['name'], d['grid'], cls), []).append(d)
+        for (name, grid, cls), ds in rows.items():
+            n = len(ds)
+            gui = sum(x['GRBM_GUI_ACTIVE'] for x in ds) / n
+            busy = sum(x['SQ_VALU_MFMA_BUSY_CYCLES'] for x in ds) / n
+            # SQ_VALU_MFMA_BUSY_CYCLES accumulates over the 1024 SIMDs (256 CUs x 4); GRBM_GUI_ACTIVE over 8 XCDs
+            pct = 100.0 * busy / 1024.0 / (gui / 8.0) if gui else 0.0
+            f.write('"%s",%d,%d,%.0f,%.0f,%.1f\n' % (name, grid, n, gui, busy, pct))
+    print(open(path).read())
 
-fetch, write = counters('fetch'), counters('write')
-kernels = []
-for key, c in fetch.items():
-    f = c['FETCH_SIZE']
-    w = write.get(key, {}).get('WRITE_SIZE', [0.0])
-    fe = sum(f) / len(f) * 1024.0                           # rocprofv3 reports KB
-    wr = sum(w) / len(w) * 1024.0
-    kernels.append({'kernel': key[0], 'grid_threads': key[1], 'launches': len(f), 'fetch_size_bytes': fe,
-                    'fetch_bytes_corrected': 2 * fe, 'write_size_bytes': wr})
-out = {'note': 'rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only, '
-               'tools/collect_profiles.sh) on `python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline`; bytes per '
-               'launch; fetch_bytes_corrected = 2 x FETCH_SIZE (gfx950 reports half of a wide 16 B/lane coalesced '
-               'stream, MI355X_MICROARCH.md section HBM); WRITE_SIZE uncalibrated',
-       'kernels': kernels, 'dominant_kernel': DOMINANT}
-# the fused instantiation is launched once per step (conv4 / conv6 use conv_wino_kernel<true, false, false>)
-NPER = 1
-key = (DOMINANT, [k for k in fetch if k[0] == DOMINANT][0][1]) if any(k[0] == DOMINANT for k in fetch) else None
-if key:
-    f = fetch[key]['FETCH_SIZE']; w = write.get(key, {}).get('WRITE_SIZE', [])
-    per = []
-    for i in range(NPER):
-        fi = f[i::NPER]; wi = w[i::NPER] or [0.0]
-        per.append({'launch_position': i, 'fetch_size_bytes': sum(fi) / len(fi) * 1024.0,
-                    'fetch_bytes_corrected': 2 * sum(fi) / len(fi) * 1024.0, 'write_size_bytes': sum(wi) / len(wi) * 1024.0})
-    out['dominant_kernel_by_launch_position'] = per
-    d = max(per, key=lambda r: r['fetch_size_bytes'])
-    out['dominant_kernel_mean_traffic_bytes_per_launch'] = d['fetch_bytes_corrected'] + d['write_size_bytes']
-json.dump(out, open(os.path.join(dst, tag + '_pmc_hbm_traffic.json'), 'w'), indent=1)
-print('dominant traffic', out.get('dominant_kernel_mean_traffic_bytes_per_launch'))
 
-mf = counters('mfma')
-with open(os.path.join(dst, tag + '_pmc_mfma_busy.csv'), 'w') as f:
-    f.write('# rocprofv3 --pmc SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace '
-            '-- python3 tools/bench_layers.py 64 (mean over the profiled launches of each conv)\n')
-    f.write('kernel,grid_threads,launches,gui_active_cycles,mfma_busy_cycles,mfma_busy_pct_of_simd_cycles\n')
-    for key, c in mf.items():
-        if 'conv' not in key[0]:
-            continue
-        n = len(c['GRBM_GUI_ACTIVE'])
-        gui = sum(c['GRBM_GUI_ACTIVE']) / n
-        busy = sum(c['SQ_VALU_MFMA_BUSY_CYCLES']) / n
-        # SQ_VALU_MFMA_BUSY_CYCLES accumulates over the 1024 SIMDs (256 CUs x 4); GRBM_GUI_ACTIVE over 8 XCDs
-        pct = 100.0 * busy / 1024.0 / (gui / 8.0) if gui else 0.0
-        f.write('"%s",%d,%d,%.0f,%.0f,%.1f\n' % (key[0], key[1], n, gui, busy, pct))
-print(open(os.path.join(dst, tag + '_pmc_mfma_busy.csv')).read())
+summarize('', '', 'conv_wino_kernel<true, false, false, false>', 3,
+          'python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline', 'python3 tools/bench_layers.py 64')
+summarize('c5_', '_c5', 'conv_f16_kernel<9, 32, true, false>', 3,
+          'python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --workload c5', 'python3 tools/bench_layers.py 16 1024 1280 f16')
