@@ -71,6 +71,7 @@ struct mp_handle {
     int persist = 8;                // persistent conv workgroups for launches with >= this many items per CU
                                     // (MP_NO_PERSIST=1: never; MP_PERSIST_MIN_ITEMS=n overrides the threshold)
     bool fuse_first = true;         // fuse the Cin=1 block into the second convolution (MP_NO_FUSE=1 disables)
+    bool head_fuse = true;          // MP_NO_HEAD_FUSE=1: separate 1x1 convolution / softmax / normalisation launches
     bool wino_fuse = false;         // MP_WINO_FUSE=1: first block computed inside the Winograd conv2 loader (default since round 2:
                                     // standalone first block + Winograd conv2 with LDS-DMA staging -- 6.50 vs 6.84 ms per 64 images)
     int* pinned = nullptr;          // small pinned host scratch (img lists, counters)
@@ -691,6 +692,7 @@ int mp_create(mp_handle** out, int device)
     { const char* e = getenv("MP_NO_FUSE"); hh->fuse_first = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_NO_WINOGRAD"); hh->wino = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_WINO_FUSE"); hh->wino_fuse = (e && e[0] == '1'); }
+    { const char* e = getenv("MP_NO_HEAD_FUSE"); hh->head_fuse = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_PERSIST_MIN_ITEMS"); if (e && atoi(e) > 0) hh->persist = atoi(e); }
     { const char* e = getenv("MP_NO_PERSIST"); if (e && e[0] == '1') hh->persist = 0; }
     if (hipHostMalloc(reinterpret_cast<void**>(&hh->pinned), 4096) != hipSuccess) {
@@ -869,6 +871,24 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
     }
     // heads
     if ((rc = run_conv(h, h->heads3, X, h->heads3.cin, 0, P, headc, 0, B, Hc, Wc, nullptr, s))) return rc;
+    if (h->head_fuse) {
+        // both 1x1 convolutions + BN + softmax / shuffle + normalisation in ONE launch that reads P once (head_tail.hip)
+        HeadTailParams t{};
+        t.x = P; t.xstride = headc; t.K = hc;
+        t.wdet = h->det1.wpack; t.bdet = h->det1.bias; t.sdet = h->det1.scale; t.tdet = h->det1.shift;
+        t.wdesc = h->desc1.wpack; t.bdesc = h->desc1.bias; t.sdesc = h->desc1.scale; t.tdesc = h->desc1.shift;
+        t.D = D; t.npx = npx; t.B = B; t.Hc = Hc; t.Wc = Wc;
+        t.prob = prob; t.logits_nchw = logits; t.desc = desc;
+        t.softmax_mode = h->cfg.softmax_mode; t.normalize = h->cfg.normalize_descriptors ? 1 : 0;
+        prof_begin(h, "heads.tail", 2.0 * hc * (65.0 + (desc ? D : 0)) * (double)npx, s);
+        const int miss = launch_head_tail(t, s);
+        prof_end(h, s);
+        if (!miss) {
+            MP_HIP(hipGetLastError());
+            return MP_OK;
+        }
+        if (h->prof) --h->prof_used;    // not covered: fall through to the separate kernels
+    }
     if ((rc = run_conv(h, h->det1, P, headc, 0, Lg, 80, 0, B, Hc, Wc, nullptr, s))) return rc;
     if (prob || logits) {
         prof_begin(h, "det.softmax_shuffle", 0.0, s);

@@ -97,6 +97,22 @@ void launch_conv_first_f16(const Conv1ParamsH& p, hipStream_t s);
 // ---------------------------------------------------------------------------------------------
 // logits [B*Hc*Wc][lstride] (65 valid) -> prob [B][Hc*8][Wc*8]  (softmax over 65, drop dustbin,
 // depth-to-space 8) and/or logits_nchw [B][65][Hc][Wc]
+// fused tail of both heads (head_tail.hip): 1x1 convolutions + BN + softmax/shuffle + L2 normalisation in one launch
+struct HeadTailParams {
+    const float* x;             // [npx][xstride] output of the 3x3 head convolution: detector channels [0,K), descriptor [K,2K)
+    int xstride, K;             // K = head channels (multiple of 32)
+    const float *wdet, *bdet, *sdet, *tdet;       // detector 1x1: pack_conv_weights(taps = 1) fragments, bias / BN scale / shift
+    const float *wdesc, *bdesc, *sdesc, *tdesc;   // descriptor 1x1 (unused when desc == nullptr)
+    int D;                      // descriptor size (64, 128 or 256)
+    long long npx;              // B * Hc * Wc
+    int B, Hc, Wc;
+    float* prob;                // [B][1][8Hc][8Wc] or nullptr
+    float* logits_nchw;         // [B][65][Hc][Wc] or nullptr
+    float* desc;                // [npx][D] or nullptr
+    int softmax_mode;           // 0: Softmax2d, 1: SuperPointMagicLeap heat map
+    int normalize;              // F.normalize the descriptors
+};
+int launch_head_tail(const HeadTailParams& p, hipStream_t s);      // 0: launched, 1: shape not covered (use the separate kernels)
 void launch_det_post(const float* logits, int lstride, int B, int Hc, int Wc, float* prob,
                      float* logits_nchw, int mode, hipStream_t s);
 void launch_det_post_f16(const _Float16* logits, int lstride, int B, int Hc, int Wc, float* prob,
