@@ -80,6 +80,27 @@ __device__ __forceinline__ int reflect_clamp_w(int v, int n)
     v = v < 0 ? 0 : v;
     return v >= n ? n - 1 : v;
 }
+// Packed fp32 add / subtract as ONE instruction each.  Written as asm because hipcc splits about half of the input
+// transform's packed operations into scalar pairs (26 v_add_f32 + 19 v_pk_add_f32 for the 32 it could be): next to the
+// MFMA stream a packed instruction costs 5 cycles and a scalar one 4 (tools/mfma_probe10.hip), so 32 packed = 160 against
+// 199 cycles per unit.
+#ifndef MPV_NOPKASM
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b)
+{
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b)
+{
+    f32x2 d;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+#else
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { return a + b; }
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) { return a - b; }
+#endif
 __device__ __forceinline__ float relu_w(float v) { return __int_as_float(max(__float_as_int(v), 0)); }
 // Accumulator element -> arch VGPR exactly where it is needed.  Left to itself hipcc copies all 256 accumulator AGPRs to
 // VGPRs at the top of the epilogue, which spills the whole loop state (and every spill reload is an s_waitcnt vmcnt(0)
@@ -358,7 +379,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const f32x2 d0 = dd[j], d1 = dd[4 + j], d2 = dd[8 + j], d3 = dd[12 + j];
-            dd[j] = d0 - d2; dd[4 + j] = d1 + d2; dd[8 + j] = d2 - d1; dd[12 + j] = d1 - d3;
+            dd[j] = pk_sub(d0, d2); dd[4 + j] = pk_add(d1, d2); dd[8 + j] = pk_sub(d2, d1); dd[12 + j] = pk_sub(d1, d3);
         }
     };
     auto tf_cols = [&]() __attribute__((always_inline)) {                    // dd <- dd B (over the column index)
@@ -366,7 +387,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const f32x2 d0 = dd[4 * i], d1 = dd[4 * i + 1], d2 = dd[4 * i + 2], d3 = dd[4 * i + 3];
-            dd[4 * i] = d0 - d2; dd[4 * i + 1] = d1 + d2; dd[4 * i + 2] = d2 - d1; dd[4 * i + 3] = d1 - d3;
+            dd[4 * i] = pk_sub(d0, d2); dd[4 * i + 1] = pk_add(d1, d2); dd[4 * i + 2] = pk_sub(d2, d1); dd[4 * i + 3] = pk_sub(d1, d3);
         }
     };
     auto tf_write = [&](int buf, int e) __attribute__((always_inline)) {     // position e = 4*i + j
