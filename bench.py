@@ -28,6 +28,11 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# Hardware queues (read by the ROCm runtime when it initialises, i.e. at the first CUDA call): RCCL creates streams of its
+# own, and with the default of 4 hardware queues the pipeline's post-processing stream then shares a queue with the
+# convolution stream -- the two serialise and a step gets 0.65 ms longer (measured: 2245 vs 2340 pairs/s with an
+# initialised RCCL communicator; no effect without one).  8 queues keep them apart.
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
 
 GFLOP_PER_IMAGE_480x640 = 51.6317        # SURVEY.md Appendix B (12 convolutions)
 PEAK_FP32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense fp32
