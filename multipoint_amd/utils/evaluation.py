@@ -65,7 +65,7 @@ def find_homography(res, reproj_threshold=3.0, max_iters=2000, seed=0):
     (predict_align_image_pair.py:205-216).  NOT OpenCV's algorithm bit for bit: every pair evaluates `max_iters` 4-point
     hypotheses in parallel (no confidence-driven early stop) and refits the best consensus set by the normalised DLT
     (OpenCV: adaptive iteration bound at confidence 0.995, refit, then a Levenberg-Marquardt polish).  Measured against an
-    independent restatement of OpenCV 4.2's published algorithm (oracle/cv_homography.py,
+    independent restatement of OpenCV 4.2's published algorithm (test infrastructure,
     tests/test_gpu_metrics.py::test_find_homography_against_opencv_semantics; planted homographies, 10-75 % outliers):
     mean corner distance differs by <= 0.11 px, the h_correctness decision (< 3 px) agrees on every pair, the inlier
     masks overlap by IoU >= 0.99 up to 50 % outliers (0.84 at 75 %: OpenCV's mask is the consensus set of its best
