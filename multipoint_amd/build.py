@@ -30,12 +30,49 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+# sources whose inline-asm LDS-DMA statements read SGPR base pointers: hipcc pads no hazards inside an asm string, so the
+# generated code is checked instead of padding every statement with s_nop (which costs 1 % of a launch)
+DMA_SOURCES = ('conv_wino.hip',)
+
+
+def check_dma_hazards(asm_path, window=8):
+    """Fail if a VALU write of an SGPR (v_readlane / v_readfirstlane: SGPR-spill reloads, uniformity copies) lands within
+    `window` instructions in front of a global_load_lds that uses that SGPR as its base: the hardware needs five wait
+    states there and nothing inserts them inside an asm statement."""
+    import re
+    lines = open(asm_path).read().split('\n')
+    n = 0
+    for i, l in enumerate(lines):
+        m = re.search(r'global_load_lds_dwordx4 v\d+, s\[(\d+):(\d+)\]', l)
+        if not m:
+            continue
+        n += 1
+        base = {int(m.group(1)), int(m.group(2))}
+        k, j = 0, i - 1
+        while j > 0 and k < window:
+            t = lines[j].strip()
+            j -= 1
+            if not t or t.startswith((';', '.')) or t.endswith(':'):
+                continue
+            k += 1
+            w = re.match(r'(v_readlane_b32|v_readfirstlane_b32) s(\d+),', t)
+            if w and int(w.group(2)) in base:
+                raise RuntimeError('%s:%d: %s writes the base SGPR of the LDS-DMA %d instructions later (needs 5 wait '
+                                   'states): open the asm statement with s_nop' % (asm_path, j + 2, t, k))
+    if n == 0:
+        raise RuntimeError('%s: no global_load_lds found -- the hazard check is looking at the wrong file' % asm_path)
+    return n
+
+
 def _compile(src):
     obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + '.o')
-    cmd = [HIPCC] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', obj]
+    extra = ['-save-temps=obj'] if src in DMA_SOURCES else []
+    cmd = [HIPCC] + FLAGS + extra + ['-c', os.path.join(CSRC, src), '-o', obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, ' '.join(cmd), r.stderr))
+    if src in DMA_SOURCES:
+        check_dma_hazards(os.path.join(OBJ_DIR, os.path.splitext(src)[0] + '-hip-amdgcn-amd-amdhsa-gfx950.s'))
     return obj
 
 

@@ -113,18 +113,16 @@ __device__ __forceinline__ float acc_read(float a)
 }
 // LDS-DMA: 64 lanes x 16 bytes from (uniform base + per-lane byte offset) to LDS bytes [lds_byte + 16*lane, +16); inactive
 // lanes write nothing.  Invisible to hipcc's s_waitcnt bookkeeping: the unit loop waits with dma_wait() before its barrier.
-// M0 (the destination base) is saved and restored: the compiler reserves it.
+// M0 (the destination base) is saved and restored: the compiler reserves it.  hipcc pads no hazards inside an asm string: a
+// VALU write of the base SGPRs (an SGPR-spill reload, a readfirstlane) needs five wait states before the DMA reads them.
+// Padding every statement with s_nop costs 1 % of a launch, so the BUILD checks the generated code instead
+// (multipoint_amd/build.py::check_dma_hazards: no such write within eight instructions of any DMA) and fails otherwise.
 __device__ __forceinline__ void dma16(const float* sbase, unsigned voff_bytes, unsigned lds_byte)
 {
     if (MPX & 2) return;
-#ifdef MPV_M0
-    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
-                 :: "v"(voff_bytes), "s"(sbase), "s"(lds_byte) : "memory", "m0");
-#else
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff_bytes), "s"(sbase), "s"(lds_byte) : "memory");
-#endif
 }
 // the same for the lanes with keep >= 0 only (zero-padding slots are skipped: inactive lanes write nothing)
 __device__ __forceinline__ void dma16_masked(const float* sbase, unsigned voff_bytes, unsigned lds_byte, int keep_if_nonneg)
@@ -136,13 +134,8 @@ __device__ __forceinline__ void dma16_masked(const float* sbase, unsigned voff_b
                  "global_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0\n\ts_mov_b64 exec, %1"
                  : "=&s"(keep), "=&s"(save) : "v"(voff_bytes), "s"(sbase), "v"(keep_if_nonneg), "s"(lds_byte) : "memory", "vcc");
 }
-#ifdef MPV_NT
-__device__ __forceinline__ void st1(float* q, float v) { __builtin_nontemporal_store(v, q); }
-__device__ __forceinline__ void st4(float* q, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(q)); }
-#else
 __device__ __forceinline__ void st1(float* q, float v) { *q = v; }
 __device__ __forceinline__ void st4(float* q, f32x4 v) { *reinterpret_cast<f32x4*>(q) = v; }
-#endif
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)p; }   // low 32 bits of a flat LDS address
 
@@ -398,11 +391,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
     // ---- GEMM operands ----
     const int a_base = (tg * 32 + (lane & 31)) * TS + (((lane >> 5) ^ ((lane >> 4) & 1)) * 4);
     const int b_base = chh * 256 + lane * 4;            // B fragment of position s: Us[buf][(2*s + chh)*256 + lane*4]
-#ifdef MPV_PF3
-    constexpr int PF = 3;
-#else
     constexpr int PF = 2;
-#endif
     f32x4 bfr[4], afr[4];                               // operand rings, slot = position & 3, fetched PF positions ahead
     const int u_half = NC * (16 * 64 * 4);              // floats between the two channel halves of a slice in wpack
     auto u_ptr = [&](int slice) __attribute__((always_inline)) -> const float* {      // half 0, unit 0 of a slice
@@ -480,10 +469,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
     afr[1] = *reinterpret_cast<const f32x4*>(&Vs[a_base + VPOS]);
     bfr[0] = *reinterpret_cast<const f32x4*>(&Us[b_base]);
     bfr[1] = *reinterpret_cast<const f32x4*>(&Us[b_base + 512]);
-    if (PF == 3) {
-        afr[2] = *reinterpret_cast<const f32x4*>(&Vs[a_base + 2 * VPOS]);
-        bfr[2] = *reinterpret_cast<const f32x4*>(&Us[b_base + 1024]);
-    }
 
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     int cur_pb = 0;                                       // FUSE: image patch buffer of the item being multiplied
@@ -542,9 +527,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                         if (s < 4) { tf_read(vb ^ 1, 2 * s); tf_read(vb ^ 1, 2 * s + 1); }
                         else if (s == 4) tf_rows();
                         else if (s == 5) tf_cols();
-                        else if (PF == 2 && s < 14) { tf_write(vb ^ 1, 2 * (s - 6)); tf_write(vb ^ 1, 2 * (s - 6) + 1); }
-                        else if (PF == 3 && s < 11) { tf_write(vb ^ 1, 3 * (s - 6)); tf_write(vb ^ 1, 3 * (s - 6) + 1); tf_write(vb ^ 1, 3 * (s - 6) + 2); }
-                        else if (PF == 3 && s == 11) tf_write(vb ^ 1, 15);
+                        else if (s < 14) { tf_write(vb ^ 1, 2 * (s - 6)); tf_write(vb ^ 1, 2 * (s - 6) + 1); }
                     } else {
                         // raw(n+2) -> raw[vb] (its previous content was transformed during unit n-1)
                         if constexpr (FUSE) {

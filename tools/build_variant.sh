@@ -7,6 +7,6 @@ NAME=$1; FLAGS=$2; SRC=${3:-conv_wino.hip}
 B=multipoint_amd/csrc/_build
 mkdir -p $B/exp
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $FLAGS -c multipoint_amd/csrc/$SRC -o $B/exp/${SRC%.hip}_$NAME.o
-OBJS=$(ls $B/*.o | grep -v "/${SRC%.hip}.o")
+OBJS=$(ls $B/*.o | grep -v "/${SRC%.hip}.o" | grep -v "amdgcn")
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o multipoint_amd/libmultipoint_hip_exp_$NAME.so $OBJS $B/exp/${SRC%.hip}_$NAME.o
 echo built multipoint_amd/libmultipoint_hip_exp_$NAME.so
