@@ -72,7 +72,11 @@ def _compile(src):
     if r.returncode != 0:
         raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, ' '.join(cmd), r.stderr))
     if src in DMA_SOURCES:
-        check_dma_hazards(os.path.join(OBJ_DIR, os.path.splitext(src)[0] + '-hip-amdgcn-amd-amdhsa-gfx950.s'))
+        stem = os.path.splitext(src)[0]
+        check_dma_hazards(os.path.join(OBJ_DIR, stem + '-hip-amdgcn-amd-amdhsa-gfx950.s'))
+        for f in os.listdir(OBJ_DIR):                      # -save-temps leftovers (19 MB): only the object is kept
+            if f.startswith(stem + '-') or f.startswith(stem + '.hip-'):
+                os.remove(os.path.join(OBJ_DIR, f))
     return obj
 
 
