@@ -92,7 +92,9 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const Conv1Params p)
         }
         const int oy = y0 + py, ox = x0 + px;
         if (oy < p.H && ox < p.W)
-            *reinterpret_cast<f32x4*>(out + ((long long)oy * p.W + ox) * C1 + c4) = o;
+            // streaming store: the 5 GB this layer writes per 64 images are read back once by the next layer, long after
+            // they have left the caches (measured 0.91 vs 0.93 ms, and the next layer runs 0.5 % faster)
+            __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(out + ((long long)oy * p.W + ox) * C1 + c4));
     }
 }
 
