@@ -32,7 +32,7 @@ def _stale(target, deps):
 
 # sources whose inline-asm LDS-DMA statements read SGPR base pointers: hipcc pads no hazards inside an asm string, so the
 # generated code is checked instead of padding every statement with s_nop (which costs 1 % of a launch)
-DMA_SOURCES = ('conv_wino.hip',)
+DMA_SOURCES = ('conv_wino.hip', 'head_tail.hip')
 
 
 def check_dma_hazards(asm_path, window=8):

@@ -10,9 +10,14 @@
 // (r&3) + 8*(r>>2) + 4*(lane>>5)).  The softmax and the L2 norm are then in-register reductions plus one exchange with
 // lane ^ 32, every register quad is 4 consecutive channels (= 4 horizontally adjacent pixels of the shuffled heat map, or
 // 16 bytes of the descriptor row), and nothing goes through LDS except the 3 x (96 + D) bias / scale / shift values.
-// Operands come straight from global memory: a lane's X fragment is 16 bytes of its own pixel's row (the 128-byte line is
-// consumed over four k-groups out of L1), the weight fragments (packed by pack_conv_weights, taps = 1) stream from L2.
+// Operands reach the matrix pipe through LDS, filled by LDS-DMA (conv_wino.hip's lesson: a DMA is free next to MFMAs, a
+// register load costs 10-45 cycles of matrix-pipe time): K is walked in chunks of 32 channels, double-buffered; per chunk
+// the workgroup's four waves share ONE copy of the weight fragments (4 x (3 + D/32) KiB, packed by pack_conv_weights with
+// taps = 1) and each wave DMAs the 8 KiB of its own 32 pixels (a lane fetches 16 bytes of its own pixel's row, so the LDS
+// image is already in fragment order); one s_waitcnt vmcnt(0) + barrier per chunk.
 #include "mp_common.h"
+
+#include <type_traits>
 
 namespace {
 
@@ -22,16 +27,29 @@ __device__ __forceinline__ float acc_rd(float a)
     asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(x) : "a"(a));
     return x;
 }
+// LDS-DMA, see conv_wino.hip: 64 lanes x 16 bytes from (uniform base + per-lane byte offset) to LDS [lds_byte + 16*lane, +16)
+__device__ __forceinline__ void dma16(const float* sbase, unsigned voff_bytes, unsigned lds_byte)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff_bytes), "s"(sbase), "s"(lds_byte) : "memory");
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ND = D / 32 descriptor blocks (0: no descriptor head)
 template <int ND>
 __global__ __launch_bounds__(256) void head_tail_kernel(const HeadTailParams p)
 {
     constexpr int NT = 3 + ND;                                    // accumulator tiles: detector 0..2, descriptor 3..
-    __shared__ __attribute__((aligned(16))) float prm[3 * (96 + 32 * (ND ? ND : 1))];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int pl = lane & 31, hf = lane >> 5;
     constexpr int NP = 96 + 32 * ND;
+    constexpr int WCH = 4 * NT * 256;                             // floats of one chunk's weights: [kgroup4][tile NT][lane][4]
+    constexpr int XCH = 2 * 4 * 256;                              // floats of one wave's X chunk: [det|desc][kgroup4][lane][4]
+    __shared__ __attribute__((aligned(16))) float wl[2 * WCH];
+    __shared__ __attribute__((aligned(16))) float xl[2 * 4 * XCH];
+    __shared__ __attribute__((aligned(16))) float prm[3 * NP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 31, hf = lane >> 5;
     for (int i = tid; i < NP; i += 256) {
         const bool det = i < 96;
         const int c = det ? i : i - 96;
@@ -39,69 +57,98 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const HeadTailParams p)
         prm[NP + i] = det ? p.sdet[c] : p.sdesc[c];
         prm[2 * NP + i] = det ? p.tdet[c] : p.tdesc[c];
     }
-    __syncthreads();
 
-    const long long tile = (long long)blockIdx.x * 4 + (tid >> 6);
-    const long long px0 = tile * 32;
-    if (px0 >= p.npx) return;
-    const long long px = px0 + pl;
-    const bool valid = px < p.npx;
-    const float* xrow = p.x + (valid ? px : p.npx - 1) * p.xstride + hf * 4;
+    // Persistent workgroups: a workgroup walks tiles of 128 consecutive pixels, gridDim.x apart; the first chunk of the next
+    // tile is DMA'd during the last chunk of the current one, so no tile pays its HBM latency in the open.  Waves (and
+    // lanes) beyond the end re-read the last pixel and store nothing -- every wave takes part in the weight DMAs and barriers.
+    const long long ntiles = (p.npx + 127) / 128;
+    long long tile = blockIdx.x;
+    long long px = 0;
+    bool valid = false;
+    unsigned xoff = 0, xoff_next = 0;
+    const float *xbase = p.x, *xbase_next = p.x;
+    auto place = [&](long long t, unsigned& off, const float*& base) __attribute__((always_inline)) {
+        const long long q = (t * 4 + wave) * 32 + pl;
+        off = (unsigned)(((q < p.npx ? q : p.npx - 1) - t * 128) * p.xstride + hf * 4) * 4u;      // bytes from the tile's first pixel
+        base = p.x + t * 128 * p.xstride;
+    };
+    place(tile, xoff, xbase);
     const int nchunks = p.K >> 5;
-    // weight fragment of N-block nb (0..), k-group kg: pack_conv_weights layout [slice64][chunk32][kgroup4][nblock2][lane][4]
-    auto wfrag = [&](const float* w, int nb, int kg) __attribute__((always_inline)) -> f32x4 {
-        const long long off = (((((long long)(nb >> 1) * nchunks + (kg >> 2)) * 4 + (kg & 3)) * 2 + (nb & 1)) * 64 + lane) * 4;
-        return *reinterpret_cast<const f32x4*>(w + off);
+    const unsigned wl_lds = (unsigned)(size_t)wl, xl_lds = (unsigned)(size_t)xl + (unsigned)wave * (XCH * 4u);
+
+    // DMA j (0 .. NT + 7) of this wave for chunk c into buffer buf: j < NT weight blocks (this wave's share of the 4 * NT:
+    // k-group = wave, tile = j), then the 8 X blocks of its own pixels
+    auto chunk_dma = [&](int c, int buf, int j, bool next_tile) __attribute__((always_inline)) {
+        if (j < NT) {
+            const int nb = j < 3 ? j : j - 3;
+            const float* w = j < 3 ? p.wdet : p.wdesc;
+            // pack_conv_weights layout [slice64][chunk32][kgroup4][nblock2][lane][4]
+            const float* src = w + (((((long long)(nb >> 1) * nchunks + c) * 4 + wave) * 2 + (nb & 1)) * 64) * 4;
+            dma16(src, (unsigned)lane * 16u, wl_lds + (unsigned)(buf * WCH + (wave * NT + j) * 256) * 4u);
+        } else {
+            const int q = j - NT, part = q >> 2, g = q & 3;
+            if (ND == 0 && part == 1) return;
+            dma16((next_tile ? xbase_next : xbase) + part * p.K + c * 32 + g * 8, next_tile ? xoff_next : xoff,
+                  xl_lds + (unsigned)(buf * 4 * XCH + (part * 4 + g) * 256) * 4u);
+        }
     };
 
+#pragma unroll
+    for (int j = 0; j < NT + 8; ++j) chunk_dma(0, 0, j, false);
+    dma_wait();
+    __syncthreads();                                              // chunk 0 and prm visible
+
+    for (;;) {
+    const bool has_next = tile + gridDim.x < ntiles;
+    if (has_next) place(tile + gridDim.x, xoff_next, xbase_next);
+    px = (tile * 4 + wave) * 32 + pl;
+    valid = px < p.npx;
     f32x16 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    const int ngroups = p.K >> 3;
-    // operand ring, RD k-groups deep: vector memory returns in order, so a weight fragment (L2) issued behind an X fragment
-    // (first touch of a line: HBM) arrives no earlier than that -- everything is fetched RD - 1 groups ahead
-    constexpr int RD = (ND <= 4) ? 3 : 2;
-    f32x4 xd[RD], xs[RD], wf[RD][NT];
-    // one operand load of k-group kg into ring slot buf: j = 0 detector X, 1 descriptor X, 2.. weight fragment j - 2
-    auto fetch1 = [&](int buf, int kg, int j) __attribute__((always_inline)) {
-        kg = kg < ngroups ? kg : ngroups - 1;
-        if (j == 0) xd[buf] = *reinterpret_cast<const f32x4*>(xrow + kg * 8);
-        else if (j == 1) { if (ND) xs[buf] = *reinterpret_cast<const f32x4*>(xrow + p.K + kg * 8); }
-        else wf[buf][j - 2] = (j - 2) < 3 ? wfrag(p.wdet, j - 2, kg) : wfrag(p.wdesc, j - 5, kg);
+    // the 16 * NT MFMAs of a chunk (buffer parity is a compile-time constant: chunks are unrolled in pairs, K is a multiple of
+    // 64 for every model -- 32-channel remainders take the generic tail below); the NT + 8 DMAs of the next chunk ride one
+    // per MFMA behind the first ones; fragments are fetched one k-group ahead
+    auto chunk = [&](int c, auto buf_tag, bool prefetch, bool next_tile) __attribute__((always_inline)) {
+        constexpr int buf = decltype(buf_tag)::value;
+        const float* const wb = wl + buf * WCH + lane * 4;
+        const float* const xb = xl + wave * XCH + buf * 4 * XCH + lane * 4;
+        f32x4 wf[2][NT], xd[2], xs[2];
+        auto frags = [&](int slot, int g) __attribute__((always_inline)) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) wf[slot][t] = *reinterpret_cast<const f32x4*>(&wb[(g * NT + t) * 256]);
+            xd[slot] = *reinterpret_cast<const f32x4*>(&xb[g * 256]);
+            if (ND) xs[slot] = *reinterpret_cast<const f32x4*>(&xb[(4 + g) * 256]);
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (g + 1 < 4) frags((g + 1) & 1, g + 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[g & 1][t][e], t < 3 ? xd[g & 1][e] : xs[g & 1][e], acc[t], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int m = (g * 4 + e) * NT + t;
+                    if (prefetch && m < NT + 8) chunk_dma(next_tile ? 0 : c + 1, buf ^ 1, m, next_tile);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        dma_wait();
+        __syncthreads();                                          // next chunk landed, this one consumed
     };
-    auto fetch = [&](int buf, int kg) __attribute__((always_inline)) {
-#pragma unroll
-        for (int j = 0; j < NT + 2; ++j) fetch1(buf, kg, j);
-    };
-    // the 4 * NT MFMAs of ring slot buf; the NT + 2 loads of the group that refills slot nbuf ride ONE per MFMA pair
-    // behind them: a burst of back-to-back vector loads costs ~45 cycles of matrix-pipe time each (tools/mfma_probe10.hip:
-    // 10 cycles at one load per MFMA, 32-48 at two to four)
-    auto step = [&](int buf, int nbuf, int nkg, bool prefetch) __attribute__((always_inline)) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wf[buf][t][e], t < 3 ? xd[buf][e] : xs[buf][e], acc[t], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                const int m = e * NT + t;
-                if (prefetch && (m & 1) == 0 && (m >> 1) < NT + 2) fetch1(nbuf, nkg, m >> 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-    };
-#pragma unroll
-    for (int i = 0; i < RD - 1; ++i) fetch(i, i);
-    // K is a multiple of 32 channels = 4 groups; the ring index must be a compile-time constant, so RD groups per trip
-    int kg = 0;
-    for (; kg + RD <= ngroups; kg += RD) {
-#pragma unroll
-        for (int i = 0; i < RD; ++i) step(i, (i + RD - 1) % RD, kg + i + RD - 1, true);
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    // (the number of chunks is even for every model: K is a multiple of 64; launch_head_tail checks it)
+    for (int c = 0; c < nchunks; c += 2) {
+        chunk(c, B0{}, true, false);
+        const bool lastc = c + 2 >= nchunks;
+        chunk(c + 1, B1{}, !lastc || has_next, lastc);
     }
-#pragma unroll
-    for (int i = 0; i < RD; ++i)
-        if (kg + i < ngroups) step(i, (i + RD - 1) % RD, kg + i + RD - 1, i + 1 < RD);
 
     // ---- detector: bias -> BN -> softmax over 65 channels -> shuffle ----
     const int cell = (int)(px % ((long long)p.Hc * p.Wc));
@@ -192,6 +239,10 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const HeadTailParams p)
             }
         }
     }
+    if (!has_next) return;
+    tile += gridDim.x;
+    xoff = xoff_next; xbase = xbase_next;
+    }
 }
 
 }  // namespace
@@ -200,10 +251,10 @@ __global__ __launch_bounds__(256) void head_tail_kernel(const HeadTailParams p)
 // caller then runs the separate 1x1 convolution / softmax / normalisation kernels)
 int launch_head_tail(const HeadTailParams& p, hipStream_t s)
 {
-    if (p.K % 32 != 0 || p.npx <= 0) return 1;
+    if (p.K % 64 != 0 || p.npx <= 0) return 1;
     const int D = p.desc ? p.D : 0;
-    const long long tiles = (p.npx + 31) / 32;
-    const dim3 grid((unsigned)((tiles + 3) / 4)), block(256);
+    const long long tiles = (p.npx + 127) / 128;                  // one workgroup per CU walks them
+    const dim3 grid((unsigned)(tiles < 256 ? tiles : 256)), block(256);
     switch (D) {
     case 0: hipLaunchKernelGGL(head_tail_kernel<0>, grid, block, 0, s, p); return 0;
     case 64: hipLaunchKernelGGL(head_tail_kernel<2>, grid, block, 0, s, p); return 0;
