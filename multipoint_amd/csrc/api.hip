@@ -629,7 +629,7 @@ int nms_common(mp_handle* h, const float* prob, const unsigned char* mask, int B
     float* list_score = work + 2 * n;
     int* remaining = static_cast<int*>(h->nms_state.p);
     MP_HIP(hipMemsetAsync(remaining, 0, 64 * 4, s));
-    launch_nms_init(prob, mask, min_prob, work, n, s);
+    // the candidate listing (prob * mask > min_prob) is fused into round 0, which reads the probability map itself
     // Rounds: a fixed number without any host read (max_rounds > 0, at most 64), or groups of 8 with one 4-byte read
     // of the undecided count after each group until it is zero (max_rounds == 0).  A round settles every chain of
     // dependent decisions inside a 32 x 32 tile, so the count of rounds is the longest chain measured in tiles: a
@@ -639,7 +639,10 @@ int nms_common(mp_handle* h, const float* prob, const unsigned char* mask, int B
     const int cap = max_rounds > 0 ? per : 4096;
     for (;;) {
         if (round >= 64) MP_HIP(hipMemsetAsync(remaining + (round & 63), 0, 8 * 4, s));      // recycle 8 counter slots
-        for (int r = 0; r < per && round < cap; ++r, ++round) launch_nms_round(work, B, H, W, fp, remaining, round, s);
+        for (int r = 0; r < per && round < cap; ++r, ++round) {
+            if (round == 0) launch_nms_round0(prob, mask, min_prob, work, B, H, W, fp, remaining, s);
+            else launch_nms_round(work, B, H, W, fp, remaining, round, s);
+        }
         if (max_rounds > 0 || round >= cap) break;
         MP_HIP(hipMemcpyAsync(h->pinned, remaining + ((round - 1) & 63), 4, hipMemcpyDeviceToHost, s));
         MP_HIP(hipStreamSynchronize(s));

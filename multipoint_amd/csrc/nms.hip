@@ -44,11 +44,15 @@ __global__ __launch_bounds__(256) void nms_init_kernel(const float* __restrict__
 // per list entry, so an iteration costs O(#undecided) instead of O(tile) -- candidates are sparse
 // (a few % of the pixels) and most of them are decided after two or three iterations.
 // RT > 0: footprint radius known at compile time (fully unrolled scan, row masks in SGPRs).
-template <int RT>
+// INIT (round 0 only): the tile is read from the probability map itself -- prob * valid_mask, thresholded (utils.py:97;
+// what nms_init_kernel writes) -- instead of from a work map a separate launch would have to write and this one re-read.
+template <int RT, bool INIT>
 __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work, int H, int W,
                                                        int tiles_x, int tiles_y, NmsFootprint fp,
                                                        int* __restrict__ flags, int ntiles_total,
-                                                       int* __restrict__ remaining, int round)
+                                                       int* __restrict__ remaining, int round,
+                                                       const float* __restrict__ prob, const uint8_t* __restrict__ mask,
+                                                       float min_prob)
 {
     __shared__ float t[(NT + 2 * MP_NMS_MAX_R) * (NT + 2 * MP_NMS_MAX_R)];
     __shared__ unsigned short list[2][NT * NT];
@@ -59,7 +63,7 @@ __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work
     const int tile_id = blockIdx.x;
     const int* fin = flags + (round & 1) * ntiles_total;
     int* fout = flags + ((round + 1) & 1) * ntiles_total;
-    if (round > 0 && fin[tile_id] == 0) {
+    if (!INIT && round > 0 && fin[tile_id] == 0) {
         if (tid == 0) fout[tile_id] = 0;
         return;
     }
@@ -75,7 +79,17 @@ __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work
     for (int f = tid; f < LW * LW; f += 256) {
         const int ly = f / LW, lx = f - ly * LW;
         const int gy = y0 + ly - R, gx = x0 + lx - R;
-        const float v = (gy >= 0 && gy < H && gx >= 0 && gx < W) ? img[(long long)gy * W + gx] : 0.f;
+        float v = 0.f;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            const long long gi = (long long)b * H * W + (long long)gy * W + gx;
+            if constexpr (INIT) {
+                v = prob[gi];
+                if (mask) v *= mask[gi] ? 1.f : 0.f;            // prob * valid_mask (predict_align_image_pair.py:128)
+                v = (v > min_prob) ? v : 0.f;                   // utils.py:97
+            } else {
+                v = work[gi];
+            }
+        }
         t[f] = v;
         if (v > 0.f && ly >= R && ly < R + NT && lx >= R && lx < R + NT)
             list[0][atomicAdd(&cnt[0], 1)] = (unsigned short)f;
@@ -182,13 +196,34 @@ void launch_nms_round(float* work, int B, int H, int W, const NmsFootprint& fp, 
     const int ntiles = B * tiles_x * tiles_y;
     if (ntiles <= 0) return;
     int* flags = remaining + 64;
+    const float* np = nullptr;
+    const uint8_t* nm = nullptr;
     if (fp.R == 3)
-        hipLaunchKernelGGL(nms_round_kernel<3>, dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
-                           tiles_y, fp, flags, ntiles, remaining, round);
+        hipLaunchKernelGGL((nms_round_kernel<3, false>), dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
+                           tiles_y, fp, flags, ntiles, remaining, round, np, nm, 0.f);
     else if (fp.R == 1)
-        hipLaunchKernelGGL(nms_round_kernel<1>, dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
-                           tiles_y, fp, flags, ntiles, remaining, round);
+        hipLaunchKernelGGL((nms_round_kernel<1, false>), dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
+                           tiles_y, fp, flags, ntiles, remaining, round, np, nm, 0.f);
     else
-        hipLaunchKernelGGL(nms_round_kernel<0>, dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
-                           tiles_y, fp, flags, ntiles, remaining, round);
+        hipLaunchKernelGGL((nms_round_kernel<0, false>), dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
+                           tiles_y, fp, flags, ntiles, remaining, round, np, nm, 0.f);
+}
+
+// round 0 with the candidate listing fused in: replaces launch_nms_init + launch_nms_round(round 0)
+void launch_nms_round0(const float* prob, const uint8_t* mask, float min_prob, float* work, int B, int H, int W,
+                       const NmsFootprint& fp, int* remaining, hipStream_t s)
+{
+    const int tiles_x = (W + NT - 1) / NT, tiles_y = (H + NT - 1) / NT;
+    const int ntiles = B * tiles_x * tiles_y;
+    if (ntiles <= 0) return;
+    int* flags = remaining + 64;
+    if (fp.R == 3)
+        hipLaunchKernelGGL((nms_round_kernel<3, true>), dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
+                           tiles_y, fp, flags, ntiles, remaining, 0, prob, mask, min_prob);
+    else if (fp.R == 1)
+        hipLaunchKernelGGL((nms_round_kernel<1, true>), dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
+                           tiles_y, fp, flags, ntiles, remaining, 0, prob, mask, min_prob);
+    else
+        hipLaunchKernelGGL((nms_round_kernel<0, true>), dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
+                           tiles_y, fp, flags, ntiles, remaining, 0, prob, mask, min_prob);
 }
