@@ -308,18 +308,19 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvParamsH p)
             }
 #pragma unroll
             for (int s = 0; s < G::STEPS; ++s) {
-                if (s + PF < G::STEPS) {
-                    bf[(s + PF) % RB][0] = wc[(s + PF) * 128];
-                    bf[(s + PF) % RB][1] = wc[(s + PF) * 128 + 64];
-                } else {
-                    bf[(s + PF) % RB][0] = wt[(s + PF - G::STEPS) * 128];
-                    bf[(s + PF) % RB][1] = wt[(s + PF - G::STEPS) * 128 + 64];
-                }
-                if (s + RA - 1 < G::STEPS) {
-                    const int sn = s + RA - 1;
-                    af[sn % RA][0] = *reinterpret_cast<const h8*>(&lds[a_base + a_off(sn)]);
-                    af[sn % RA][1] = *reinterpret_cast<const h8*>(&lds[a_base + A_MB + a_off(sn)]);
-                }
+                // ONE memory instruction behind each MFMA: issued as a burst in front of the four MFMAs of a step, the same
+                // loads cost ~45 cycles of matrix-pipe time each instead of ~10 (tools/mfma_probe10.hip)
+                const h8* const wsrc = (s + PF < G::STEPS) ? wc + (s + PF) * 128 : wt + (s + PF - G::STEPS) * 128;
+                acc[0][0] = mma(af[s % RA][0], bf[s % RB][0], (FIRST && s == 0) ? zero16 : acc[0][0]);
+                __builtin_amdgcn_sched_barrier(0);
+                bf[(s + PF) % RB][0] = wsrc[0];
+                __builtin_amdgcn_sched_barrier(0);
+                acc[0][1] = mma(af[s % RA][0], bf[s % RB][1], (FIRST && s == 0) ? zero16 : acc[0][1]);
+                __builtin_amdgcn_sched_barrier(0);
+                bf[(s + PF) % RB][1] = wsrc[64];
+                __builtin_amdgcn_sched_barrier(0);
+                acc[1][0] = mma(af[s % RA][1], bf[s % RB][0], (FIRST && s == 0) ? zero16 : acc[1][0]);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < PER_STEP; ++u) {
                     const int j = (s - S0) * PER_STEP + u;
@@ -327,10 +328,13 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvParamsH p)
                         stg[j] = *reinterpret_cast<const h8*>(in_next + (goff[j] >= 0 ? goff[j] : 0));
                 }
                 __builtin_amdgcn_sched_barrier(0);
-                acc[0][0] = mma(af[s % RA][0], bf[s % RB][0], (FIRST && s == 0) ? zero16 : acc[0][0]);
-                acc[0][1] = mma(af[s % RA][0], bf[s % RB][1], (FIRST && s == 0) ? zero16 : acc[0][1]);
-                acc[1][0] = mma(af[s % RA][1], bf[s % RB][0], (FIRST && s == 0) ? zero16 : acc[1][0]);
                 acc[1][1] = mma(af[s % RA][1], bf[s % RB][1], (FIRST && s == 0) ? zero16 : acc[1][1]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + RA - 1 < G::STEPS) {
+                    const int sn = s + RA - 1;
+                    af[sn % RA][0] = *reinterpret_cast<const h8*>(&lds[a_base + a_off(sn)]);
+                    af[sn % RA][1] = *reinterpret_cast<const h8*>(&lds[a_base + A_MB + a_off(sn)]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             MPH_T(t_steps1);
