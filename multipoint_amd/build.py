@@ -49,7 +49,7 @@ def check_dma_hazards(asm_path, window=8):
         n += 1
         base = {int(m.group(1)), int(m.group(2))}
         k, j = 0, i - 1
-        while j > 0 and k < window:
+        while j >= 0 and k < window:
             t = lines[j].strip()
             j -= 1
             if not t or t.startswith((';', '.')) or t.endswith(':'):

@@ -51,13 +51,15 @@ def test_forward_matches_oracle(oracle, shipped, B, H, W):
 
 
 @pytest.mark.parametrize('env', [{'MP_PERSIST_MIN_ITEMS': '1'}, {'MP_NO_PERSIST': '1'}, {'MP_NO_FUSE': '1'},
-                                 {'MP_WINO_FUSE': '1'}, {'MP_NO_WINOGRAD': '1'}, {'MP_NO_WINOGRAD': '1', 'MP_NO_FUSE': '1'}])
+                                 {'MP_WINO_FUSE': '1'}, {'MP_NO_WINOGRAD': '1'}, {'MP_NO_WINOGRAD': '1', 'MP_NO_FUSE': '1'},
+                                 {'MP_NO_HEAD_FUSE': '1'}])
 @pytest.mark.parametrize('B,H,W', [(6, 120, 160), (3, 200, 328)])
 def test_forward_kernel_variants(oracle, monkeypatch, env, B, H, W):
     """Every convolution kernel variant against the oracle on the same inputs: the persistent one-workgroup-per-CU
     kernel forced onto small launches (all tile shapes, partial tiles at the right/bottom edge), the per-tile kernel
     only, the first block fused into the Winograd conv2 loader, the unfused first block in front of the direct second
-    convolution, the first block fused into the direct kernel.  The default -- standalone first block + Winograd conv2
+    convolution, the first block fused into the direct kernel, the four separate head-tail launches instead of the fused
+    head_tail kernel.  The default -- standalone first block + Winograd conv2
     with LDS-DMA staging -- is what every other test of this file runs."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)

@@ -294,3 +294,25 @@ def test_bench_self_launches_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '4'], capture_output=True, text=True,
                        env=env, timeout=300)
     assert r.returncode != 0 and 'does not match WORLD_SIZE=2' in (r.stdout + r.stderr)
+
+
+def test_build_checks_dma_hazards(tmp_path):
+    """multipoint_amd/build.py refuses generated code in which a VALU write of an SGPR (spill reload / readfirstlane) sits
+    right in front of an LDS-DMA that uses it as its base (the hardware needs five wait states, hipcc pads nothing inside an
+    asm statement)."""
+    from multipoint_amd import build as b
+    ok = tmp_path / 'ok.s'
+    ok.write_text('\ts_add_u32 s12, s11, s2\n\ts_addc_u32 s13, s1, s3\n\ts_mov_b32 m0, s17\n\ts_nop 0\n'
+                  '\tglobal_load_lds_dwordx4 v48, s[12:13]\n')
+    assert b.check_dma_hazards(str(ok)) == 1
+    bad = tmp_path / 'bad.s'
+    bad.write_text('\tv_readlane_b32 s12, v90, 3\n\ts_mov_b32 m0, s17\n\ts_nop 0\n\tglobal_load_lds_dwordx4 v48, s[12:13]\n')
+    with pytest.raises(RuntimeError, match='base SGPR'):
+        b.check_dma_hazards(str(bad))
+    far = tmp_path / 'far.s'
+    far.write_text('\tv_readlane_b32 s12, v90, 3\n' + '\ts_nop 0\n' * 9 + '\tglobal_load_lds_dwordx4 v48, s[12:13]\n')
+    assert b.check_dma_hazards(str(far)) == 1
+    none = tmp_path / 'none.s'
+    none.write_text('\ts_nop 0\n')
+    with pytest.raises(RuntimeError, match='no global_load_lds'):
+        b.check_dma_hazards(str(none))
