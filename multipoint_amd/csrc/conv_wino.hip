@@ -140,9 +140,18 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)p; }   // low 32 bits of a flat LDS address
 
 // ZPAD: zero-padding model (ZeroPad2d(1): reflection_pad false, SuperPointMagicLeap); the FUSE variant reads p.pad_zero
-template <bool POOL, bool BNF, bool FUSE, bool ZPAD>
+// TC: tile columns of an item (8: 8 x 8 Winograd tiles = 16 x 16 pixels; 16: 4 x 16 tiles = 8 x 32 pixels, for layers whose
+// height is a multiple of 8 but not of 16 -- 120 x 160 -- where the square item spends 6.7 % of its rows outside the image)
+template <bool POOL, bool BNF, bool FUSE, bool ZPAD, int TC = 8>
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
 {
+    static_assert(TC == 8 || TC == 16, "an item is 64 Winograd tiles: 8 x 8 or 4 x 16");
+    static_assert(!FUSE || TC == 8, "the fused first block is written for the square item");
+    constexpr int TR = 64 / TC;                          // tile rows of an item
+    constexpr int WTX = 2 * TC, WTY = 2 * TR;            // output pixels of an item
+    constexpr int PWX = WTX + 2, PWY = WTY + 2;          // raw patch (18 x 18 or 34 x 10)
+    constexpr int NPXG = PWX * PWY;                      // patch pixels: 324 or 340 (<= 352 = 11 DMA blocks of 32 pixels)
+    static_assert(NPXG * 2 <= 11 * 64 && (NPXG * 2 + 255) / 256 == NRAW, "raw buffer geometry");
     static_assert(!FUSE || POOL, "the fused first block feeds the pooled second encoder convolution");
     static_assert(!(FUSE && ZPAD), "the fused variant handles both paddings at run time");
     __shared__ __attribute__((aligned(16))) float Vs[2 * VBUF];
@@ -178,7 +187,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
         const int bi = (int)udiv((unsigned)trow, p.magic_ty, (unsigned)p.tiles_y);
         const int ty = trow - bi * p.tiles_y;
         w.img = p.img_list ? p.img_list[bi] : bi;
-        w.y0 = ty * WT; w.x0 = tx * WT;
+        w.y0 = ty * WTY; w.x0 = tx * WTX;
         w.in_base = p.in + (long long)w.img * p.H * p.W * p.in_cstride + p.in_coff;
         return w;
     };
@@ -188,15 +197,15 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
     unsigned rvoff[NRAW];         // !FUSE: byte offset of the granule's source (clamped to 0 for padding / unused slots)
     bool roff_rel = false;        // roff holds the item-invariant offsets of interior items
     auto raw_offsets = [&](const Where& w) __attribute__((always_inline)) -> const float* {
-        const bool interior = (w.y0 >= 1) && (w.y0 + WT < p.H) && (w.x0 >= 1) && (w.x0 + WT < p.W);
+        const bool interior = (w.y0 >= 1) && (w.y0 + WTY < p.H) && (w.x0 >= 1) && (w.x0 + WTX < p.W);
         if (interior) {
             if (!roff_rel) {
 #pragma unroll
                 for (int j = 0; j < NRAW; ++j) {
                     const int f = tid + j * 256, q = f >> 1;
-                    const int py = q / PW, px = q - py * PW;
-                    if constexpr (FUSE) roff[j] = (f < NPX * 2) ? (py + 1) * IT + (px + 1) : IT + 1;   // window centre in the image patch
-                    else roff[j] = (f < NPX * 2) ? (py * p.W + px) * p.in_cstride + (f & 1) * 4 : 0;
+                    const int py = q / PWX, px = q - py * PWX;
+                    if constexpr (FUSE) roff[j] = (f < NPXG * 2) ? (py + 1) * IT + (px + 1) : IT + 1;   // window centre in the image patch
+                    else roff[j] = (f < NPXG * 2) ? (py * p.W + px) * p.in_cstride + (f & 1) * 4 : 0;
                     rvoff[j] = (unsigned)roff[j] * 4u;
                 }
                 roff_rel = true;
@@ -207,9 +216,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
 #pragma unroll
         for (int j = 0; j < NRAW; ++j) {
             const int f = tid + j * 256, q = f >> 1;
-            const int py = q / PW, px = q - py * PW;
+            const int py = q / PWX, px = q - py * PWX;
             int off = -1;
-            if (f < NPX * 2) {
+            if (f < NPXG * 2) {
                 int gy = w.y0 + py - 1, gx = w.x0 + px - 1;
                 bool zero = false;
                 if (p.pad_zero) {
@@ -272,7 +281,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                 f32x4 v = rreg[j];
                 if ((rzero >> j) & 1u) v = f32x4{0.f, 0.f, 0.f, 0.f};
                 // unconditional store (no branch inside the unit body): granules beyond the patch go to the dummy block
-                *reinterpret_cast<f32x4*>(&raw[buf * RAWBUF + (f < NPX * 2 ? f * 4 : 11 * 256 + lane * 4)]) = v;
+                *reinterpret_cast<f32x4*>(&raw[buf * RAWBUF + (f < NPXG * 2 ? f * 4 : 11 * 256 + lane * 4)]) = v;
             }
         }
     };
@@ -355,7 +364,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
 
     // ---- input transform V = B^T d B of one unit: thread = (tile t, channel pair cg) ----
     const int t_tile = tid >> 2, t_cg = tid & 3;
-    const int tr_base = (((t_tile >> 3) * 2) * PW + (t_tile & 7) * 2) * RS + t_cg * 2;     // top-left of the 4x4 window
+    const int tr_base = (((t_tile / TC) * 2) * PWX + (t_tile % TC) * 2) * RS + t_cg * 2;   // top-left of the 4x4 window
     // V[pos][tile][8]: tile t's 16-byte halves are swapped when bit 4 of t is set (conflict-free A-fragment reads)
     const int tw_base = t_tile * TS + (((t_cg >> 1) ^ ((t_tile >> 4) & 1)) * 4) + (t_cg & 1) * 2;
     f32x2 dd[16];
@@ -364,7 +373,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = 2 * k + u, i = e >> 2, j = e & 3;
-            dd[e] = *reinterpret_cast<const f32x2*>(&raw[buf * RAWBUF + tr_base + (i * PW + j) * RS]);
+            dd[e] = *reinterpret_cast<const f32x2*>(&raw[buf * RAWBUF + tr_base + (i * PWX + j) * RS]);
         }
     };
     auto tf_rows = [&]() __attribute__((always_inline)) {                    // dd <- B^T dd (over the row index)
@@ -596,9 +605,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
             for (int s = 0; s < 16; ++s) sink += acc_read(acc[s][0]);
             if (sink == 123.456f) p.out[tid] = sink;
         } else if constexpr (POOL) {
-            // lane = output channel, register r = tile (r&3) + 8*(r>>2) + 4*(lane>>5) of the wave's tile group, i.e.
-            // tile row tg*4 + (r>>2), tile column (r&3) + 4*(lane>>5).  Two registers (= two tiles) at a time so that
-            // the 24 additions of Y = A^T M A and the BN affine are packed instructions.
+            // lane = output channel, register r = tile ti = (r&3) + 8*(r>>2) + 4*(lane>>5) of the wave's tile group, i.e.
+            // tile row tg*(32/TC) + ti / TC, tile column ti % TC (the 4*(lane>>5) never carries into the row: TC is a
+            // multiple of 8).  Two registers (= two tiles) at a time so that the 24 additions of Y = A^T M A and the BN
+            // affine are packed instructions.
             const int cl = chh * 32 + (lane & 31);
             const float bia = prm[cl], scl = prm[64 + cl], sft = prm[128 + cl];
             const f32x2 bia2 = {bia, bia}, scl2 = {scl, scl}, sft2 = {sft, sft};
@@ -611,7 +621,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
             };
             const int cs = p.out_cstride;
             const int Ho = p.H >> 1, Wo = p.W >> 1;
-            const int oy0 = (cur.y0 >> 1) + tg * 4, ox0 = (cur.x0 >> 1) + 4 * (lane >> 5);
+            const int oy0 = (cur.y0 >> 1) + tg * (32 / TC), ox0 = (cur.x0 >> 1) + 4 * (lane >> 5);
             float* const obase = p.out + (((long long)cur.img * Ho + oy0) * Wo + (cur.x0 >> 1)) * cs + p.out_coff + cur.slice * 64;
             const int lane_off = 4 * (lane >> 5) * cs + cl;
             const bool chok = ch < p.cout;
@@ -629,7 +639,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const float v = fmaxf(fmaxf(y00[u], y01[u]), fmaxf(y10[u], y11[u]));
-                    const int dy = (r + u) >> 2, dx = (r + u) & 3;               // wave-uniform part of the tile position
+                    const int tb = ((r + u) & 3) + 8 * ((r + u) >> 2);           // wave-uniform part of the tile index
+                    const int dy = tb / TC, dx = tb % TC;
                     if (FULL || (oy0 + dy < Ho && ox0 + dx < Wo && chok)) st1(&obase[((long long)dy * Wo + dx) * cs + lane_off], v);
                 }
             }
@@ -637,7 +648,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
             // lane = tile (lane&31) of the wave's tile group, register r = output channel (r&3) + 8*(r>>2) + 4*(lane>>5)
             // of the wave's channel half: each register quad is 4 consecutive channels of the tile's 2x2 pixels
             const int tl = tg * 32 + (lane & 31);
-            const int oy = cur.y0 + 2 * (tl >> 3), ox = cur.x0 + 2 * (tl & 7);
+            const int oy = cur.y0 + 2 * (tl / TC), ox = cur.x0 + 2 * (tl % TC);
             const int cs = p.out_cstride;
             float* const opix = p.out + (((long long)cur.img * p.H + oy) * p.W + ox) * cs + p.out_coff + cur.slice * 64;
             const bool ok00 = (oy < p.H) & (ox < p.W), ok01 = (oy < p.H) & (ox + 1 < p.W);
@@ -689,7 +700,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
             }
         }
         };
-        if (cur.y0 + WT <= p.H && cur.x0 + WT <= p.W && cur.slice * 64 + 64 <= p.cout) epilogue(std::true_type{});
+        if (cur.y0 + WTY <= p.H && cur.x0 + WTX <= p.W && cur.slice * 64 + 64 <= p.cout) epilogue(std::true_type{});
         else epilogue(std::false_type{});
         MPW_T(t_e1);
         MPW_ADD(2, t_e0, t_e1);                                        // epilogue
@@ -710,11 +721,12 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
     }
 }
 
-template <bool POOL, bool FUSE>
+template <bool POOL, bool FUSE, int TC>
 int launch_w(const ConvParams& p, hipStream_t s)
 {
     ConvParams q = p;
-    q.tiles_x = (p.W + WT - 1) / WT; q.tiles_y = (p.H + WT - 1) / WT;
+    constexpr int WTX = 2 * TC, WTY = 2 * (64 / TC);
+    q.tiles_x = (p.W + WTX - 1) / WTX; q.tiles_y = (p.H + WTY - 1) / WTY;
     const long long nitems = (long long)p.B * q.tiles_x * q.tiles_y * p.nslices;
     if (nitems <= 0) return 0;
     if (p.cin % (2 * UC) != 0) return 1;        // units are unrolled in pairs (api.hip pads cin to a multiple of 32)
@@ -726,11 +738,11 @@ int launch_w(const ConvParams& p, hipStream_t s)
     const unsigned grid = (unsigned)std::min<long long>(256, ((nitems + 7) / 8) * 8);
     const ConvParams& pp = q;
     if (!FUSE && p.pad_zero) {
-        if (p.bn_first) hipLaunchKernelGGL((conv_wino_kernel<POOL, true, false, true>), dim3(grid), dim3(256), 0, s, pp);
-        else hipLaunchKernelGGL((conv_wino_kernel<POOL, false, false, true>), dim3(grid), dim3(256), 0, s, pp);
+        if (p.bn_first) hipLaunchKernelGGL((conv_wino_kernel<POOL, true, false, true, TC>), dim3(grid), dim3(256), 0, s, pp);
+        else hipLaunchKernelGGL((conv_wino_kernel<POOL, false, false, true, TC>), dim3(grid), dim3(256), 0, s, pp);
     } else {
-        if (p.bn_first) hipLaunchKernelGGL((conv_wino_kernel<POOL, true, FUSE, false>), dim3(grid), dim3(256), 0, s, pp);
-        else hipLaunchKernelGGL((conv_wino_kernel<POOL, false, FUSE, false>), dim3(grid), dim3(256), 0, s, pp);
+        if (p.bn_first) hipLaunchKernelGGL((conv_wino_kernel<POOL, true, FUSE, false, TC>), dim3(grid), dim3(256), 0, s, pp);
+        else hipLaunchKernelGGL((conv_wino_kernel<POOL, false, FUSE, false, TC>), dim3(grid), dim3(256), 0, s, pp);
     }
     return 0;
 }
@@ -741,7 +753,10 @@ int launch_w(const ConvParams& p, hipStream_t s)
 // fuse1: p.img / p.w1 / p.b1 / p.s1 / p.t1 describe the first encoder block, p.in is not read (pooled, cin == 64 only)
 int launch_conv_wino(const ConvParams& p, bool pool, bool fuse1, hipStream_t s)
 {
-    if (fuse1) return launch_w<true, true>(p, s);
-    if (pool) return launch_w<true, false>(p, s);
-    return launch_w<false, false>(p, s);
+    if (fuse1) return launch_w<true, true, 8>(p, s);
+    // 4 x 16-tile items (8 x 32 pixels) where they tile the layer with fewer phantom rows than 8 x 8 tiles (16 x 16 pixels)
+    const long long sq = (long long)((p.H + 15) / 16) * ((p.W + 15) / 16);
+    const long long wide = (long long)((p.H + 7) / 8) * ((p.W + 31) / 32);
+    if (wide < sq) return pool ? launch_w<true, false, 16>(p, s) : launch_w<false, false, 16>(p, s);
+    return pool ? launch_w<true, false, 8>(p, s) : launch_w<false, false, 8>(p, s);
 }
