@@ -347,10 +347,10 @@ def main():
                      'conv_mfma_persist_kernel<9,32,true,false> (enc.conv2, direct convolution)'
         else:
             issued = (conv2_flop if fused else flop) / 2.25
-            kernel = ('conv_wino_kernel<true,false,true,false> (encoder conv1 -- Cin = 1, computed on the vector pipe inside the loader '
+            kernel = ('conv_wino_kernel<true,false,true,false,8> (encoder conv1 -- Cin = 1, computed on the vector pipe inside the loader '
                       '-- fused into enc.conv2 64->64 @480x640 by Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32 + bias/ReLU/BN '
                       '+ 2x2 max-pool)') if fused else \
-                     ('conv_wino_kernel<true,false,false,false> (enc.conv2 64->64 @480x640 by Winograd F(2x2,3x3) on '
+                     ('conv_wino_kernel<true,false,false,false,8> (enc.conv2 64->64 @480x640 by Winograd F(2x2,3x3) on '
                       'v_mfma_f32_32x32x2_f32, operands staged by LDS-DMA, + bias/ReLU/BN + 2x2 max-pool)')
         ach = issued / (ms * 1e-3) / 1e12
         alg = flop / (ms * 1e-3) / 1e12
