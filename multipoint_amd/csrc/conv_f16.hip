@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256) void conv_first_f16_kernel(const Conv1ParamsH 
             o[2 * e] = r[0]; o[2 * e + 1] = r[1];
         }
         const int oy = y0 + py, ox = x0 + px;
-        if (oy < p.H && ox < p.W) *reinterpret_cast<h8*>(out + ((long long)oy * p.W + ox) * 64 + c8) = o;
+        if (oy < p.H && ox < p.W) __builtin_nontemporal_store(o, reinterpret_cast<h8*>(out + ((long long)oy * p.W + ox) * 64 + c8));   // streaming, as conv_first.hip
     }
 }
 
