@@ -24,6 +24,7 @@ struct ConvLayer {            // one MFMA conv launch
     const char* name = "";
     float *wpack = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
     float* upack = nullptr;       // 3x3 layers: Winograd-domain weights U = G g G^T (conv_wino.hip)
+    float* u43pack = nullptr;     // 3x3 layers: F(4x4,3x3) weights (conv_wino43.hip)
     _Float16* wpack_h = nullptr;  // mixed_precision: fp16 fragments (conv_f16.hip) and the fp16-rounded bias
     float* bias_h = nullptr;
     int cin = 0, cout = 0, taps = 9, nslices = 0;
@@ -71,6 +72,7 @@ struct mp_handle {
     int persist = 8;                // persistent conv workgroups for launches with >= this many items per CU
                                     // (MP_NO_PERSIST=1: never; MP_PERSIST_MIN_ITEMS=n overrides the threshold)
     bool fuse_first = true;         // fuse the Cin=1 block into the second convolution (MP_NO_FUSE=1 disables)
+    int wino43 = 1;                 // MP_WINO43: 0 off, 1 (default) F(4x4,3x3) for the 3x3 layers with 64 input channels, 2 all
     bool head_fuse = true;          // MP_NO_HEAD_FUSE=1: separate 1x1 convolution / softmax / normalisation launches
     bool wino_fuse = false;         // MP_WINO_FUSE=1: first block computed inside the Winograd conv2 loader (default since round 2:
                                     // standalone first block + Winograd conv2 with LDS-DMA staging -- 6.50 vs 6.84 ms per 64 images)
@@ -275,6 +277,38 @@ void pack_wino_weights(const std::vector<const float*>& srcs, const std::vector<
                         }
 }
 
+// Winograd F(4x4,3x3) weights for conv_wino43_kernel: U[pos = 6a+b] = (G g G^T)[a][b] with
+// G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]], evaluated in double and rounded to
+// fp32 ONCE (1/6 and 1/24 are not binary fractions).  Layout = the LDS image of a unit of 4 input channels:
+//   [slice64][unit = cin/4][ch(4)][cout(64)][pos(36)]
+void pack_wino43_weights(const std::vector<const float*>& srcs, const std::vector<int>& couts, int cin, int cin_real,
+                         std::vector<float>& out)
+{
+    static const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
+                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    int cout = 0;
+    for (int c : couts) cout += c;
+    const int nslices = (cout + 63) / 64, nunits = cin / 4;
+    out.assign((size_t)nslices * nunits * 4 * 64 * 36, 0.f);
+    for (int s = 0; s < nslices; ++s)
+        for (int u = 0; u < nunits; ++u)
+            for (int ch = 0; ch < 4; ++ch)
+                for (int co64 = 0; co64 < 64; ++co64) {
+                    int co = s * 64 + co64;
+                    const int ci = u * 4 + ch;
+                    if (co >= cout || ci >= cin_real) continue;
+                    size_t t = 0;
+                    while (co >= couts[t]) { co -= couts[t]; ++t; }
+                    const float* g = srcs[t] + ((size_t)co * cin_real + ci) * 9;
+                    double tmp[6][3];
+                    for (int a = 0; a < 6; ++a)
+                        for (int j = 0; j < 3; ++j) tmp[a][j] = G[a][0] * g[j] + G[a][1] * g[3 + j] + G[a][2] * g[6 + j];
+                    float* o = out.data() + ((((size_t)s * nunits + u) * 4 + ch) * 64 + co64) * 36;
+                    for (int a = 0; a < 6; ++a)
+                        for (int b = 0; b < 6; ++b) o[6 * a + b] = (float)(tmp[a][0] * G[b][0] + tmp[a][1] * G[b][1] + tmp[a][2] * G[b][2]);
+                }
+}
+
 // fp16 flavour for conv_f16_kernel: chunks of 64 input channels, steps of 16:
 //   [slice][chunk][step = tap*4 + kgroup][nblock(2)][lane(64)][8]
 //   element e of lane l = half(W[cout = slice*64 + nblock*32 + (l&31)][cin = chunk*64 + kgroup*16 + (l>>5)*8 + e][tap])
@@ -346,6 +380,11 @@ int build_conv(mp_handle* h, TensorMap& tm, ConvLayer& L, const char* name,
         std::vector<float> up;
         pack_wino_weights(srcs, couts, cin, cin_real, up);
         if ((rc = upload(h, up, &L.upack))) return rc;
+        if (h->wino43 && cin % 8 == 0) {
+            std::vector<float> u4;
+            pack_wino43_weights(srcs, couts, cin, cin_real, u4);
+            if ((rc = upload(h, u4, &L.u43pack))) return rc;
+        }
     }
     if (h->cfg.mixed_precision) {
         std::vector<uint16_t> ph;
@@ -485,7 +524,10 @@ int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, 
                2.0 * L.taps * L.cin * L.cout * (double)B * H * W + (fuse ? 2.0 * 9 * 64 * (double)B * H * W : 0.0), s);
     if (fuse) { p.img = images; p.w1 = fuse->w; p.b1 = fuse->bias; p.s1 = fuse->scale; p.t1 = fuse->shift; }
     int big;
-    if (L.taps == 9 && L.upack && h->wino && (!fuse || (L.pool && L.cin == 64))) {
+    if (L.taps == 9 && L.u43pack && h->wino && !fuse && (h->wino43 == 2 || L.cin == 64) && conv_wino43_supports(p)) {
+        p.wpack = L.u43pack;
+        big = launch_conv_wino43(p, L.pool, s);
+    } else if (L.taps == 9 && L.upack && h->wino && (!fuse || (L.pool && L.cin == 64))) {
         p.wpack = L.upack;
         big = launch_conv_wino(p, L.pool, fuse != nullptr, s);
     } else {
@@ -696,6 +738,7 @@ int mp_create(mp_handle** out, int device)
     { const char* e = getenv("MP_NO_WINOGRAD"); hh->wino = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_WINO_FUSE"); hh->wino_fuse = (e && e[0] == '1'); }
     { const char* e = getenv("MP_NO_HEAD_FUSE"); hh->head_fuse = !(e && e[0] == '1'); }
+    { const char* e = getenv("MP_WINO43"); if (e && e[0] >= '0' && e[0] <= '2') hh->wino43 = e[0] - '0'; }
     { const char* e = getenv("MP_PERSIST_MIN_ITEMS"); if (e && atoi(e) > 0) hh->persist = atoi(e); }
     { const char* e = getenv("MP_NO_PERSIST"); if (e && e[0] == '1') hh->persist = 0; }
     if (hipHostMalloc(reinterpret_cast<void**>(&hh->pinned), 4096) != hipSuccess) {

@@ -59,6 +59,9 @@ int launch_conv_mfma(const ConvParams& p, int taps, int mbw, bool pool, bool fus
 void launch_conv_first(const Conv1Params& p, hipStream_t s);
 // Winograd F(2x2,3x3) flavour of the 3x3 layers (conv_wino.hip); p.wpack = weights packed by pack_wino_weights()
 int launch_conv_wino(const ConvParams& p, bool pool, bool fuse1, hipStream_t s);
+// Winograd F(4x4,3x3) (conv_wino43.hip): p.wpack = pack_wino43_weights() output; supports() says whether the shape is covered
+bool conv_wino43_supports(const ConvParams& p);
+int launch_conv_wino43(const ConvParams& p, bool pool, hipStream_t s);
 
 // fp16 path (mixed_precision: activations and packed weights fp16, fp32 accumulate; conv_f16.hip).
 // Same tiling as ConvParams; a chunk is 64 input channels, so cin must be a multiple of 64.
