@@ -26,6 +26,25 @@
 #include <algorithm>
 #include <type_traits>
 
+#ifdef MP_TIMING
+// developer instrumentation (tools/conv_timing_wino.py with MP_TIMING_KERNEL=43): per-workgroup cycle sums per phase, wave 0
+__device__ unsigned long long g_timing_q[256 * 8];
+__device__ int g_timing_q_sel = 480;
+extern "C" int mp_debug_select_height_wino43(int h) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_timing_q_sel), &h, sizeof(int)); }
+extern "C" int mp_debug_read_timing_wino43(unsigned long long* host, int n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_timing_q), sizeof(unsigned long long) * n);
+}
+#define MPQ_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define MPQ_ADD(slot, a, b) do { tsum[slot] += (b) - (a); } while (0)
+#else
+#define MPQ_T(var) do { } while (0)
+#define MPQ_ADD(slot, a, b) do { } while (0)
+#endif
+
+#ifndef MPQX
+#define MPQX 0     // developer elimination switches (timing only, results WRONG): 1 no input transform, 2 no DMA, 4 no fragment reads, 8 no epilogue
+#endif
 namespace {
 
 constexpr int TR4 = 4, TC4 = 8;                    // tiles of an item: 4 rows x 8 columns
@@ -52,6 +71,7 @@ __device__ __forceinline__ float relu_q(float v) { return __int_as_float(max(__f
 // LDS-DMA, see conv_wino.hip (hazards in front of the statement are checked at build time: multipoint_amd/build.py)
 __device__ __forceinline__ void dma16(const float* sbase, unsigned voff_bytes, unsigned lds_byte)
 {
+    if (MPQX & 2) return;
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff_bytes), "s"(sbase), "s"(lds_byte) : "memory");
@@ -162,13 +182,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     // (waves 2..7 have no second block: their DMA lands there)
     auto raw_dma = [&](const float* base, int chunk, int buf, int j) __attribute__((always_inline)) {
         const int g = (wave + 8 * j < NRB) ? wave + 8 * j : NRB;
-        dma16(base + chunk * UC4, rvoff[j], raw_lds + (unsigned)(buf * RB4 + g * 256) * 4u);
+        if (MPQX & 16) return;
+        dma16(base + chunk * UC4, (MPQX & 64) ? (unsigned)lane * 16u : rvoff[j], raw_lds + (unsigned)(buf * RB4 + g * 256) * 4u);
     };
     // weight block i of this wave (36 KiB-blocks of 1 KiB per unit: waves 0-3 take 5, waves 4-7 take 4; index 36+ = dummy
     // re-load of block 35) of the unit at `ub` -> U[buf]
     auto u_dma = [&](const float* ub, int buf, int i) __attribute__((always_inline)) {
         int b = wave + 8 * i;
         b = b < 36 ? b : 35;
+        if (MPQX & 32) return;
         dma16(ub + b * 256, (unsigned)lane * 16u, us_lds + (unsigned)(buf * UB4 + b * 256) * 4u);
     };
     auto u_ptr = [&](int slice) __attribute__((always_inline)) -> const float* {      // unit 0 of a slice
@@ -192,19 +214,23 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     const int p2_write = (2 * w_cp * 32 + w_tile) * 36 + 6 * sub6;
     f32x2 td[6], tr[6];
     auto tf_pass1 = [&](int buf) __attribute__((always_inline)) {
+        if (MPQX & 1) return;
 #pragma unroll
         for (int i = 0; i < 6; ++i) td[i] = *reinterpret_cast<const f32x2*>(&raw[buf * RB4 + p1_read + i * PX * 4]);
     };
     auto tf_pass1b = [&]() __attribute__((always_inline)) {
+        if (MPQX & 1) return;
         bt6(td, tr);                                      // tr[i'] = (B^T d)[i'][column sub6]
 #pragma unroll
         for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x2*>(&myscr[(i * 6 + sub6) * 2]) = tr[i];
     };
     auto tf_pass2 = [&]() __attribute__((always_inline)) {
+        if (MPQX & 1) return;
 #pragma unroll
         for (int j = 0; j < 6; ++j) td[j] = *reinterpret_cast<const f32x2*>(&myscr[(sub6 * 6 + j) * 2]);
     };
     auto tf_pass2b = [&](int buf) __attribute__((always_inline)) {
+        if (MPQX & 1) return;
         bt6(td, tr);                                      // tr[j'] = V[row sub6][j']
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
@@ -250,7 +276,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     bf[1] = *reinterpret_cast<const f32x4*>(&Vs[b_base + 4]);
 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#ifdef MP_TIMING
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const bool t_on = ((POOL ? p.H : -p.H) == g_timing_q_sel);
+#endif
     for (;;) {
+        MPQ_T(t_item);
         f32x4 acc[36];
         const int item_next = item + stride;
         const bool has_next = item_next < item_end;
@@ -268,6 +299,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
             const float* const urn = Us + (vb ^ 1) * UB4 + a_base;
             const float* const vrn = Vs + (vb ^ 1) * VB4 + b_base;
             const float* const un = last ? unext : up + (long long)(c + 1) * UB4;
+            MPQ_T(t_u0);
+#ifdef MP_TIMING
+            unsigned long long t_b0 = 0, t_b1 = 0;
+#endif
 #pragma unroll
             for (int g = 0; g < 9; ++g) {
 #pragma unroll
@@ -276,7 +311,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                     // weights as the A operand: D[cout][tile] -- lane = tile, register quad = 4 consecutive output channels
                     acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g % 3][e], bf[g % 3][e], FIRST ? zero4 : acc[s], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (e == 0) {
+                    if (e == 0 && !(MPQX & 4)) {
                         // fragments two groups ahead; groups 7, 8 fetch groups 0, 1 of the NEXT unit (behind the unit barrier)
                         af[(g + 2) % 3] = *reinterpret_cast<const f32x4*>(g + 2 < 9 ? &ur[4 * (g + 2)] : &urn[4 * (g - 7)]);
                         bf[(g + 2) % 3] = *reinterpret_cast<const f32x4*>(g + 2 < 9 ? &vr[4 * (g + 2)] : &vrn[4 * (g - 7)]);
@@ -297,13 +332,25 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                         if (g == 6) {
                             // unit barrier: every fragment of the unit has been fetched (two groups ahead), V(n+1) is
                             // written, the DMAs of the unit were issued before group 7
+#ifdef MP_TIMING
+                            t_b0 = __builtin_amdgcn_s_memtime();
+#endif
                             dma_wait();
+#ifdef MP_TIMING
+                            t_b1 = __builtin_amdgcn_s_memtime();
+#endif
                             __syncthreads();
+#ifdef MP_TIMING
+                            tsum[4] += __builtin_amdgcn_s_memtime() - t_b1;
+#endif
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
                 }
             }
+            MPQ_T(t_u1);
+            MPQ_ADD(0, t_u0, t_u1);                                   // a unit incl. its barrier
+            MPQ_ADD(1, t_b0, t_b1);                                   // the DMA wait alone (slot 4: the barrier behind it)
         };
         auto unit = [&](const int c, auto first_tag, auto vb_tag) __attribute__((always_inline)) {
             unit_body(c, first_tag, vb_tag);
@@ -318,9 +365,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
         }
         unit(NC - 1, std::false_type{}, VB1{});
 
+        MPQ_T(t_e0);
+        MPQ_ADD(3, t_item, t_e0);                                      // whole unit loop of the item
         // ---- output transform Y = A^T M A in registers, bias / ReLU / BN, [2x2 max-pool], store ----
         // lane = tile (lane & 15) of the wave's tile block, registers r = output channels 4 * (lane >> 4) + r of its channel block
-        {
+        if (MPQX & 8) {
+            float sink = 0.f;
+#pragma unroll
+            for (int s2 = 0; s2 < 36; ++s2) sink += acc[s2][0] + acc[s2][1] + acc[s2][2] + acc[s2][3];
+            if (sink == 123.456f) p.out[tid] = sink;
+        } else {
             const int tl = tb * 16 + (lane & 15);                       // tile of the item: row tl >> 3, column tl & 7
             const int cl = cb * 16 + 4 * (lane >> 4);                   // first of this lane's 4 output channels in the slice
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(&prm[cl]);
@@ -329,8 +383,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
             const int oy = cur.y0 + 4 * (tl >> 3), ox = cur.x0 + 4 * (tl & 7);
             const int ch0 = cur.slice * 64 + cl;
             const int cs = p.out_cstride;
-            // per channel pair h (registers 2h, 2h+1): transform, activation, [pool], 8-byte stores -- the 72 accumulator
-            // registers of a finished pair are dead before the next one starts (register budget: 256 per lane)
+            // per channel pair h (registers 2h, 2h+1): transform, activation, [pool] -- the 72 accumulator registers of a
+            // finished pair are dead before the next one starts (register budget: 256 per lane); the first pair's results
+            // wait in registers so that every pixel is ONE 16-byte store of the lane's 4 channels
+            constexpr int NO = POOL ? 2 : 4;                            // output rows / columns per tile
+            f32x2 keep[NO][NO];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 f32x2 tcol[4][6];                                       // T[a][j] = sum_i A^T[a][i] M[i][j]
@@ -357,36 +414,52 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                         yv[a][b] = v;
                     }
                 }
-                const bool pairok = ch0 + 2 * h + 1 < p.cout;
-                if constexpr (POOL) {
-                    const int Ho = p.H >> 1, Wo = p.W >> 1;
-                    float* const o = p.out + (((long long)cur.img * Ho + (oy >> 1)) * Wo + (ox >> 1)) * cs + p.out_coff + ch0 + 2 * h;
+                f32x2 res[NO][NO];
 #pragma unroll
-                    for (int a = 0; a < 2; ++a)
+                for (int a = 0; a < NO; ++a)
 #pragma unroll
-                        for (int b = 0; b < 2; ++b) {
-                            f32x2 v;
+                    for (int b = 0; b < NO; ++b) {
+                        if constexpr (POOL) {
 #pragma unroll
                             for (int r = 0; r < 2; ++r)
-                                v[r] = fmaxf(fmaxf(yv[2 * a][2 * b][r], yv[2 * a][2 * b + 1][r]), fmaxf(yv[2 * a + 1][2 * b][r], yv[2 * a + 1][2 * b + 1][r]));
-                            if (((oy >> 1) + a < Ho) && ((ox >> 1) + b < Wo)) {
-                                if (pairok) *reinterpret_cast<f32x2*>(o + ((long long)a * Wo + b) * cs) = v;
-                                else if (ch0 + 2 * h < p.cout) o[((long long)a * Wo + b) * cs] = v[0];
-                            }
+                                res[a][b][r] = fmaxf(fmaxf(yv[2 * a][2 * b][r], yv[2 * a][2 * b + 1][r]),
+                                                     fmaxf(yv[2 * a + 1][2 * b][r], yv[2 * a + 1][2 * b + 1][r]));
+                        } else {
+                            res[a][b] = yv[a][b];
                         }
+                    }
+                if (h == 0) {
+#pragma unroll
+                    for (int a = 0; a < NO; ++a)
+#pragma unroll
+                        for (int b = 0; b < NO; ++b) keep[a][b] = res[a][b];
                 } else {
-                    float* const o = p.out + (((long long)cur.img * p.H + oy) * p.W + ox) * cs + p.out_coff + ch0 + 2 * h;
+                    const int Ho = POOL ? p.H >> 1 : p.H, Wo = POOL ? p.W >> 1 : p.W;
+                    const int py0 = POOL ? oy >> 1 : oy, px0 = POOL ? ox >> 1 : ox;
+                    float* const o = p.out + (((long long)cur.img * Ho + py0) * Wo + px0) * cs + p.out_coff + ch0;
+                    const bool quad_ok = ch0 + 3 < p.cout;
 #pragma unroll
-                    for (int a = 0; a < 4; ++a)
+                    for (int a = 0; a < NO; ++a)
 #pragma unroll
-                        for (int b = 0; b < 4; ++b)
-                            if ((oy + a < p.H) && (ox + b < p.W)) {
-                                if (pairok) *reinterpret_cast<f32x2*>(o + ((long long)a * p.W + b) * cs) = yv[a][b];
-                                else if (ch0 + 2 * h < p.cout) o[((long long)a * p.W + b) * cs] = yv[a][b][0];
+                        for (int b = 0; b < NO; ++b)
+                            if ((py0 + a < Ho) && (px0 + b < Wo)) {
+                                const f32x4 v = {keep[a][b][0], keep[a][b][1], res[a][b][0], res[a][b][1]};
+                                float* const q = o + ((long long)a * Wo + b) * cs;
+                                if (quad_ok) *reinterpret_cast<f32x4*>(q) = v;
+                                else
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) if (ch0 + r < p.cout) q[r] = v[r];
                             }
                 }
             }
         }
+        MPQ_T(t_e1);
+        MPQ_ADD(2, t_e0, t_e1);                                        // epilogue
+#ifdef MP_TIMING
+        tsum[7] += 1;
+        if (!has_next && tid == 0 && t_on)
+            for (int i = 0; i < 8; ++i) g_timing_q[blockIdx.x * 8 + i] = tsum[i];
+#endif
         if (!has_next) return;
         if (next_slice != cur.slice) {
             __syncthreads();

@@ -15,16 +15,17 @@ img = torch.rand(64, 1, 480, 640, device='cuda')
 for _ in range(2): net({'image': img})
 torch.cuda.synchronize()
 sel = int(os.environ.get('MP_TIMING_H', '240'))
-assert lib.mp_debug_select_height_wino(sel) == 0
+K43 = os.environ.get('MP_TIMING_KERNEL') == '43'          # conv_wino43.hip instead of conv_wino.hip
+assert (lib.mp_debug_select_height_wino43 if K43 else lib.mp_debug_select_height_wino)(sel) == 0
 net.profile(True)
 net({'image': img}); torch.cuda.synchronize()
 prof = {n: ms for n, ms, fl in net.profile_read()}
 buf = (ctypes.c_ulonglong * (256 * 8))()
-assert lib.mp_debug_read_timing_wino(buf, 256 * 8) == 0
+assert (lib.mp_debug_read_timing_wino43 if K43 else lib.mp_debug_read_timing_wino)(buf, 256 * 8) == 0
 t = np.frombuffer(buf, dtype=np.uint64).reshape(256, 8).astype(np.float64)
 t = t[(t[:, 7] > 0) & (t[:, 7] < 1e6)]
 n = t[:, 7]
-for i, nm in enumerate(['MFMA steps (all units)', 'unit barriers', 'epilogue', 'unit loop incl. barriers']):
+for i, nm in enumerate(['MFMA steps (all units)', 'unit barriers', 'epilogue', 'unit loop incl. barriers'] + (['s_barrier behind the DMA wait'] if K43 else [])):
     v = t[:, i] / n
     print('%-28s mean %8.0f  p10 %8.0f  p90 %8.0f cycles/item' % (nm, v.mean(), np.percentile(v, 10), np.percentile(v, 90)))
 layer = {480: 'enc.conv2', 240: 'enc.conv4', 120: 'enc.conv6', -240: 'enc.conv3', -120: 'enc.conv5', -60: 'heads.conv3x3'}.get(sel)
