@@ -35,10 +35,10 @@ def _stale(target, deps):
 DMA_SOURCES = ('conv_wino.hip', 'conv_wino43.hip', 'head_tail.hip')
 
 
-def check_dma_hazards(asm_path, window=8):
-    """Fail if a VALU write of an SGPR (v_readlane / v_readfirstlane: SGPR-spill reloads, uniformity copies) lands within
-    `window` instructions in front of a global_load_lds that uses that SGPR as its base: the hardware needs five wait
-    states there and nothing inserts them inside an asm statement."""
+def check_dma_hazards(asm_path, wait_states=5):
+    """Fail if a VALU write of an SGPR (v_readlane / v_readfirstlane: SGPR-spill reloads, uniformity copies) lands fewer than
+    `wait_states` wait states in front of a global_load_lds that uses that SGPR as its base (every instruction in between is
+    one wait state, `s_nop N` is N + 1): the hardware needs five there and nothing inserts them inside an asm statement."""
     import re
     lines = open(asm_path).read().split('\n')
     n = 0
@@ -48,17 +48,18 @@ def check_dma_hazards(asm_path, window=8):
             continue
         n += 1
         base = {int(m.group(1)), int(m.group(2))}
-        k, j = 0, i - 1
-        while j >= 0 and k < window:
+        ws, j = 0, i - 1
+        while j >= 0 and ws < wait_states:
             t = lines[j].strip()
             j -= 1
             if not t or t.startswith((';', '.')) or t.endswith(':'):
                 continue
-            k += 1
             w = re.match(r'(v_readlane_b32|v_readfirstlane_b32) s(\d+),', t)
             if w and int(w.group(2)) in base:
-                raise RuntimeError('%s:%d: %s writes the base SGPR of the LDS-DMA %d instructions later (needs 5 wait '
-                                   'states): open the asm statement with s_nop' % (asm_path, j + 2, t, k))
+                raise RuntimeError('%s:%d: %s writes the base SGPR of an LDS-DMA only %d wait states later (needs %d): '
+                                   'open the asm statement with s_nop' % (asm_path, j + 2, t, ws, wait_states))
+            nop = re.match(r's_nop (\d+)', t)
+            ws += int(nop.group(1)) + 1 if nop else 1
     if n == 0:
         raise RuntimeError('%s: no global_load_lds found -- the hazard check is looking at the wrong file' % asm_path)
     return n

@@ -72,6 +72,7 @@ struct mp_handle {
     int persist = 8;                // persistent conv workgroups for launches with >= this many items per CU
                                     // (MP_NO_PERSIST=1: never; MP_PERSIST_MIN_ITEMS=n overrides the threshold)
     bool fuse_first = true;         // fuse the Cin=1 block into the second convolution (MP_NO_FUSE=1 disables)
+    bool planar = true;             // MP_NO_PLANAR=1: NHWC also between two F(4x4,3x3) layers
     int wino43 = 1;                 // MP_WINO43: 0 off, 1 (default) F(4x4,3x3) for the 3x3 layers with 64 input channels, 2 all
     bool head_fuse = true;          // MP_NO_HEAD_FUSE=1: separate 1x1 convolution / softmax / normalisation launches
     bool wino_fuse = false;         // MP_WINO_FUSE=1: first block computed inside the Winograd conv2 loader (default since round 2:
@@ -497,9 +498,18 @@ int too_large(mp_handle* h, const char* name, int B, int H, int W)
                                   "): split the batch");
 }
 
+// does run_conv() send this 3x3 layer at H x W to the F(4x4,3x3) kernel?
+bool uses_wino43(const mp_handle* h, const ConvLayer& L, int H, int W, bool fuse)
+{
+    if (!(L.taps == 9 && L.u43pack && h->wino && !fuse && (h->wino43 == 2 || L.cin == 64))) return false;
+    ConvParams q{};
+    q.pad_zero = h->cfg.reflection_pad ? 0 : 1; q.cin = L.cin; q.H = H; q.W = W;
+    return conv_wino43_supports(q);
+}
+
 int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, int in_coff, float* out,
               int out_cstride, int out_coff, int B, int H, int W, const int* img_list, hipStream_t s,
-              const FirstLayer* fuse = nullptr, const float* images = nullptr)
+              const FirstLayer* fuse = nullptr, const float* images = nullptr, int in_planar = 0, int out_planar = 0)
 {
     ConvParams p{};
     p.in = in; p.out = out; p.wpack = L.wpack; p.bias = L.bias; p.scale = L.scale; p.shift = L.shift;
@@ -524,8 +534,8 @@ int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, 
                2.0 * L.taps * L.cin * L.cout * (double)B * H * W + (fuse ? 2.0 * 9 * 64 * (double)B * H * W : 0.0), s);
     if (fuse) { p.img = images; p.w1 = fuse->w; p.b1 = fuse->bias; p.s1 = fuse->scale; p.t1 = fuse->shift; }
     int big;
-    if (L.taps == 9 && L.u43pack && h->wino && !fuse && (h->wino43 == 2 || L.cin == 64) && conv_wino43_supports(p)) {
-        p.wpack = L.u43pack;
+    if (uses_wino43(h, L, H, W, fuse != nullptr)) {
+        p.wpack = L.u43pack; p.in_planar = in_planar; p.out_planar = out_planar;
         big = launch_conv_wino43(p, L.pool, s);
     } else if (L.taps == 9 && L.upack && h->wino && (!fuse || (L.pool && L.cin == 64))) {
         p.wpack = L.upack;
@@ -738,6 +748,7 @@ int mp_create(mp_handle** out, int device)
     { const char* e = getenv("MP_NO_WINOGRAD"); hh->wino = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_WINO_FUSE"); hh->wino_fuse = (e && e[0] == '1'); }
     { const char* e = getenv("MP_NO_HEAD_FUSE"); hh->head_fuse = !(e && e[0] == '1'); }
+    { const char* e = getenv("MP_NO_PLANAR"); if (e && e[0] == '1') hh->planar = false; }
     { const char* e = getenv("MP_WINO43"); if (e && e[0] >= '0' && e[0] <= '2') hh->wino43 = e[0] - '0'; }
     { const char* e = getenv("MP_PERSIST_MIN_ITEMS"); if (e && atoi(e) > 0) hh->persist = atoi(e); }
     { const char* e = getenv("MP_NO_PERSIST"); if (e && e[0] == '1') hh->persist = 0; }
@@ -899,6 +910,13 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
         // the fused loader is a 64-channel direct-convolution kernel; with Winograd on, the standalone first block +
         // Winograd second convolution is faster than the fused direct kernel
         const bool fuse1 = h->fuse_first && h->cfg.channel_version == 0 && (!h->wino || h->wino_fuse);
+        // a tensor written by conv1 or an F(4x4,3x3) layer AND read by an F(4x4,3x3) layer is channel-quad planar
+        bool f43[8] = {};
+        for (int i = 0, hh = H, ww = W; i < 7; ++i) {
+            f43[i] = h->planar && uses_wino43(h, E.conv[i], hh, ww, i == 0 && fuse1);
+            if (E.conv[i].pool) { hh /= 2; ww /= 2; }
+        }
+        c1.out_planar = f43[0] ? 1 : 0;
         if (!fuse1) {
             prof_begin(h, "enc.conv1", 2.0 * 9 * 64 * (double)nb * H * W, s);
             launch_conv_first(c1, s);
@@ -910,7 +928,8 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
         for (int i = 0; i < 7; ++i) {
             const ConvLayer& L = E.conv[i];
             if ((rc = run_conv(h, L, src, L.cin, 0, i == 6 ? X : dst, L.cout, 0, nb, hh, ww, lptr[e], s,
-                     (i == 0 && fuse1) ? &E.first : nullptr, images))) return rc;
+                     (i == 0 && fuse1) ? &E.first : nullptr, images, (i == 0 || f43[i - 1]) && f43[i],
+                     f43[i] && f43[i + 1]))) return rc;
             if (L.pool) { hh /= 2; ww /= 2; }
             float* t = src; src = dst; dst = t;
         }

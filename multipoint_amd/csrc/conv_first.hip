@@ -98,6 +98,73 @@ __global__ __launch_bounds__(256) void conv_first_kernel(const Conv1Params p)
     }
 }
 
+// The same block writing the channel-quad-planar layout [B][C1/4][H][W][4] that conv_wino43.hip consumes: a thread owns ONE pixel
+// and walks the C1/4 channel quads (weights and bias / scale / shift of a quad are wave-uniform: LDS broadcast reads), so a
+// store instruction writes two 512-byte row segments of one plane.  The multiply-add order is the NHWC kernel's.
+template <int C1>
+__global__ __launch_bounds__(256) void conv_first_planar_kernel(const Conv1Params p)
+{
+    __shared__ float tile[LH * LW];
+    __shared__ __attribute__((aligned(16))) float wl[9 * C1], pl[3 * C1];
+    const int tid = threadIdx.x;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    int t = blockIdx.x;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y;
+    const int bi = t / tiles_y;
+    const int img = p.img_list ? p.img_list[bi] : bi;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const float* in = p.in + (long long)img * p.H * p.W;
+    for (int f = tid; f < LH * LW; f += 256) {
+        const int ly = f / LW, lx = f - ly * LW;
+        int gy = y0 + ly - 1, gx = x0 + lx - 1;
+        float v;
+        if (p.pad_zero) {
+            const bool zero = (gy < 0) | (gy >= p.H) | (gx < 0) | (gx >= p.W);
+            gy = min(max(gy, 0), p.H - 1); gx = min(max(gx, 0), p.W - 1);
+            v = zero ? 0.f : in[gy * p.W + gx];
+        } else {
+            v = in[reflect_clamp1(gy, p.H) * p.W + reflect_clamp1(gx, p.W)];
+        }
+        tile[f] = v;
+    }
+    for (int f = tid; f < 9 * C1; f += 256) wl[f] = p.w[f];
+    for (int f = tid; f < C1; f += 256) { pl[f] = p.bias[f]; pl[C1 + f] = p.scale[f]; pl[2 * C1 + f] = p.shift[f]; }
+    __syncthreads();
+
+    const int py = tid / TW, px = tid % TW;
+    float x[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) x[kh * 3 + kw] = tile[(py + kh) * LW + px + kw];
+    const int oy = y0 + py, ox = x0 + px;
+    const bool ok = oy < p.H && ox < p.W;
+    const long long plane = (long long)p.H * p.W * 4;
+    float* out = p.out + (long long)img * (C1 / 4) * plane + ((long long)oy * p.W + ox) * 4;
+#pragma unroll 4
+    for (int q = 0; q < C1 / 4; ++q) {
+        f32x4 wv[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) wv[k] = *reinterpret_cast<const f32x4*>(&wl[k * C1 + 4 * q]);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(&pl[4 * q]);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(&pl[C1 + 4 * q]);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(&pl[2 * C1 + 4 * q]);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float a = 0.f;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) a = fmaf(x[k], wv[k][e], a);
+            a += b[e];
+            if (p.bn_first) a = fmaxf(a * sc[e] + sh[e], 0.f);
+            else a = fmaxf(a, 0.f) * sc[e] + sh[e];
+            o[e] = a;
+        }
+        if (ok) __builtin_nontemporal_store(o, reinterpret_cast<f32x4*>(out + q * plane));
+    }
+}
+
 }  // namespace
 
 void launch_conv_first(const Conv1Params& p, hipStream_t s)
@@ -105,6 +172,11 @@ void launch_conv_first(const Conv1Params& p, hipStream_t s)
     const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
     const long long nblk = (long long)p.B * tiles_x * tiles_y;
     if (nblk <= 0) return;
+    if (p.out_planar) {
+        if (p.channels == 32) hipLaunchKernelGGL(conv_first_planar_kernel<32>, dim3((unsigned)nblk), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL(conv_first_planar_kernel<64>, dim3((unsigned)nblk), dim3(256), 0, s, p);
+        return;
+    }
     if (p.channels == 32) hipLaunchKernelGGL(conv_first_kernel<32>, dim3((unsigned)nblk), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(conv_first_kernel<64>, dim3((unsigned)nblk), dim3(256), 0, s, p);
 }

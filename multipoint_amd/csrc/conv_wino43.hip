@@ -55,7 +55,7 @@ constexpr int UC4 = 4;                             // input channels per unit
 constexpr int VB4 = UC4 * 32 * 36;                 // floats per V buffer  [ch][tile][pos]   (18 KiB)
 constexpr int UB4 = UC4 * 64 * 36;                 // floats per U buffer  [ch][cout][pos]   (36 KiB)
 constexpr int NRB = (NPIX + 63) / 64;              // raw DMA blocks of 64 granules (10)
-constexpr int RB4 = (NRB + 1) * 64 * 4;            // floats per raw buffer: 10 blocks + a dummy block (11 KiB)
+constexpr int RB4 = NRB * 64 * 4;                  // floats per raw buffer: 10 blocks (10 KiB); one dummy block behind the three
 constexpr int SW4 = 8 * 36 * 2;                    // floats of a wave's transform scratch: 8 windows x 36 x (2 channels)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
 {
     __shared__ __attribute__((aligned(16))) float Vs[2 * VB4];
     __shared__ __attribute__((aligned(16))) float Us[2 * UB4];
-    __shared__ __attribute__((aligned(16))) float raw[2 * RB4];
+    __shared__ __attribute__((aligned(16))) float raw[3 * RB4 + 256];
     __shared__ __attribute__((aligned(16))) float scr[8 * SW4];
     __shared__ __attribute__((aligned(16))) float prm[3 * 64];
 
@@ -142,11 +142,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
         const int ty = trow - bi * p.tiles_y;
         w.img = p.img_list ? p.img_list[bi] : bi;
         w.y0 = ty * OY; w.x0 = tx * OX;
-        w.in_base = p.in + (long long)w.img * p.H * p.W * p.in_cstride + p.in_coff;
+        // planar input [B][cin/4][H][W][4]: base of the image's first plane; a unit's plane is chunk * H * W * 4 floats on
+        w.in_base = p.in_planar ? p.in + (long long)w.img * (p.cin / 4) * p.H * p.W * 4
+                                : p.in + (long long)w.img * p.H * p.W * p.in_cstride + p.in_coff;
         return w;
     };
 
     // ---- raw patch staging by DMA: granule f = block * 64 + lane = patch pixel f; this wave issues blocks wave, wave + 8 ----
+    const int pix_stride = p.in_planar ? 4 : p.in_cstride;              // floats between horizontally adjacent pixels
+    const long long unit_stride = p.in_planar ? (long long)p.H * p.W * 4 : UC4;     // floats between consecutive units
     unsigned rvoff[2];            // byte offset of the granule's source pixel (channel 0 of the unit)
     bool roff_rel = false;        // rvoff holds the item-invariant offsets of interior items
     auto raw_offsets = [&](const Where& w) __attribute__((always_inline)) -> const float* {
@@ -157,11 +161,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                 for (int j = 0; j < 2; ++j) {
                     const int f = (wave + 8 * j) * 64 + lane;
                     const int py = f / PX, px = f - py * PX;
-                    rvoff[j] = (f < NPIX) ? (unsigned)((py * p.W + px) * p.in_cstride) * 4u : 0u;
+                    rvoff[j] = (f < NPIX) ? (unsigned)((py * p.W + px) * pix_stride) * 4u : 0u;
                 }
                 roff_rel = true;
             }
-            return w.in_base + (long long)((w.y0 - 1) * p.W + (w.x0 - 1)) * p.in_cstride;
+            return w.in_base + (long long)((w.y0 - 1) * p.W + (w.x0 - 1)) * pix_stride;
         }
         roff_rel = false;
 #pragma unroll
@@ -171,19 +175,24 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
             unsigned off = 0;
             if (f < NPIX) {
                 const int gy = reflect_clamp_q(w.y0 + py - 1, p.H), gx = reflect_clamp_q(w.x0 + px - 1, p.W);
-                off = (unsigned)((gy * p.W + gx) * p.in_cstride) * 4u;
+                off = (unsigned)((gy * p.W + gx) * pix_stride) * 4u;
             }
             rvoff[j] = off;
         }
         return w.in_base;
     };
     const unsigned raw_lds = lds_addr(raw), us_lds = lds_addr(Us);
-    // raw block j (0, 1) of this wave for channel unit `chunk` of the cursor's item -> raw[buf]; block 10 is the dummy block
-    // (waves 2..7 have no second block: their DMA lands there)
-    auto raw_dma = [&](const float* base, int chunk, int buf, int j) __attribute__((always_inline)) {
-        const int g = (wave + 8 * j < NRB) ? wave + 8 * j : NRB;
+    // raw block j (0, 1) of this wave for channel unit `chunk` of the cursor's item -> the raw buffer at float offset `boff`;
+    // waves 2..7 have no second block: their DMA lands in the dummy block behind the three buffers (every wave issues two, so
+    // that one s_waitcnt vmcnt(2) leaves exactly the unit's raw DMAs in flight in all of them)
+    // (src: the unit's first channel at the patch origin, kept as a running pointer by the cursor; boff_bytes: the raw buffer)
+    const unsigned raw_m0 = raw_lds + (unsigned)wave * 1024u;             // block `wave` of buffer 0
+    const unsigned raw_dummy = raw_lds + 3u * RB4 * 4u;
+    auto raw_dma = [&](const float* src, unsigned boff_bytes, int j) __attribute__((always_inline)) {
+        const unsigned dst = j == 0 ? raw_m0 + boff_bytes : (wave + 8 < NRB ? raw_m0 + 8192u + boff_bytes : raw_dummy);
         if (MPQX & 16) return;
-        dma16(base + chunk * UC4, (MPQX & 64) ? (unsigned)lane * 16u : rvoff[j], raw_lds + (unsigned)(buf * RB4 + g * 256) * 4u);
+        if (MPQX & 128) { dma16(p.in, (unsigned)lane * 16u, dst); return; }   // L1-hot source
+        dma16(src, (MPQX & 64) ? (unsigned)lane * 16u : rvoff[j], dst);
     };
     // weight block i of this wave (36 KiB-blocks of 1 KiB per unit: waves 0-3 take 5, waves 4-7 take 4; index 36+ = dummy
     // re-load of block 35) of the unit at `ub` -> U[buf]
@@ -191,6 +200,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
         int b = wave + 8 * i;
         b = b < 36 ? b : 35;
         if (MPQX & 32) return;
+        if (MPQX & 256) { dma16(p.wpack, (unsigned)lane * 16u, us_lds + (unsigned)(buf * UB4 + b * 256) * 4u); return; }     // L1-hot source
         dma16(ub + b * 256, (unsigned)lane * 16u, us_lds + (unsigned)(buf * UB4 + b * 256) * 4u);
     };
     auto u_ptr = [&](int slice) __attribute__((always_inline)) -> const float* {      // unit 0 of a slice
@@ -213,16 +223,25 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     // pass 2: row `sub6`: scratch pairs [sub6][0..5]; V[ch][tile][pos = 6*sub6 + j]
     const int p2_write = (2 * w_cp * 32 + w_tile) * 36 + 6 * sub6;
     f32x2 td[6], tr[6];
-    auto tf_pass1 = [&](int buf) __attribute__((always_inline)) {
+    // the lane's read position in the raw buffer the NEXT transform reads (two registers: rows 0-3 and rows 4-5 are
+    // within a ds_read2_b64's offset range of them); advanced inside the VALU cluster of pass 1b, where an add is cheap
+    // (absolute LDS byte addresses, so that the reads take the registers as they are)
+    typedef const __attribute__((address_space(3))) f32x2* lds_pair_ptr;
+    const unsigned p1_base = lds_addr(raw) + (unsigned)p1_read * 4u;
+    unsigned p1_a = p1_base, p1_b = p1_base + 4u * PX * 16u;
+    auto tf_pass1 = [&]() __attribute__((always_inline)) {
         if (MPQX & 1) return;
 #pragma unroll
-        for (int i = 0; i < 6; ++i) td[i] = *reinterpret_cast<const f32x2*>(&raw[buf * RB4 + p1_read + i * PX * 4]);
+        for (int i = 0; i < 4; ++i) td[i] = reinterpret_cast<lds_pair_ptr>(p1_a)[i * PX * 2];
+#pragma unroll
+        for (int i = 4; i < 6; ++i) td[i] = reinterpret_cast<lds_pair_ptr>(p1_b)[(i - 4) * PX * 2];
     };
-    auto tf_pass1b = [&]() __attribute__((always_inline)) {
+    auto tf_pass1b = [&](unsigned next_byte) __attribute__((always_inline)) {   // next_byte: raw buffer of the next transform
         if (MPQX & 1) return;
         bt6(td, tr);                                      // tr[i'] = (B^T d)[i'][column sub6]
 #pragma unroll
         for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x2*>(&myscr[(i * 6 + sub6) * 2]) = tr[i];
+        p1_a = p1_base + next_byte; p1_b = p1_base + 4u * PX * 16u + next_byte;
     };
     auto tf_pass2 = [&]() __attribute__((always_inline)) {
         if (MPQX & 1) return;
@@ -247,10 +266,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     // ---- prologue ----
     Where cur = decode(item);
     const float* rbase = raw_offsets(cur);
+    const float* rsrc = rbase;               // the cursor's unit: rbase + ld_chunk * unit_stride
     Where ld_item = cur;
     int ld_chunk = 0;
     int ld_next_item = item + stride;
     auto ld_advance = [&]() __attribute__((always_inline)) {
+        rsrc += unit_stride;
         if (++ld_chunk == NC) {
             ld_chunk = 0;
             if (ld_next_item < item_end) {
@@ -258,17 +279,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                 rbase = raw_offsets(ld_item);
                 ld_next_item += stride;
             }
+            rsrc = rbase;
         }
     };
     const float* up = u_ptr(cur.slice);
-    raw_dma(rbase, ld_chunk, 0, 0); raw_dma(rbase, ld_chunk, 0, 1); ld_advance();     // raw(0)
-    raw_dma(rbase, ld_chunk, 1, 0); raw_dma(rbase, ld_chunk, 1, 1); ld_advance();     // raw(1)
+    // raw(k) lives in raw buffer k % 3: unit n transforms raw(n+1) and sends raw(n+3) over raw(n)
+    raw_dma(rsrc, 0u, 0); raw_dma(rsrc, 0u, 1); ld_advance();                                       // raw(0)
+    raw_dma(rsrc, RB4 * 4u, 0); raw_dma(rsrc, RB4 * 4u, 1); ld_advance();                           // raw(1)
+    raw_dma(rsrc, 2u * RB4 * 4u, 0); raw_dma(rsrc, 2u * RB4 * 4u, 1); ld_advance();                 // raw(2)
+    unsigned rd_byte = 0u, rt_byte = RB4 * 4u;           // byte offsets of the raw buffer unit n DMAs into / transforms from
 #pragma unroll
     for (int i = 0; i < 5; ++i) u_dma(up, 0, i);                                       // U(0)
     load_prm(cur.slice);
     dma_wait();
     __syncthreads();
-    tf_pass1(0); tf_pass1b(); tf_pass2(); tf_pass2b(0);                                // V(0)
+    tf_pass1(); tf_pass1b(RB4 * 4u); tf_pass2(); tf_pass2b(0);                                // V(0); unit 0 transforms raw(1)
     __syncthreads();
     af[0] = *reinterpret_cast<const f32x4*>(&Us[a_base]);
     bf[0] = *reinterpret_cast<const f32x4*>(&Vs[b_base]);
@@ -316,16 +341,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                         af[(g + 2) % 3] = *reinterpret_cast<const f32x4*>(g + 2 < 9 ? &ur[4 * (g + 2)] : &urn[4 * (g - 7)]);
                         bf[(g + 2) % 3] = *reinterpret_cast<const f32x4*>(g + 2 < 9 ? &vr[4 * (g + 2)] : &vrn[4 * (g - 7)]);
                     } else if (e == 1) {
-                        // DMAs early in the unit (the barrier behind group 6 waits for them): raw(n+2) -> raw[vb] first
-                        // (HBM), then U(n+1) -> U[vb^1] (L2)
-                        if (g == 0) { raw_dma(rbase, ld_chunk, vb, 0); raw_dma(rbase, ld_chunk, vb, 1); }
-                        else if (g == 1) { u_dma(un, vb ^ 1, 0); u_dma(un, vb ^ 1, 1); }
-                        else if (g == 2) { u_dma(un, vb ^ 1, 2); u_dma(un, vb ^ 1, 3); }
-                        else if (g == 3) u_dma(un, vb ^ 1, 4);
+                        // U(n+1) -> U[vb^1] (L2 hits) FIRST, raw(n+3) (HBM) behind them: the memory pipe returns in order
+                        // across the whole CU, so a weight DMA queued behind an HBM miss of any wave returns at HBM
+                        // latency.  In this order the raw DMAs have the rest of the unit and the whole next one
+                        // (the barrier waits with vmcnt(2): everything but them) before U(n+2) queues up behind them.
+                        if (g == 0) { u_dma(un, vb ^ 1, 0); u_dma(un, vb ^ 1, 1); }
+                        else if (g == 1) { u_dma(un, vb ^ 1, 2); u_dma(un, vb ^ 1, 3); }
+                        else if (g == 2) u_dma(un, vb ^ 1, 4);
+                        else if (g == 3) {
+                            const unsigned db_ = (MPQX & 4096) ? (vb ^ 1) * RB4 * 4u : rd_byte;
+                            raw_dma(rsrc, db_, 0); raw_dma(rsrc, db_, 1);
+                        }
                     } else if (e == 2) {
                         // input transform of unit n+1: raw[vb^1] -> V[vb^1]
-                        if (g == 0) tf_pass1(vb ^ 1);
-                        else if (g == 1) tf_pass1b();
+                        if (g == 0) tf_pass1();
+                        else if (g == 1) tf_pass1b((MPQX & 4096) ? vb * RB4 * 4u : 3u * RB4 * 4u - rd_byte - rt_byte);     // unit n+1 transforms raw((n+2) % 3)
                         else if (g == 2) tf_pass2();
                         else if (g == 3) tf_pass2b(vb ^ 1);
                     } else {
@@ -335,7 +365,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
 #ifdef MP_TIMING
                             t_b0 = __builtin_amdgcn_s_memtime();
 #endif
-                            dma_wait();
+                            // U(n+1), raw(n+2) (and an item's output stores) have landed; raw(n+3) stays in flight
+                            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
 #ifdef MP_TIMING
                             t_b1 = __builtin_amdgcn_s_memtime();
 #endif
@@ -355,6 +386,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
         auto unit = [&](const int c, auto first_tag, auto vb_tag) __attribute__((always_inline)) {
             unit_body(c, first_tag, vb_tag);
             ld_advance();
+            const unsigned ro = 3u * RB4 * 4u - rd_byte - rt_byte;     // rotate the raw ring: (rd, rt) <- (rt, third)
+            rd_byte = rt_byte; rt_byte = ro;
         };
         using VB0 = std::integral_constant<int, 0>;
         using VB1 = std::integral_constant<int, 1>;
@@ -436,7 +469,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                 } else {
                     const int Ho = POOL ? p.H >> 1 : p.H, Wo = POOL ? p.W >> 1 : p.W;
                     const int py0 = POOL ? oy >> 1 : oy, px0 = POOL ? ox >> 1 : ox;
-                    float* const o = p.out + (((long long)cur.img * Ho + py0) * Wo + px0) * cs + p.out_coff + ch0;
+                    // NHWC: pixel stride cs floats; planar [B][cout/4][Ho][Wo][4]: this lane's quad is plane ch0 / 4
+                    const int ps = p.out_planar ? 4 : cs;
+                    float* const o = p.out_planar
+                        ? p.out + (((long long)cur.img * (p.cout / 4) + (ch0 >> 2)) * Ho * Wo + (long long)py0 * Wo + px0) * 4
+                        : p.out + (((long long)cur.img * Ho + py0) * Wo + px0) * cs + p.out_coff + ch0;
                     const bool quad_ok = ch0 + 3 < p.cout;
 #pragma unroll
                     for (int a = 0; a < NO; ++a)
@@ -444,7 +481,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                         for (int b = 0; b < NO; ++b)
                             if ((py0 + a < Ho) && (px0 + b < Wo)) {
                                 const f32x4 v = {keep[a][b][0], keep[a][b][1], res[a][b][0], res[a][b][1]};
-                                float* const q = o + ((long long)a * Wo + b) * cs;
+                                float* const q = o + ((long long)a * Wo + b) * ps;
                                 if (quad_ok) *reinterpret_cast<f32x4*>(q) = v;
                                 else
 #pragma unroll
@@ -460,7 +497,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
         if (!has_next && tid == 0 && t_on)
             for (int i = 0; i < 8; ++i) g_timing_q[blockIdx.x * 8 + i] = tsum[i];
 #endif
-        if (!has_next) return;
+        if (!has_next) { dma_wait(); return; }      // the prefetch DMAs still in flight write THIS workgroup's LDS: drain them
         if (next_slice != cur.slice) {
             __syncthreads();
             load_prm(next_slice);

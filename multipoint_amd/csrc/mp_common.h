@@ -39,6 +39,9 @@ struct ConvParams {
     unsigned magic_slices, magic_tx, magic_ty;   // multiply-high division constants (filled in by the launcher)
     int nitems;           // work items (tile, slice) of the launch (filled in by the launcher)
     int persist;          // 0: per-tile kernel only; n > 0: persistent workgroups for launches with >= n items per CU
+    // conv_wino43.hip only: channel-quad-planar tensors [B][C/4][H][W][4] instead of NHWC (a unit of 4 input channels is then
+    // contiguous row by row: its patch DMA touches ~10 cache lines per instruction instead of 64)
+    int in_planar, out_planar;
 };
 
 // first layer (Cin = 1, direct VALU conv, HBM-write bound)
@@ -51,6 +54,7 @@ struct Conv1Params {
     int B, H, W;
     int pad_zero, bn_first;
     int channels;         // output channels incl. zero padding: 64 (channel_version 0) or 32
+    int out_planar;       // write [B][channels/4][H][W][4] (the consumer is conv_wino43.hip) instead of NHWC
 };
 
 // the conv launchers return 0, or 1 when the launch has more work items than the kernels' 32-bit magic-number tile decode

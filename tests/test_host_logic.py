@@ -312,6 +312,12 @@ def test_build_checks_dma_hazards(tmp_path):
     far = tmp_path / 'far.s'
     far.write_text('\tv_readlane_b32 s12, v90, 3\n' + '\ts_nop 0\n' * 9 + '\tglobal_load_lds_dwordx4 v48, s[12:13]\n')
     assert b.check_dma_hazards(str(far)) == 1
+    nop = tmp_path / 'nop.s'                             # s_nop N is N + 1 wait states: 1 + 4 = 5 suffice, 1 + 3 do not
+    nop.write_text('\tv_readlane_b32 s13, v90, 3\n\ts_mov_b32 m0, s17\n\ts_nop 3\n\tglobal_load_lds_dwordx4 v48, s[12:13]\n')
+    assert b.check_dma_hazards(str(nop)) == 1
+    nop.write_text('\tv_readlane_b32 s13, v90, 3\n\ts_mov_b32 m0, s17\n\ts_nop 2\n\tglobal_load_lds_dwordx4 v48, s[12:13]\n')
+    with pytest.raises(RuntimeError, match='base SGPR'):
+        b.check_dma_hazards(str(nop))
     none = tmp_path / 'none.s'
     none.write_text('\ts_nop 0\n')
     with pytest.raises(RuntimeError, match='no global_load_lds'):
