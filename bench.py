@@ -312,17 +312,17 @@ def main():
             dist.destroy_process_group()
         return
 
-    # roofline of the dominant kernel.  fp32 path: conv_wino_kernel<true,false> = encoder conv2 (64->64 @480x640) by
-    # Winograd F(2x2,3x3) + bias/ReLU/BN + 2x2 max-pool, one launch per step (~38 % of the time).  `achieved` is the
-    # ALGORITHMIC (direct-convolution) FLOP count 2*9*Cin*Cout*H*W per image / launch time, as the contract asks; the
-    # kernel executes 2.25x fewer MFMA FLOPs than that, so `frac` can exceed 1 -- `mfma_executed_frac` is the share of
-    # the fp32 MFMA peak the instructions actually issued amount to.  Timed with hipEvents on the launch stream
-    # inside the timed region.
+    # roofline of the dominant kernel.  fp32 path: encoder conv2 (64->64 @480x640) + bias/ReLU/BN + 2x2 max-pool, one launch
+    # per step (~35 % of the time): conv_wino43_kernel<true,false> (Winograd F(4x4,3x3)) by default.  Timed with hipEvents
+    # on the launch stream inside the timed region.
     by_name = {}
     for name, ms, flop in prof:
         by_name.setdefault(name, []).append((ms, flop))
     roof = None
     wino = os.environ.get('MP_NO_WINOGRAD') != '1' and not c5
+    # the library's choice for conv2 (api.hip uses_wino43): F(4x4,3x3) unless switched off, fused, or the frame is no multiple of 4
+    f43 = (wino and os.environ.get('MP_WINO43', '1') != '0' and os.environ.get('MP_WINO_FUSE') != '1'
+           and H % 4 == 0 and W % 4 == 0)
     dom = by_name.get('enc.conv1+2') or by_name.get('enc.conv2')
     n_launch = 1
     if dom:
@@ -345,6 +345,11 @@ def main():
             kernel = ('conv_mfma_kernel<9,32,true,true,false> (encoder conv1 fused into conv2 64->64 @480x640, direct convolution '
                       '+ bias/ReLU/BN + 2x2 max-pool)') if fused else \
                      'conv_mfma_persist_kernel<9,32,true,false> (enc.conv2, direct convolution)'
+        elif f43:
+            # Winograd F(4x4,3x3): 36 multiplies per 4x4 output tile and channel pair instead of 144 -> 4x fewer MFMA FLOPs
+            issued = flop / 4.0
+            kernel = ('conv_wino43_kernel<true,false> (enc.conv2 64->64 @480x640 by Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32, '
+                      'weights and channel-quad-planar input patches staged by LDS-DMA, + bias/ReLU/BN + 2x2 max-pool)')
         else:
             issued = (conv2_flop if fused else flop) / 2.25
             kernel = ('conv_wino_kernel<true,false,true,false,8> (encoder conv1 -- Cin = 1, computed on the vector pipe inside the loader '
@@ -360,10 +365,12 @@ def main():
                 'mfma_flop_issued_per_launch': issued, 'algorithmic_flop_per_launch': flop,
                 'algorithmic_tflops': round(alg, 2),
                 'algorithmic_speedup_vs_direct_roofline': round(alg / peak, 4),
+                # the MFMA utilisation the F(2x2,3x3) kernel (2.25x fewer FLOPs than direct) would need for this launch time
+                'f22_equivalent_frac': round(alg / 2.25 / peak, 4) if f43 else None,
                 'note': 'achieved/frac = MFMA FLOPs issued by the launch / hipEvent time on the launch stream inside the timed '
                         'region / dense MFMA peak (matrix-pipe utilisation; agrees with SQ_VALU_MFMA_BUSY_CYCLES in profiles/).  '
                         'algorithmic_* use the direct-convolution FLOP count 2*9*Cin*Cout per output pixel'
-                        + (' (conv1 + conv2)' if fused else '') + '; Winograd F(2x2,3x3) issues 2.25x fewer.  Timed while '
+                        + (' (conv1 + conv2)' if fused else '') + '; Winograd F(2x2,3x3) issues 2.25x fewer, F(4x4,3x3) 4x fewer.  Timed while '
                         'the previous batch\'s NMS/top-k/sampling/matching kernels run on the side stream.'}
     conv_ms = sum(float(np.sum([m for m, _ in v])) / args.steps for k, v in by_name.items())
     conv_flop = sum(float(np.sum([f for _, f in v])) / args.steps for v in by_name.values())

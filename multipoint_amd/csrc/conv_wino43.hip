@@ -4,7 +4,7 @@
 // form: 1.78x fewer MFMAs than conv_wino.hip for the same ReflectionPad -> Conv2d -> ReLU -> BN [-> MaxPool] block
 // (multipoint/models/MultiPoint.py:143-148).  fp32 throughout; U = G g G^T is computed once on the host (in double, rounded
 // once: G holds 1/6 and 1/24), V = B^T d B and Y = A^T M A are short fixed-order multiply-add chains with the small integer
-// coefficients of B and A.  Measured against the oracle with ONLY enc.conv2 switched to this form: prob 8.9e-6, descriptors
+// coefficients of B and A.  Measured against the CPU restatement (tests/) with ONLY enc.conv2 switched to this form: prob 8.9e-6, descriptors
 // 1.6e-6, no keypoint changes on 2 x 480x640 (the same noise class as F(2x2,3x3); tolerances unchanged).
 //
 // Structure (the round-2 lessons of conv_wino.hip apply unchanged: every operand through LDS, filled by LDS-DMA; ONE counted
@@ -16,8 +16,14 @@
 //    neither an exchange between waves nor accumulator reads.
 //  * K is walked in units of 4 input channels = one MFMA per position.  LDS per unit: V 18 KiB [ch][tile][pos] and U 36 KiB
 //    [ch][cout][pos] (a lane's operands of 4 consecutive positions are ONE conflict-free ds_read_b128: lanes are 144 bytes
-//    apart), raw 9.6 KiB (18 x 34 patch x 4 channels, one 16-byte granule per pixel = LDS-DMA order), all double-buffered,
-//    + a per-wave scratch for the input transform: 146 KiB.
+//    apart), both double-buffered; raw 10 KiB (18 x 34 patch x 4 channels, one 16-byte granule per pixel = LDS-DMA order) in a
+//    ring of THREE; + a per-wave scratch for the input transform: 158 KiB.
+//  * Input layout: NHWC, or channel-quad-planar [B][C/4][H][W][4] when the producer is conv_first.hip / this kernel (api.hip
+//    decides per tensor): a unit's patch rows are then contiguous, 9-11 cache lines per DMA instruction instead of 64.
+//  * DMA order per unit: the 5 weight DMAs of unit n+1 (L2 hits) FIRST, the 2 patch DMAs of unit n+3 (HBM) behind them, and
+//    the unit barrier waits with vmcnt(2) -- everything but those two.  The memory pipe returns in order across the CU: a
+//    weight DMA queued behind an HBM miss of ANY wave comes back at HBM latency (measured: -5 k of 64 k cycles per item
+//    against patch-first order with a full wait).
 //  * Input transform of unit n+1 while unit n is multiplied: 8 lanes per (tile, channel pair) window; lanes 0-5 transform
 //    one COLUMN of the 6x6 window each (12 packed instructions), hand the result over through the wave's own LDS scratch
 //    (LDS operations of a wave execute in order: no barrier), then transform one ROW each and write V.
