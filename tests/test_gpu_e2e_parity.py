@@ -112,11 +112,12 @@ def test_unlimited_topk_lists_grow_instead_of_truncating(oracle):
 
 def test_launch_beyond_tile_decode_is_an_error(oracle):
     """A layer with more work items than the kernels' 32-bit magic-number tile decode addresses (items x max divisor >= 2^32)
-    must fail with MP_EINVAL -- not return MP_OK with stale outputs: a 16 x 1048576 image has 65536 tile columns."""
+    must fail with MP_EINVAL -- not return MP_OK with stale outputs: a 16 x 2097152 image has 65536 columns of the
+    F(4x4,3x3) kernel's 32-pixel-wide items (and 131072 of the F(2x2,3x3) kernel's)."""
     import multipoint_amd.models as M
     cfg = dict(oracle.SHIPPED_MODEL_CONFIG)
     net = M.MultiPoint(dict(cfg)); net.load_state_dict(oracle.make_weights(0, cfg)); net.to('cuda'); net.eval()
     with pytest.raises(ValueError, match='too many work items'):            # MP_EINVAL -> ValueError (_lib.check)
-        net({'image': torch.zeros((1, 1, 16, 1 << 20), device='cuda')})
+        net({'image': torch.zeros((1, 1, 16, 1 << 21), device='cuda')})
     out = net({'image': torch.rand((1, 1, 16, 64), device='cuda')})              # the handle is still usable afterwards
     assert torch.isfinite(out['prob']).all()
