@@ -20,10 +20,11 @@
 //    ring of THREE; + a per-wave scratch for the input transform: 158 KiB.
 //  * Input layout: NHWC, or channel-quad-planar [B][C/4][H][W][4] when the producer is conv_first.hip / this kernel (api.hip
 //    decides per tensor): a unit's patch rows are then contiguous, 9-11 cache lines per DMA instruction instead of 64.
-//  * DMA order per unit: the 5 weight DMAs of unit n+1 (L2 hits) FIRST, the 2 patch DMAs of unit n+3 (HBM) behind them, and
-//    the unit barrier waits with vmcnt(2) -- everything but those two.  The memory pipe returns in order across the CU: a
-//    weight DMA queued behind an HBM miss of ANY wave comes back at HBM latency (measured: -5 k of 64 k cycles per item
-//    against patch-first order with a full wait).
+//  * DMA order: the memory pipe returns in order across the CU, so a weight DMA (L2 hit) queued behind a patch DMA (HBM miss)
+//    of ANY wave comes back at HBM latency.  The 5 weight DMAs of unit n+2 therefore go out right behind the barrier of unit
+//    n, the 2 patch DMAs of unit n+3 six MFMA groups ahead of the next weights, and the barrier waits with vmcnt(2) --
+//    for everything but the patch DMAs, which have until the next barrier (64.7 k -> 58.8 k cycles per item against
+//    patch-first order with a full wait).
 //  * Input transform of unit n+1 while unit n is multiplied: 8 lanes per (tile, channel pair) window; lanes 0-5 transform
 //    one COLUMN of the 6x6 window each (12 packed instructions), hand the result over through the wave's own LDS scratch
 //    (LDS operations of a wave execute in order: no barrier), then transform one ROW each and write V.
@@ -296,6 +297,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     unsigned rd_byte = 0u, rt_byte = RB4 * 4u;           // byte offsets of the raw buffer unit n DMAs into / transforms from
 #pragma unroll
     for (int i = 0; i < 5; ++i) u_dma(up, 0, i);                                       // U(0)
+#pragma unroll
+    for (int i = 0; i < 5; ++i) u_dma(up + UB4, 1, i);                                 // U(1)
     load_prm(cur.slice);
     dma_wait();
     __syncthreads();
@@ -324,12 +327,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
         auto unit_body = [&](const int c, auto first_tag, auto vb_tag) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_tag)::value;
             constexpr int vb = decltype(vb_tag)::value;
-            const bool last = c + 1 == NC;
             const float* const ur = Us + vb * UB4 + a_base;
             const float* const vr = Vs + vb * VB4 + b_base;
             const float* const urn = Us + (vb ^ 1) * UB4 + a_base;
             const float* const vrn = Vs + (vb ^ 1) * VB4 + b_base;
-            const float* const un = last ? unext : up + (long long)(c + 1) * UB4;
+            const float* const un2 = c + 2 < NC ? up + (long long)(c + 2) * UB4 : unext + (long long)(c + 2 - NC) * UB4;
             MPQ_T(t_u0);
 #ifdef MP_TIMING
             unsigned long long t_b0 = 0, t_b1 = 0;
@@ -347,17 +349,16 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                         af[(g + 2) % 3] = *reinterpret_cast<const f32x4*>(g + 2 < 9 ? &ur[4 * (g + 2)] : &urn[4 * (g - 7)]);
                         bf[(g + 2) % 3] = *reinterpret_cast<const f32x4*>(g + 2 < 9 ? &vr[4 * (g + 2)] : &vrn[4 * (g - 7)]);
                     } else if (e == 1) {
-                        // U(n+1) -> U[vb^1] (L2 hits) FIRST, raw(n+3) (HBM) behind them: the memory pipe returns in order
-                        // across the whole CU, so a weight DMA queued behind an HBM miss of any wave returns at HBM
-                        // latency.  In this order the raw DMAs have the rest of the unit and the whole next one
-                        // (the barrier waits with vmcnt(2): everything but them) before U(n+2) queues up behind them.
-                        if (g == 0) { u_dma(un, vb ^ 1, 0); u_dma(un, vb ^ 1, 1); }
-                        else if (g == 1) { u_dma(un, vb ^ 1, 2); u_dma(un, vb ^ 1, 3); }
-                        else if (g == 2) u_dma(un, vb ^ 1, 4);
-                        else if (g == 3) {
-                            const unsigned db_ = (MPQX & 4096) ? (vb ^ 1) * RB4 * 4u : rd_byte;
-                            raw_dma(rsrc, db_, 0); raw_dma(rsrc, db_, 1);
-                        }
+                        // The memory pipe returns in order across the whole CU: a weight DMA (L2 hit) queued behind a patch
+                        // DMA (HBM miss) of ANY wave comes back at HBM latency.  So the two kinds are kept apart in time:
+                        // U(n+2) -> U[vb] right behind this unit's barrier (groups 7, 8: every wave has fetched its last
+                        // fragment of U[vb] by then), raw(n+3) in groups 0, 1 of the next body -- six groups of MFMAs
+                        // before the next weights queue up behind it.  The barrier waits with vmcnt(2): for everything
+                        // but the two patch DMAs, which have until the NEXT barrier.
+                        if (g == 7) { u_dma(un2, vb, 0); u_dma(un2, vb, 1); u_dma(un2, vb, 2); }
+                        else if (g == 8) { u_dma(un2, vb, 3); u_dma(un2, vb, 4); }
+                        else if (g == 0) raw_dma(rsrc, rd_byte, 0);
+                        else if (g == 1) raw_dma(rsrc, rd_byte, 1);
                     } else if (e == 2) {
                         // input transform of unit n+1: raw[vb^1] -> V[vb^1]
                         if (g == 0) tf_pass1();
