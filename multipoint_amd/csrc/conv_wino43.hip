@@ -86,21 +86,45 @@ __device__ __forceinline__ void dma16(const float* sbase, unsigned voff_bytes, u
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)p; }
 
-// 1-D input transform B^T d (6 -> 6), packed over two channels.  B^T =
+// Packed fp32 arithmetic as explicit instructions: hipcc scalarises a third of the transform's packed multiply-adds (4 v_fma_f32
+// for 2 v_pk_fma_f32 per pass), and next to an MFMA stream every vector instruction costs matrix-pipe time.
+// K = 2.0 / 4.0 are inline constants (op_sel_hi 0: the low half feeds both lanes); 5.0 comes in a scalar register pair.
+#define MPQ_PK_FMA(K)                                                                                              \
+    __device__ __forceinline__ f32x2 pk_fma_##K(f32x2 a, f32x2 c) {      /* a * K + c */                           \
+        f32x2 d; asm("v_pk_fma_f32 %0, %1, " #K ".0, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(c)); return d; } \
+    __device__ __forceinline__ f32x2 pk_fnma_##K(f32x2 a, f32x2 c) {     /* c - a * K */                           \
+        f32x2 d; asm("v_pk_fma_f32 %0, %1, " #K ".0, %2 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(c)); return d; }
+MPQ_PK_FMA(2)
+MPQ_PK_FMA(4)
+__device__ __forceinline__ f32x2 pk_fnma_5(f32x2 a, f32x2 c)             // c - a * 5
+{
+    f32x2 d;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "s"(0x40A0000040A00000ull), "v"(c));
+    return d;
+}
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b)
+{
+    f32x2 d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d;
+}
+// 1-D input transform B^T d (6 -> 6), packed over two channels: 12 instructions.  B^T =
 //   [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
 __device__ __forceinline__ void bt6(const f32x2 d[6], f32x2 r[6])
 {
-    const f32x2 c4 = {4.f, 4.f}, c5 = {5.f, 5.f}, c2 = {2.f, 2.f};
-    const f32x2 t0 = d[4] - c4 * d[2];             // d4 - 4 d2
-    const f32x2 t1 = d[3] - c4 * d[1];             // d3 - 4 d1
-    const f32x2 t2 = d[4] - d[2];
-    const f32x2 t3 = d[3] - d[1];
-    r[0] = c4 * d[0] + (d[4] - c5 * d[2]);
-    r[1] = t0 + t1;
-    r[2] = t0 - t1;
-    r[3] = t2 + c2 * t3;
-    r[4] = t2 - c2 * t3;
-    r[5] = c4 * d[1] + (d[5] - c5 * d[3]);
+#if defined(MPQX) && (MPQX & 131072)
+    for (int i = 0; i < 6; ++i) r[i] = d[i];        // timing only: no arithmetic
+    return;
+#endif
+    const f32x2 t0 = pk_fnma_4(d[2], d[4]);        // d4 - 4 d2
+    const f32x2 t1 = pk_fnma_4(d[1], d[3]);        // d3 - 4 d1
+    const f32x2 t2 = pk_sub(d[4], d[2]);
+    const f32x2 t3 = pk_sub(d[3], d[1]);
+    r[0] = pk_fma_4(d[0], pk_fnma_5(d[2], d[4]));  // 4 d0 + (d4 - 5 d2)
+    r[1] = pk_add(t0, t1);
+    r[2] = pk_sub(t0, t1);
+    r[3] = pk_fma_2(t3, t2);                       // t2 + 2 t3
+    r[4] = pk_fnma_2(t3, t2);                      // t2 - 2 t3
+    r[5] = pk_fma_4(d[1], pk_fnma_5(d[3], d[5]));  // 4 d1 + (d5 - 5 d3)
 }
 // 1-D output transform A^T m (6 -> 4), packed over two output channels.  A^T =
 //   [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
@@ -230,6 +254,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     // pass 2: row `sub6`: scratch pairs [sub6][0..5]; V[ch][tile][pos = 6*sub6 + j]
     const int p2_write = (2 * w_cp * 32 + w_tile) * 36 + 6 * sub6;
     f32x2 td[6], tr[6];
+    f32x2 tq[6], tq2[6];                                 // MPQX & 65536 only
     // the lane's read position in the raw buffer the NEXT transform reads (two registers: rows 0-3 and rows 4-5 are
     // within a ds_read2_b64's offset range of them); advanced inside the VALU cluster of pass 1b, where an add is cheap
     // (absolute LDS byte addresses, so that the reads take the registers as they are)
@@ -237,7 +262,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     const unsigned p1_base = lds_addr(raw) + (unsigned)p1_read * 4u;
     unsigned p1_a = p1_base, p1_b = p1_base + 4u * PX * 16u;
     auto tf_pass1 = [&]() __attribute__((always_inline)) {
-        if (MPQX & 1) return;
+        if (MPQX & (1 | 16384)) return;
+        if (MPQX & 65536) {               // timing only: the reads are issued, nothing depends on them until the unit's end
+#pragma unroll
+            for (int i = 0; i < 4; ++i) tq[i] = reinterpret_cast<lds_pair_ptr>(p1_a)[i * PX * 2];
+#pragma unroll
+            for (int i = 4; i < 6; ++i) tq[i] = reinterpret_cast<lds_pair_ptr>(p1_b)[(i - 4) * PX * 2];
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) td[i] = reinterpret_cast<lds_pair_ptr>(p1_a)[i * PX * 2];
 #pragma unroll
@@ -246,23 +278,45 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     auto tf_pass1b = [&](unsigned next_byte) __attribute__((always_inline)) {   // next_byte: raw buffer of the next transform
         if (MPQX & 1) return;
         bt6(td, tr);                                      // tr[i'] = (B^T d)[i'][column sub6]
-#pragma unroll
-        for (int i = 0; i < 6; ++i) *reinterpret_cast<f32x2*>(&myscr[(i * 6 + sub6) * 2]) = tr[i];
         p1_a = p1_base + next_byte; p1_b = p1_base + 4u * PX * 16u + next_byte;
     };
+    // the LDS write path takes two 8-byte stores per MFMA gap for free and saturates beyond: the transform's
+    // stores go out in pairs, one pair per gap
+    auto tf_pass1w = [&](int k) __attribute__((always_inline)) {                // rows 2k, 2k+1 of the scratch
+        if (MPQX & (1 | 32768)) return;
+#pragma unroll
+        for (int i = 2 * k; i < 2 * k + 2; ++i) *reinterpret_cast<f32x2*>(&myscr[(i * 6 + sub6) * 2]) = tr[i];
+    };
     auto tf_pass2 = [&]() __attribute__((always_inline)) {
-        if (MPQX & 1) return;
+        if (MPQX & (1 | 16384)) return;
+        if (MPQX & 65536) {
+#pragma unroll
+            for (int j = 0; j < 6; ++j) tq2[j] = *reinterpret_cast<const f32x2*>(&myscr[(sub6 * 6 + j) * 2]);
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < 6; ++j) td[j] = *reinterpret_cast<const f32x2*>(&myscr[(sub6 * 6 + j) * 2]);
     };
-    auto tf_pass2b = [&](int buf) __attribute__((always_inline)) {
+    // V[ch][tile][6 * row + j], j = 0..5, of the lane's two channels: ds_write2_b32 takes two unrelated registers, so the
+    // packed results go out as they are (hipcc pairs them into ds_write_b64 through nine v_mov)
+    const unsigned p2_addr = lds_addr(Vs) + (unsigned)p2_write * 4u;
+    auto tf_pass2b = [&]() __attribute__((always_inline)) {
         if (MPQX & 1) return;
         bt6(td, tr);                                      // tr[j'] = V[row sub6][j']
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            Vs[buf * VB4 + p2_write + j] = tr[j][0];
-            Vs[buf * VB4 + p2_write + 32 * 36 + j] = tr[j][1];
-        }
+    };
+    auto tf_pass2w = [&](int buf, int k) __attribute__((always_inline)) {       // positions 2k, 2k+1 of both channels
+        if (MPQX & (1 | 32768)) return;
+        const unsigned a0 = p2_addr + (unsigned)buf * (VB4 * 4u), a1 = a0 + 32u * 36u * 4u;
+        const int j = 2 * k;
+        if (k == 0)
+            asm volatile("ds_write2_b32 %0, %1, %2 offset0:0 offset1:1\n\tds_write2_b32 %3, %4, %5 offset0:0 offset1:1"
+                         :: "v"(a0), "v"(tr[j][0]), "v"(tr[j + 1][0]), "v"(a1), "v"(tr[j][1]), "v"(tr[j + 1][1]) : "memory");
+        else if (k == 1)
+            asm volatile("ds_write2_b32 %0, %1, %2 offset0:2 offset1:3\n\tds_write2_b32 %3, %4, %5 offset0:2 offset1:3"
+                         :: "v"(a0), "v"(tr[j][0]), "v"(tr[j + 1][0]), "v"(a1), "v"(tr[j][1]), "v"(tr[j + 1][1]) : "memory");
+        else
+            asm volatile("ds_write2_b32 %0, %1, %2 offset0:4 offset1:5\n\tds_write2_b32 %3, %4, %5 offset0:4 offset1:5"
+                         :: "v"(a0), "v"(tr[j][0]), "v"(tr[j + 1][0]), "v"(a1), "v"(tr[j][1]), "v"(tr[j + 1][1]) : "memory");
     };
 
     // ---- GEMM operands: a lane's fragments of 4 consecutive positions are one ds_read_b128 ----
@@ -302,7 +356,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     load_prm(cur.slice);
     dma_wait();
     __syncthreads();
-    tf_pass1(); tf_pass1b(RB4 * 4u); tf_pass2(); tf_pass2b(0);                                // V(0); unit 0 transforms raw(1)
+    tf_pass1(); tf_pass1b(RB4 * 4u); tf_pass1w(0); tf_pass1w(1); tf_pass1w(2); tf_pass2(); tf_pass2b();
+    tf_pass2w(0, 0); tf_pass2w(0, 1); tf_pass2w(0, 2);                                // V(0); unit 0 transforms raw(1)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the V stores are asm statements: hipcc does not count them
     __syncthreads();
     af[0] = *reinterpret_cast<const f32x4*>(&Us[a_base]);
     bf[0] = *reinterpret_cast<const f32x4*>(&Vs[b_base]);
@@ -323,6 +379,17 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                                         : cur.slice;
         const float* unext = u_ptr(next_slice);
 
+        // schedule of the input transform inside a unit (group g, slot e behind the e-th MFMA of the group)
+        auto tf_at = [&](const int g, const int e, const int vb) __attribute__((always_inline)) {
+            if (g == 0 && e == 2) tf_pass1();
+            else if (g == 2 && e == 2) { tf_pass1b(3u * RB4 * 4u - rd_byte - rt_byte); tf_pass1w(0); }   // unit n+1 transforms raw((n+2) % 3)
+            else if (g == 2 && e == 3) tf_pass1w(1);
+            else if (g == 3 && e == 1) tf_pass1w(2);
+            else if (g == 3 && e == 2) tf_pass2();
+            else if (g == 5 && e == 2) { tf_pass2b(); tf_pass2w(vb ^ 1, 0); }
+            else if (g == 5 && e == 3) tf_pass2w(vb ^ 1, 1);
+            else if (g == 6 && e == 1) tf_pass2w(vb ^ 1, 2);
+        };
         // the 36 MFMAs of a unit and everything that rides in their shadow: one basic block
         auto unit_body = [&](const int c, auto first_tag, auto vb_tag) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_tag)::value;
@@ -344,6 +411,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                     // weights as the A operand: D[cout][tile] -- lane = tile, register quad = 4 consecutive output channels
                     acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g % 3][e], bf[g % 3][e], FIRST ? zero4 : acc[s], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
+                    if (e != 2) tf_at(g, e, vb);
                     if (e == 0 && !(MPQX & 4)) {
                         // fragments two groups ahead; groups 7, 8 fetch groups 0, 1 of the NEXT unit (behind the unit barrier)
                         af[(g + 2) % 3] = *reinterpret_cast<const f32x4*>(g + 2 < 9 ? &ur[4 * (g + 2)] : &urn[4 * (g - 7)]);
@@ -361,10 +429,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                         else if (g == 1) raw_dma(rsrc, rd_byte, 1);
                     } else if (e == 2) {
                         // input transform of unit n+1: raw[vb^1] -> V[vb^1]
-                        if (g == 0) tf_pass1();
-                        else if (g == 1) tf_pass1b((MPQX & 4096) ? vb * RB4 * 4u : 3u * RB4 * 4u - rd_byte - rt_byte);     // unit n+1 transforms raw((n+2) % 3)
-                        else if (g == 2) tf_pass2();
-                        else if (g == 3) tf_pass2b(vb ^ 1);
+                        // input transform of unit n+1, raw -> V[vb^1]: reads, arithmetic and stores of the two passes spread
+                        // over groups 0-6 (the schedule table is tf_at())
+                        tf_at(g, 2, vb);
                     } else {
                         if (g == 6) {
                             // unit barrier: every fragment of the unit has been fetched (two groups ahead), V(n+1) is
@@ -373,7 +440,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                             t_b0 = __builtin_amdgcn_s_memtime();
 #endif
                             // U(n+1), raw(n+2) (and an item's output stores) have landed; raw(n+3) stays in flight
-                            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                            // (lgkmcnt: the V stores are asm statements hipcc does not count)
+                            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                            if (MPQX & 65536) {
+#pragma unroll
+                                for (int q = 0; q < 6; ++q) asm volatile("" :: "v"(tq[q]), "v"(tq2[q]));
+                            }
 #ifdef MP_TIMING
                             t_b1 = __builtin_amdgcn_s_memtime();
 #endif
