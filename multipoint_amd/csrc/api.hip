@@ -503,7 +503,7 @@ bool uses_wino43(const mp_handle* h, const ConvLayer& L, int H, int W, bool fuse
 {
     if (!(L.taps == 9 && L.u43pack && h->wino && !fuse && (h->wino43 == 2 || L.cin == 64))) return false;
     ConvParams q{};
-    q.pad_zero = h->cfg.reflection_pad ? 0 : 1; q.cin = L.cin; q.H = H; q.W = W;
+    q.pad_zero = h->cfg.reflection_pad ? 0 : 1; q.cin = L.cin; q.cout = L.cout; q.H = H; q.W = W;
     return conv_wino43_supports(q);
 }
 

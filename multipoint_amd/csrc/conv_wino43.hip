@@ -251,6 +251,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     // pass 1: column `sub6` of the window: patch pixels (4*w_ty + i, 4*w_tx + sub6), i = 0..5, channels 2*w_cp, 2*w_cp+1
     const int p1_read = ((4 * w_ty) * PX + 4 * w_tx + sub6) * 4 + 2 * w_cp;             // floats into raw[]
     float* const myscr = scr + wave * SW4 + (win & 7) * 72;                             // this window's 36 pairs
+    const unsigned scr_w = lds_addr(myscr + sub6 * 2);                                  // pass 1 stores pair (i, sub6) at + 48 i bytes
     // pass 2: row `sub6`: scratch pairs [sub6][0..5]; V[ch][tile][pos = 6*sub6 + j]
     const int p2_write = (2 * w_cp * 32 + w_tile) * 36 + 6 * sub6;
     f32x2 td[6], tr[6];
@@ -283,9 +284,19 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     // the LDS write path takes two 8-byte stores per MFMA gap for free and saturates beyond: the transform's
     // stores go out in pairs, one pair per gap
     auto tf_pass1w = [&](int k) __attribute__((always_inline)) {                // rows 2k, 2k+1 of the scratch
-        if (MPQX & (1 | 32768)) return;
-#pragma unroll
-        for (int i = 2 * k; i < 2 * k + 2; ++i) *reinterpret_cast<f32x2*>(&myscr[(i * 6 + sub6) * 2]) = tr[i];
+        if (MPQX & 1) return;
+        if (MPQX & 32768) { asm volatile("" :: "v"(tr[2 * k]), "v"(tr[2 * k + 1])); return; }     // timing only: no store
+        // lanes 6, 7 of a window sit out: three lanes storing to one address are a 3-way bank conflict on every store
+        unsigned long long save;
+        if (k == 0)
+            asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %4\n\tds_write2_b64 %1, %2, %3 offset0:0 offset1:6\n\ts_mov_b64 exec, %0"
+                         : "=&s"(save) : "v"(scr_w), "v"(tr[0]), "v"(tr[1]), "s"(0x3F3F3F3F3F3F3F3Full) : "memory");
+        else if (k == 1)
+            asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %4\n\tds_write2_b64 %1, %2, %3 offset0:12 offset1:18\n\ts_mov_b64 exec, %0"
+                         : "=&s"(save) : "v"(scr_w), "v"(tr[2]), "v"(tr[3]), "s"(0x3F3F3F3F3F3F3F3Full) : "memory");
+        else
+            asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %4\n\tds_write2_b64 %1, %2, %3 offset0:24 offset1:30\n\ts_mov_b64 exec, %0"
+                         : "=&s"(save) : "v"(scr_w), "v"(tr[4]), "v"(tr[5]), "s"(0x3F3F3F3F3F3F3F3Full) : "memory");
     };
     auto tf_pass2 = [&]() __attribute__((always_inline)) {
         if (MPQX & (1 | 16384)) return;
@@ -305,18 +316,20 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
         bt6(td, tr);                                      // tr[j'] = V[row sub6][j']
     };
     auto tf_pass2w = [&](int buf, int k) __attribute__((always_inline)) {       // positions 2k, 2k+1 of both channels
-        if (MPQX & (1 | 32768)) return;
+        if (MPQX & 1) return;
+        if (MPQX & 262144) { asm volatile("" :: "v"(tr[2 * k]), "v"(tr[2 * k + 1])); return; }    // timing only: no store
         const unsigned a0 = p2_addr + (unsigned)buf * (VB4 * 4u), a1 = a0 + 32u * 36u * 4u;
         const int j = 2 * k;
-        if (k == 0)
-            asm volatile("ds_write2_b32 %0, %1, %2 offset0:0 offset1:1\n\tds_write2_b32 %3, %4, %5 offset0:0 offset1:1"
-                         :: "v"(a0), "v"(tr[j][0]), "v"(tr[j + 1][0]), "v"(a1), "v"(tr[j][1]), "v"(tr[j + 1][1]) : "memory");
-        else if (k == 1)
-            asm volatile("ds_write2_b32 %0, %1, %2 offset0:2 offset1:3\n\tds_write2_b32 %3, %4, %5 offset0:2 offset1:3"
-                         :: "v"(a0), "v"(tr[j][0]), "v"(tr[j + 1][0]), "v"(a1), "v"(tr[j][1]), "v"(tr[j + 1][1]) : "memory");
-        else
-            asm volatile("ds_write2_b32 %0, %1, %2 offset0:4 offset1:5\n\tds_write2_b32 %3, %4, %5 offset0:4 offset1:5"
-                         :: "v"(a0), "v"(tr[j][0]), "v"(tr[j + 1][0]), "v"(a1), "v"(tr[j][1]), "v"(tr[j + 1][1]) : "memory");
+        unsigned long long save;
+#define MPQ_VST(O0, O1)                                                                                                        \
+        asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %7\n\tds_write2_b32 %1, %2, %3 offset0:" #O0 " offset1:" #O1   \
+                     "\n\tds_write2_b32 %4, %5, %6 offset0:" #O0 " offset1:" #O1 "\n\ts_mov_b64 exec, %0"                        \
+                     : "=&s"(save) : "v"(a0), "v"(tr[j][0]), "v"(tr[j + 1][0]), "v"(a1), "v"(tr[j][1]), "v"(tr[j + 1][1]),       \
+                       "s"(0x3F3F3F3F3F3F3F3Full) : "memory")
+        if (k == 0) MPQ_VST(0, 1);
+        else if (k == 1) MPQ_VST(2, 3);
+        else MPQ_VST(4, 5);
+#undef MPQ_VST
     };
 
     // ---- GEMM operands: a lane's fragments of 4 consecutive positions are one ds_read_b128 ----
@@ -548,24 +561,26 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                 } else {
                     const int Ho = POOL ? p.H >> 1 : p.H, Wo = POOL ? p.W >> 1 : p.W;
                     const int py0 = POOL ? oy >> 1 : oy, px0 = POOL ? ox >> 1 : ox;
-                    // NHWC: pixel stride cs floats; planar [B][cout/4][Ho][Wo][4]: this lane's quad is plane ch0 / 4
-                    const int ps = p.out_planar ? 4 : cs;
-                    float* const o = p.out_planar
-                        ? p.out + (((long long)cur.img * (p.cout / 4) + (ch0 >> 2)) * Ho * Wo + (long long)py0 * Wo + px0) * 4
-                        : p.out + (((long long)cur.img * Ho + py0) * Wo + px0) * cs + p.out_coff + ch0;
-                    const bool quad_ok = ch0 + 3 < p.cout;
+                    // a uniform per-image base + 32-bit byte offsets (an image's output is far below 4 GB).  NHWC: pixel stride
+                    // cs floats; planar [B][cout/4][Ho][Wo][4]: this lane's quad is plane ch0 / 4, pixel stride 16 bytes
+                    char* const img_base = reinterpret_cast<char*>(
+                        p.out_planar ? p.out + (long long)cur.img * (p.cout / 4) * Ho * Wo * 4
+                                     : p.out + (long long)cur.img * Ho * Wo * cs + p.out_coff);
+                    const unsigned ps = p.out_planar ? 16u : (unsigned)cs * 4u;                       // bytes per pixel step
+                    const unsigned rs = (unsigned)Wo * ps;                                            // bytes per row step
+                    const unsigned o0 = p.out_planar ? (unsigned)(((ch0 >> 2) * Ho + py0) * Wo + px0) * 16u
+                                                     : (unsigned)((py0 * Wo + px0) * cs + ch0) * 4u;
+                    // H and W are multiples of 4 (conv_wino43_supports) and tiles are 4-aligned: a tile is inside the image or
+                    // outside as a whole, and cout is a multiple of 4 -- ONE test, then NO x NO unconditional 16-byte stores
+                    if (oy < p.H && ox < p.W && ch0 < p.cout) {
 #pragma unroll
-                    for (int a = 0; a < NO; ++a)
+                        for (int a = 0; a < NO; ++a)
 #pragma unroll
-                        for (int b = 0; b < NO; ++b)
-                            if ((py0 + a < Ho) && (px0 + b < Wo)) {
+                            for (int b = 0; b < NO; ++b) {
                                 const f32x4 v = {keep[a][b][0], keep[a][b][1], res[a][b][0], res[a][b][1]};
-                                float* const q = o + ((long long)a * Wo + b) * ps;
-                                if (quad_ok) *reinterpret_cast<f32x4*>(q) = v;
-                                else
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) if (ch0 + r < p.cout) q[r] = v[r];
+                                *reinterpret_cast<f32x4*>(img_base + (o0 + (unsigned)a * rs + (unsigned)b * ps)) = v;
                             }
+                    }
                 }
             }
         }
@@ -612,7 +627,7 @@ int launch_q(const ConvParams& p, hipStream_t s)
 // channels a multiple of 8 (units of 4, unrolled in pairs), spatial size a multiple of the 4x4 tile
 bool conv_wino43_supports(const ConvParams& p)
 {
-    return !p.pad_zero && p.cin % 8 == 0 && p.H % 4 == 0 && p.W % 4 == 0 && p.H >= 4 && p.W >= 4;
+    return !p.pad_zero && p.cin % 8 == 0 && p.cout % 4 == 0 && p.H % 4 == 0 && p.W % 4 == 0 && p.H >= 4 && p.W >= 4;
 }
 
 // p.wpack must point at the F(4x4,3x3) weights packed by pack_wino43_weights() (api.hip)
