@@ -72,8 +72,8 @@ struct mp_handle {
     int persist = 8;                // persistent conv workgroups for launches with >= this many items per CU
                                     // (MP_NO_PERSIST=1: never; MP_PERSIST_MIN_ITEMS=n overrides the threshold)
     bool fuse_first = true;         // fuse the Cin=1 block into the second convolution (MP_NO_FUSE=1 disables)
-    bool planar = true;             // MP_NO_PLANAR=1: NHWC also between two F(4x4,3x3) layers
-    int wino43 = 1;                 // MP_WINO43: 0 off, 1 (default) F(4x4,3x3) for the 3x3 layers with 64 input channels, 2 all
+    int planar = 1;                 // 0 (MP_NO_PLANAR=1): NHWC everywhere; 1: channel-quad-planar tensors where they pay; 2 (MP_PLANAR=2): between every two F(4x4,3x3) layers
+    int wino43 = 2;                 // MP_WINO43: 0 off, 1 F(4x4,3x3) for the 3x3 layers with 64 input channels only, 2 (default) every 3x3 layer it supports
     bool head_fuse = true;          // MP_NO_HEAD_FUSE=1: separate 1x1 convolution / softmax / normalisation launches
     bool wino_fuse = false;         // MP_WINO_FUSE=1: first block computed inside the Winograd conv2 loader (default since round 2:
                                     // standalone first block + Winograd conv2 with LDS-DMA staging -- 6.50 vs 6.84 ms per 64 images)
@@ -748,7 +748,8 @@ int mp_create(mp_handle** out, int device)
     { const char* e = getenv("MP_NO_WINOGRAD"); hh->wino = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_WINO_FUSE"); hh->wino_fuse = (e && e[0] == '1'); }
     { const char* e = getenv("MP_NO_HEAD_FUSE"); hh->head_fuse = !(e && e[0] == '1'); }
-    { const char* e = getenv("MP_NO_PLANAR"); if (e && e[0] == '1') hh->planar = false; }
+    { const char* e = getenv("MP_NO_PLANAR"); if (e && e[0] == '1') hh->planar = 0; }
+    { const char* e = getenv("MP_PLANAR"); if (e && e[0] >= '0' && e[0] <= '2') hh->planar = e[0] - '0'; }
     { const char* e = getenv("MP_WINO43"); if (e && e[0] >= '0' && e[0] <= '2') hh->wino43 = e[0] - '0'; }
     { const char* e = getenv("MP_PERSIST_MIN_ITEMS"); if (e && atoi(e) > 0) hh->persist = atoi(e); }
     { const char* e = getenv("MP_NO_PERSIST"); if (e && e[0] == '1') hh->persist = 0; }
@@ -911,12 +912,17 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
         // Winograd second convolution is faster than the fused direct kernel
         const bool fuse1 = h->fuse_first && h->cfg.channel_version == 0 && (!h->wino || h->wino_fuse);
         // a tensor written by conv1 or an F(4x4,3x3) layer AND read by an F(4x4,3x3) layer is channel-quad planar
-        bool f43[8] = {};
+        // -- when the producer's stores are few: conv1, or a POOLED F(4x4,3x3) layer.  (An un-pooled layer stores 16 pixels per
+        // lane and tile; planar, a store instruction then writes 16-byte pieces 64 bytes apart instead of 64-byte runs, which
+        // costs the producer more than the consumer's patch DMAs gain: conv3 1.29 vs 1.17 ms.)
+        bool f43[8] = {}, pl[9] = {};               // pl[i]: the input tensor of E.conv[i] is planar
         for (int i = 0, hh = H, ww = W; i < 7; ++i) {
-            f43[i] = h->planar && uses_wino43(h, E.conv[i], hh, ww, i == 0 && fuse1);
+            f43[i] = uses_wino43(h, E.conv[i], hh, ww, i == 0 && fuse1);
             if (E.conv[i].pool) { hh /= 2; ww /= 2; }
         }
-        c1.out_planar = f43[0] ? 1 : 0;
+        pl[0] = h->planar && f43[0];
+        for (int i = 1; i < 7; ++i) pl[i] = h->planar && f43[i - 1] && f43[i] && (E.conv[i - 1].pool || h->planar == 2);
+        c1.out_planar = pl[0] ? 1 : 0;
         if (!fuse1) {
             prof_begin(h, "enc.conv1", 2.0 * 9 * 64 * (double)nb * H * W, s);
             launch_conv_first(c1, s);
@@ -928,14 +934,13 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
         for (int i = 0; i < 7; ++i) {
             const ConvLayer& L = E.conv[i];
             if ((rc = run_conv(h, L, src, L.cin, 0, i == 6 ? X : dst, L.cout, 0, nb, hh, ww, lptr[e], s,
-                     (i == 0 && fuse1) ? &E.first : nullptr, images, (i == 0 || f43[i - 1]) && f43[i],
-                     f43[i] && f43[i + 1]))) return rc;
+                     (i == 0 && fuse1) ? &E.first : nullptr, images, pl[i], pl[i + 1]))) return rc;
             if (L.pool) { hh /= 2; ww /= 2; }
             float* t = src; src = dst; dst = t;
         }
     }
     // heads
-    if ((rc = run_conv(h, h->heads3, X, h->heads3.cin, 0, P, headc, 0, B, Hc, Wc, nullptr, s))) return rc;
+    if ((rc = run_conv(h, h->heads3, X, h->heads3.cin, 0, P, headc, 0, B, Hc, Wc, nullptr, s))) return rc;       // (a planar encoder output was measured: slower)
     if (h->head_fuse) {
         // both 1x1 convolutions + BN + softmax / shuffle + normalisation in ONE launch that reads P once (head_tail.hip)
         HeadTailParams t{};

@@ -52,18 +52,19 @@ def test_forward_matches_oracle(oracle, shipped, B, H, W):
 
 @pytest.mark.parametrize('env', [{'MP_PERSIST_MIN_ITEMS': '1'}, {'MP_NO_PERSIST': '1'}, {'MP_NO_FUSE': '1'},
                                  {'MP_WINO_FUSE': '1'}, {'MP_NO_WINOGRAD': '1'}, {'MP_NO_WINOGRAD': '1', 'MP_NO_FUSE': '1'},
-                                 {'MP_NO_HEAD_FUSE': '1'}, {'MP_WINO43': '0'}, {'MP_WINO43': '2'}, {'MP_NO_PLANAR': '1'},
-                                 {'MP_WINO43': '2', 'MP_NO_PLANAR': '1'}])
+                                 {'MP_NO_HEAD_FUSE': '1'}, {'MP_WINO43': '0'}, {'MP_WINO43': '1'}, {'MP_NO_PLANAR': '1'},
+                                 {'MP_PLANAR': '2'}, {'MP_WINO43': '1', 'MP_PLANAR': '2'}])
 @pytest.mark.parametrize('B,H,W', [(6, 120, 160), (3, 200, 328)])
 def test_forward_kernel_variants(oracle, monkeypatch, env, B, H, W):
     """Every convolution kernel variant against the oracle on the same inputs: the persistent one-workgroup-per-CU
     kernel forced onto small launches (all tile shapes, partial tiles at the right/bottom edge), the per-tile kernel
     only, the first block fused into the Winograd conv2 loader, the unfused first block in front of the direct second
     convolution, the first block fused into the direct kernel, the four separate head-tail launches instead of the fused
-    head_tail kernel, Winograd F(2x2,3x3) everywhere (MP_WINO43=0), F(4x4,3x3) on every 3x3 layer it supports instead of
-    the 64-input-channel ones only (MP_WINO43=2), NHWC instead of channel-quad-planar tensors between F(4x4,3x3) layers
-    (MP_NO_PLANAR=1).  The default -- standalone first block writing planar, F(4x4,3x3) for conv2..conv5 where the
-    frame is a multiple of 4, F(2x2,3x3) behind them, LDS-DMA staging -- is what every other test of this file runs."""
+    head_tail kernel, Winograd F(2x2,3x3) everywhere (MP_WINO43=0), F(4x4,3x3) on the 64-input-channel layers only
+    (MP_WINO43=1), NHWC everywhere (MP_NO_PLANAR=1) or channel-quad-planar tensors between EVERY two F(4x4,3x3) layers
+    (MP_PLANAR=2) instead of behind conv1 and the pooled layers only.  The default -- standalone first block writing
+    planar, F(4x4,3x3) on every 3x3 layer whose frame is a multiple of 4 (F(2x2,3x3) otherwise), LDS-DMA staging -- is
+    what every other test of this file runs."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     net, sd = _net(oracle, oracle.SHIPPED_MODEL_CONFIG, seed=4)          # new handle: reads the environment
@@ -111,6 +112,11 @@ def test_planar_layout_is_bit_identical(oracle, monkeypatch, upd, B, H, W):
     net2, _ = _net(oracle, cfg, seed=5)
     b = net2({'image': img.cuda(), 'is_optical': flags})
     assert torch.equal(a['prob'], b['prob']) and torch.equal(a['desc'], b['desc'])
+    monkeypatch.delenv('MP_NO_PLANAR')
+    monkeypatch.setenv('MP_PLANAR', '2')                # planar between EVERY two F(4x4,3x3) layers (un-pooled producers too)
+    net3, _ = _net(oracle, cfg, seed=5)
+    c = net3({'image': img.cuda(), 'is_optical': flags})
+    assert torch.equal(c['prob'], b['prob']) and torch.equal(c['desc'], b['desc'])
 
 
 @pytest.mark.parametrize('upd', [{'channel_version': 1}, {'channel_version': 2}, {'channel_version': 1, 'descriptor_size': 128},
