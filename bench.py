@@ -348,7 +348,7 @@ def main():
         elif f43:
             # Winograd F(4x4,3x3): 36 multiplies per 4x4 output tile and channel pair instead of 144 -> 4x fewer MFMA FLOPs
             issued = flop / 4.0
-            kernel = ('conv_wino43_kernel<true,false> (enc.conv2 64->64 @480x640 by Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32, '
+            kernel = ('conv_wino43_kernel<true,false,8> (enc.conv2 64->64 @480x640 by Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32, '
                       'weights and channel-quad-planar input patches staged by LDS-DMA, + bias/ReLU/BN + 2x2 max-pool)')
         else:
             issued = (conv2_flop if fused else flop) / 2.25

@@ -54,10 +54,9 @@ extern "C" int mp_debug_read_timing_wino43(unsigned long long* host, int n)
 #endif
 namespace {
 
-constexpr int TR4 = 4, TC4 = 8;                    // tiles of an item: 4 rows x 8 columns
-constexpr int OY = 4 * TR4, OX = 4 * TC4;          // output pixels of an item: 16 x 32
-constexpr int PY = OY + 2, PX = OX + 2;            // raw patch: 18 x 34
-constexpr int NPIX = PY * PX;                      // 612 patch pixels = 16-byte granules (4 channels each)
+// an item's 32 tiles are 4 rows x 8 columns (16 x 32 output pixels, raw patch 18 x 34) or -- TC4 = 4 -- 8 rows x 4 columns (32 x 16
+// pixels, patch 34 x 18): launch_q picks the shape with fewer phantom tiles (60 x 80 layers: 8 instead of 12 items per image)
+constexpr int NPIX = 18 * 34;                      // 612 patch pixels = 16-byte granules (4 channels each), either shape
 constexpr int UC4 = 4;                             // input channels per unit
 constexpr int VB4 = UC4 * 32 * 36;                 // floats per V buffer  [ch][tile][pos]   (18 KiB)
 constexpr int UB4 = UC4 * 64 * 36;                 // floats per U buffer  [ch][cout][pos]   (36 KiB)
@@ -138,9 +137,13 @@ __device__ __forceinline__ void at6(const f32x2 m[6], f32x2 y[4])
     y[3] = (d1 + c8 * d2) + m[5];
 }
 
-template <bool POOL, bool BNF>
+template <bool POOL, bool BNF, int TC4>
 __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
 {
+    constexpr int TR4 = 32 / TC4;                      // tile rows x tile columns of an item
+    constexpr int OY = 4 * TR4, OX = 4 * TC4;          // output pixels of an item
+    constexpr int PY = OY + 2, PX = OX + 2;            // raw patch
+    static_assert(PY * PX == NPIX, "item shape");
     __shared__ __attribute__((aligned(16))) float Vs[2 * VB4];
     __shared__ __attribute__((aligned(16))) float Us[2 * UB4];
     __shared__ __attribute__((aligned(16))) float raw[3 * RB4 + 256];
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     // ---- input transform V = B^T d B of one unit: 8 lanes per window (tile, channel pair); lanes 0-5 work ----
     const int win = tid >> 3, sub = tid & 7;             // window 0..63 of the unit: tile = win >> 1, channel pair = win & 1
     const int w_tile = win >> 1, w_cp = win & 1;
-    const int w_ty = w_tile >> 3, w_tx = w_tile & 7;     // tile row / column inside the item (8 tiles per row)
+    const int w_ty = w_tile / TC4, w_tx = w_tile % TC4;  // tile row / column inside the item
     const int sub6 = sub < 6 ? sub : 5;                  // lanes 6, 7 repeat lane 5's work (results identical, harmless)
     // pass 1: column `sub6` of the window: patch pixels (4*w_ty + i, 4*w_tx + sub6), i = 0..5, channels 2*w_cp, 2*w_cp+1
     const int p1_read = ((4 * w_ty) * PX + 4 * w_tx + sub6) * 4 + 2 * w_cp;             // floats into raw[]
@@ -500,12 +503,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
             for (int s2 = 0; s2 < 36; ++s2) sink += acc[s2][0] + acc[s2][1] + acc[s2][2] + acc[s2][3];
             if (sink == 123.456f) p.out[tid] = sink;
         } else {
-            const int tl = tb * 16 + (lane & 15);                       // tile of the item: row tl >> 3, column tl & 7
+            const int tl = tb * 16 + (lane & 15);                       // tile of the item: row tl / TC4, column tl % TC4
             const int cl = cb * 16 + 4 * (lane >> 4);                   // first of this lane's 4 output channels in the slice
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(&prm[cl]);
             const f32x4 s4 = *reinterpret_cast<const f32x4*>(&prm[64 + cl]);
             const f32x4 t4 = *reinterpret_cast<const f32x4*>(&prm[128 + cl]);
-            const int oy = cur.y0 + 4 * (tl >> 3), ox = cur.x0 + 4 * (tl & 7);
+            const int oy = cur.y0 + 4 * (tl / TC4), ox = cur.x0 + 4 * (tl % TC4);
             const int ch0 = cur.slice * 64 + cl;
             const int cs = p.out_cstride;
             // per channel pair h (registers 2h, 2h+1): transform, activation, [pool] -- the 72 accumulator registers of a
@@ -602,9 +605,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     }
 }
 
-template <bool POOL>
+template <bool POOL, int TC4>
 int launch_q(const ConvParams& p, hipStream_t s)
 {
+    constexpr int OY = 4 * (32 / TC4), OX = 4 * TC4;
     ConvParams q = p;
     q.tiles_x = (p.W + OX - 1) / OX; q.tiles_y = (p.H + OY - 1) / OY;
     const long long nitems = (long long)p.B * q.tiles_x * q.tiles_y * p.nslices;
@@ -616,9 +620,17 @@ int launch_q(const ConvParams& p, hipStream_t s)
     q.nitems = (int)nitems;
     const unsigned grid = (unsigned)std::min<long long>(256, ((nitems + 7) / 8) * 8);
     const ConvParams& pp = q;
-    if (p.bn_first) hipLaunchKernelGGL((conv_wino43_kernel<POOL, true>), dim3(grid), dim3(512), 0, s, pp);
-    else hipLaunchKernelGGL((conv_wino43_kernel<POOL, false>), dim3(grid), dim3(512), 0, s, pp);
+    if (p.bn_first) hipLaunchKernelGGL((conv_wino43_kernel<POOL, true, TC4>), dim3(grid), dim3(512), 0, s, pp);
+    else hipLaunchKernelGGL((conv_wino43_kernel<POOL, false, TC4>), dim3(grid), dim3(512), 0, s, pp);
     return 0;
+}
+
+// the item shape that covers the frame with fewer items (16 x 32 pixels on a tie: longer contiguous patch rows)
+template <bool POOL>
+int launch_shape(const ConvParams& p, hipStream_t s)
+{
+    const long long wide = (long long)((p.W + 31) / 32) * ((p.H + 15) / 16), tall = (long long)((p.W + 15) / 16) * ((p.H + 31) / 32);
+    return tall < wide ? launch_q<POOL, 4>(p, s) : launch_q<POOL, 8>(p, s);
 }
 
 }  // namespace
@@ -633,5 +645,5 @@ bool conv_wino43_supports(const ConvParams& p)
 // p.wpack must point at the F(4x4,3x3) weights packed by pack_wino43_weights() (api.hip)
 int launch_conv_wino43(const ConvParams& p, bool pool, hipStream_t s)
 {
-    return pool ? launch_q<true>(p, s) : launch_q<false>(p, s);
+    return pool ? launch_shape<true>(p, s) : launch_shape<false>(p, s);
 }

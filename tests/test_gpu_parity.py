@@ -38,7 +38,7 @@ def shipped(oracle):
 
 # ------------------------------------------------------------------------------------------ forward
 @pytest.mark.parametrize('B,H,W', [(2, 64, 64), (1, 240, 320), (3, 72, 104), (1, 16, 16), (2, 480, 640), (5, 40, 264),
-                                   (1, 1024, 1280), (2, 24, 2048), (1, 1032, 16)])
+                                   (1, 1024, 1280), (2, 24, 2048), (1, 1032, 16), (3, 88, 48)])
 def test_forward_matches_oracle(oracle, shipped, B, H, W):
     net, sd = shipped
     img = oracle.make_images(100 + H, B, H, W)
@@ -98,7 +98,7 @@ def test_fused_first_block_equals_unfused(oracle, monkeypatch, upd, B, H, W):
 
 
 @pytest.mark.parametrize('upd', [{}, {'multispectral': True}, {'bn_first': True}])
-@pytest.mark.parametrize('B,H,W', [(3, 72, 104), (2, 16, 16), (1, 240, 320)])
+@pytest.mark.parametrize('B,H,W', [(3, 72, 104), (2, 16, 16), (1, 240, 320), (2, 88, 48)])
 def test_planar_layout_is_bit_identical(oracle, monkeypatch, upd, B, H, W):
     """Channel-quad-planar tensors [B][C/4][H][W][4] between conv1 and the F(4x4,3x3) layers (default) against NHWC everywhere
     (MP_NO_PLANAR=1): the layout changes which bytes a DMA fetches, not one multiply-add, so the outputs are EQUAL -- partial
