@@ -1,8 +1,13 @@
+#!/bin/bash
+# Developer tool (GPU box, repo root): everything profiles/ is regenerated from -- the rocprofv3 passes of
+# tools/collect_profiles.sh plus the bench lines (default, --workload c5, RCCL world size 1, F(2x2,3x3)-only A/B).
+#   bash tools/collect_all.sh gpurun_out/prof_rNN ; python tools/summarize_profiles.py gpurun_out/prof_rNN rNN
 set -u
-R=gpurun_out/prof_r02b
-bash tools/collect_profiles.sh $R > $R.log 2>&1
-python3 bench.py > $R/bench_n1.json 2> $R/bench_n1.err
-python3 bench.py --workload c5 > $R/bench_c5.json 2> $R/bench_c5.err
-python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --no-cpu-baseline > $R/bench_rccl.json 2> $R/bench_rccl.err
-MP_WINO43=0 python3 bench.py --no-cpu-baseline > $R/bench_f22.json 2> $R/bench_f22.err
-ls -l $R | head -40
+R=${1:-gpurun_out/prof}
+mkdir -p "$R"
+bash tools/collect_profiles.sh "$R" > "$R.log" 2>&1
+python3 bench.py > "$R/bench_n1.json" 2> "$R/bench_n1.err"
+python3 bench.py --workload c5 > "$R/bench_c5.json" 2> "$R/bench_c5.err"
+python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --no-cpu-baseline > "$R/bench_rccl.json" 2> "$R/bench_rccl.err"
+MP_WINO43=0 python3 bench.py --no-cpu-baseline > "$R/bench_f22.json" 2> "$R/bench_f22.err"
+ls -l "$R" | head -40
