@@ -34,7 +34,8 @@ def _cpu_side(oracle, sd, cfg, P, H, W, mixed):
     return _cpu_cache[key]
 
 
-@pytest.mark.parametrize('variant,P,root_tol', [('winograd', 16, 2e-4), ('direct', 16, 2e-4), ('fp16', 4, None)])
+@pytest.mark.parametrize('variant,P,root_tol', [('winograd', 16, 2e-4), ('winograd22', 16, 2e-4), ('direct', 16, 2e-4),
+                                                ('fp16', 4, None)])
 def test_e2e_keypoint_flip_accounting(oracle, monkeypatch, variant, P, root_tol):
     import multipoint_amd.models as M
     from multipoint_amd.pipeline import PairPipeline
@@ -43,6 +44,8 @@ def test_e2e_keypoint_flip_accounting(oracle, monkeypatch, variant, P, root_tol)
     cfg = dict(oracle.SHIPPED_MODEL_CONFIG)
     if variant == 'direct':
         monkeypatch.setenv('MP_NO_WINOGRAD', '1')
+    if variant == 'winograd22':                      # F(2x2,3x3) on every 3x3 layer ('winograd' = the default: F(4x4,3x3))
+        monkeypatch.setenv('MP_WINO43', '0')
     if variant == 'fp16':
         cfg['mixed_precision'] = True
     sd = oracle.make_weights(0, cfg)
