@@ -62,6 +62,7 @@ struct mp_handle {
     DevBuf ws2;                     // NMS work map + kept lists
     DevBuf ws3;                     // matching arg-min arrays
     DevBuf ws4;                     // pair metrics: warped keypoints + inverse match map
+    DevBuf fuse43_ws;               // conv_wino43.hip with the first block fused in: per-workgroup patch scratch (80 MB)
     DevBuf nms_state;               // 64 round counters + tile flags
     DevBuf kp_scratch;              // segment counts + list totals of the keypoint compaction
     int* nms_total = nullptr;       // device: undecided candidates summed over all calls since the last read
@@ -75,6 +76,7 @@ struct mp_handle {
     int planar = 1;                 // 0 (MP_NO_PLANAR=1): NHWC everywhere; 1: channel-quad-planar tensors where they pay; 2 (MP_PLANAR=2): between every two F(4x4,3x3) layers
     int wino43 = 2;                 // MP_WINO43: 0 off, 1 F(4x4,3x3) for the 3x3 layers with 64 input channels only, 2 (default) every 3x3 layer it supports
     bool head_fuse = true;          // MP_NO_HEAD_FUSE=1: separate 1x1 convolution / softmax / normalisation launches
+    bool fuse43 = true;             // first block evaluated inside the F(4x4,3x3) conv2 kernel (MP_NO_FUSE43=1: its own launch)
     bool wino_fuse = false;         // MP_WINO_FUSE=1: first block computed inside the Winograd conv2 loader (default since round 2:
                                     // standalone first block + Winograd conv2 with LDS-DMA staging -- 6.50 vs 6.84 ms per 64 images)
     int* pinned = nullptr;          // small pinned host scratch (img lists, counters)
@@ -501,7 +503,9 @@ int too_large(mp_handle* h, const char* name, int B, int H, int W)
 // does run_conv() send this 3x3 layer at H x W to the F(4x4,3x3) kernel?
 bool uses_wino43(const mp_handle* h, const ConvLayer& L, int H, int W, bool fuse)
 {
-    if (!(L.taps == 9 && L.u43pack && h->wino && !fuse && (h->wino43 == 2 || L.cin == 64))) return false;
+    // fuse: the first block is evaluated by the layer's kernel -- with F(4x4,3x3) only by the pooled 64 -> 64 layer, 64 real channels
+    if (fuse && !(h->fuse43 && !h->wino_fuse && L.pool && L.cin == 64 && L.cout == 64 && h->cfg.channel_version == 0)) return false;
+    if (!(L.taps == 9 && L.u43pack && h->wino && (h->wino43 == 2 || L.cin == 64))) return false;
     ConvParams q{};
     q.pad_zero = h->cfg.reflection_pad ? 0 : 1; q.cin = L.cin; q.cout = L.cout; q.H = H; q.W = W;
     return conv_wino43_supports(q);
@@ -536,7 +540,12 @@ int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, 
     int big;
     if (uses_wino43(h, L, H, W, fuse != nullptr)) {
         p.wpack = L.u43pack; p.in_planar = in_planar; p.out_planar = out_planar;
-        big = launch_conv_wino43(p, L.pool, s);
+        if (fuse) {
+            int rc;
+            if ((rc = ensure(h, h->fuse43_ws, conv_wino43_scratch_floats() * 4))) return rc;
+            p.scratch = static_cast<float*>(h->fuse43_ws.p);
+        }
+        big = launch_conv_wino43(p, L.pool, s, fuse != nullptr);
     } else if (L.taps == 9 && L.upack && h->wino && (!fuse || (L.pool && L.cin == 64))) {
         p.wpack = L.upack;
         big = launch_conv_wino(p, L.pool, fuse != nullptr, s);
@@ -747,6 +756,7 @@ int mp_create(mp_handle** out, int device)
     { const char* e = getenv("MP_NO_FUSE"); hh->fuse_first = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_NO_WINOGRAD"); hh->wino = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_WINO_FUSE"); hh->wino_fuse = (e && e[0] == '1'); }
+    { const char* e = getenv("MP_NO_FUSE43"); hh->fuse43 = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_NO_HEAD_FUSE"); hh->head_fuse = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_NO_PLANAR"); if (e && e[0] == '1') hh->planar = 0; }
     { const char* e = getenv("MP_PLANAR"); if (e && e[0] >= '0' && e[0] <= '2') hh->planar = e[0] - '0'; }
@@ -770,6 +780,7 @@ void mp_destroy(mp_handle* h)
     if (h->ws2.p) (void)hipFree(h->ws2.p);
     if (h->ws3.p) (void)hipFree(h->ws3.p);
     if (h->ws4.p) (void)hipFree(h->ws4.p);
+    if (h->fuse43_ws.p) (void)hipFree(h->fuse43_ws.p);
     if (h->nms_state.p) (void)hipFree(h->nms_state.p);
     if (h->kp_scratch.p) (void)hipFree(h->kp_scratch.p);
     if (h->nms_total) (void)hipFree(h->nms_total);
@@ -910,7 +921,8 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
         c1.channels = E.first.channels;
         // the fused loader is a 64-channel direct-convolution kernel; with Winograd on, the standalone first block +
         // Winograd second convolution is faster than the fused direct kernel
-        const bool fuse1 = h->fuse_first && h->cfg.channel_version == 0 && (!h->wino || h->wino_fuse);
+        const bool fuse1 = h->fuse_first && h->cfg.channel_version == 0 &&
+                           (!h->wino || h->wino_fuse || uses_wino43(h, E.conv[0], H, W, true));
         // a tensor written by conv1 or an F(4x4,3x3) layer AND read by an F(4x4,3x3) layer is channel-quad planar
         // -- when the producer's stores are few: conv1, or a POOLED F(4x4,3x3) layer.  (An un-pooled layer stores 16 pixels per
         // lane and tile; planar, a store instruction then writes 16-byte pieces 64 bytes apart instead of 64-byte runs, which

@@ -141,7 +141,12 @@ __device__ __forceinline__ void at6(const f32x2 m[6], f32x2 y[4])
     y[3] = (d1 + c8 * d2) + m[5];
 }
 
-template <bool POOL, bool BNF, int TC4>
+// F1: the layer's input is the first encoder block (Cin = 1 -> 64, conv_first.hip's arithmetic) of p.img, computed by this
+// kernel itself: at the start of an item the workgroup evaluates the block on the NEXT item's 18 x 34 patch (vector pipe, no
+// MFMAs in flight: ~5 k cycles of an item's ~60 k) and parks the result in its own global scratch, patch order, channel quads
+// planar -- the unit loop then DMAs its raw patches from there (L2 / Infinity Cache hits, 1 KiB contiguous per instruction,
+// no reflection cases) instead of from a 5 GB tensor that a separate HBM-write-bound launch would have to produce.
+template <bool POOL, bool BNF, int TC4, bool F1>
 __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
 {
     constexpr int TR4 = 32 / TC4;                      // tile rows x tile columns of an item
@@ -153,6 +158,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     __shared__ __attribute__((aligned(16))) float raw[3 * RB4 + 256];
     __shared__ __attribute__((aligned(16))) float scr[8 * SW4];
     __shared__ __attribute__((aligned(16))) float prm[3 * 64];
+    __shared__ float w1s[F1 ? 9 * 64 : 1];               // F1: the first block's weights [tap][channel], loaded once
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -188,10 +194,20 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
 
     // ---- raw patch staging by DMA: granule f = block * 64 + lane = patch pixel f; this wave issues blocks wave, wave + 8 ----
     const int pix_stride = p.in_planar ? 4 : p.in_cstride;              // floats between horizontally adjacent pixels
-    const long long unit_stride = p.in_planar ? (long long)p.H * p.W * 4 : UC4;     // floats between consecutive units
+    const long long unit_stride = F1 ? NPIX * 4 : p.in_planar ? (long long)p.H * p.W * 4 : UC4;     // floats between consecutive units
     unsigned rvoff[2];            // byte offset of the granule's source pixel (channel 0 of the unit)
     bool roff_rel = false;        // rvoff holds the item-invariant offsets of interior items
+    int ld_par = 0;                   // F1: scratch buffer (item parity) of the cursor's item
+    float* const sbase = F1 ? p.scratch + (long long)blockIdx.x * (2 * 16 * NPIX * 4) : nullptr;
     auto raw_offsets = [&](const Where& w) __attribute__((always_inline)) -> const float* {
+        if (F1) {                     // patch order in the scratch: granule f at byte 16 f of the unit's plane
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int f = (wave + 8 * j) * 64 + lane;
+                rvoff[j] = (f < NPIX) ? (unsigned)f * 16u : 0u;
+            }
+            return sbase + ld_par * (16 * NPIX * 4);
+        }
         const bool interior = (w.y0 >= 1) && (w.y0 + OY < p.H) && (w.x0 >= 1) && (w.x0 + OX < p.W);
         if (interior) {
             if (!roff_rel) {
@@ -344,8 +360,89 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     const int b_base = ((lane >> 4) * 32 + tb * 16 + (lane & 15)) * 36;    // V[ch = lane>>4][tile][pos]
     f32x4 af[3], bf[3];                                                     // rings over position groups of 4
 
+    // ---- F1: the first encoder block on an item's patch -> scratch[par] ----
+    // Patch pixel (py, px) is the block's output at (reflect(y0 + py - 1), reflect(x0 + px - 1)) -- THIS layer's reflection
+    // padding -- whose own 3x3 window reads the image with the block's reflection padding: the image patch staged in LDS
+    // holds rows reflect(y0 - 2 + r), so a window is always three consecutive staged rows / columns.
+    // The block is a GEMM D[channel][pixel] = W[channel][tap] * X[tap][pixel] with K = 9 taps padded to 12 on the matrix pipe,
+    // which idles between two unit loops (the vector form cost 15 k cycles per item): per block of 16 pixels and 16 channels
+    // three v_mfma_f32_16x16x4_f32; a lane gathers its pixel's taps k = 4j + lane/16 from the LDS image, and the result
+    // registers of a lane are 4 consecutive channels of one pixel = one 16-byte store into the quad-planar scratch.
+    // (Same products as conv_first.hip, summed by the MFMA in its own order: equal to the standalone launch to 1-2 ulp.)
+    const int c1_kg = lane >> 4, c1_lp = lane & 15;
+#ifdef MP_TIMING
+    unsigned long long c1_t1 = 0;
+#endif
+    auto conv1_item = [&](const Where& w, int par) __attribute__((always_inline)) {
+        constexpr int IW = PX + 2, IH = PY + 2;
+        float* const ip = scr;                                    // the transform scratch is idle between two unit loops:
+        float* const wl = scr + 768;                              // image patch (720 floats + a zero) + bias, scale, shift [3][64]
+        const float* const im = p.img + (long long)w.img * p.H * p.W;
+        for (int f = tid; f < IH * IW; f += 512) {
+            const int r = f / IW, c = f - r * IW;
+            ip[f] = im[reflect_clamp_q(w.y0 + r - 2, p.H) * p.W + reflect_clamp_q(w.x0 + c - 2, p.W)];
+        }
+        if (tid == 0) ip[IH * IW] = 0.f;                          // what the padding taps 9..11 read
+        if (tid < 192) wl[tid] = tid < 64 ? p.b1[tid] : tid < 128 ? p.s1[tid - 64] : p.t1[tid - 128];
+        // A operand: weights of tap k = 4j + lane/16 (0 beyond tap 8), channel 16 * block + lane % 16
+        float wa[4][3];
+        int toff[3];                                              // tap k's offset inside a window (the zero cell for the padding taps)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int k = 4 * j + c1_kg;
+            toff[j] = k < 9 ? (k / 3) * IW + (k % 3) : -1;
+#pragma unroll
+            for (int cbk = 0; cbk < 4; ++cbk) wa[cbk][j] = k < 9 ? w1s[k * 64 + cbk * 16 + c1_lp] : 0.f;
+        }
+        __syncthreads();
+#ifdef MP_TIMING
+        c1_t1 = __builtin_amdgcn_s_memtime();
+#endif
+        float* const S = sbase + par * (16 * NPIX * 4);
+        // (one block at a time: the GEMM loop's state stays in registers across this phase, there is room for little else)
+#pragma unroll 1
+        for (int blk = wave; blk < (NPIX + 15) / 16; blk += 8) {
+            const int f = blk * 16 + c1_lp;
+            const int fc = f < NPIX ? f : NPIX - 1;
+            const int py = fc / PX, px = fc - py * PX;
+            int ly = reflect_clamp_q(w.y0 + py - 1, p.H) - w.y0 + 1, lx = reflect_clamp_q(w.x0 + px - 1, p.W) - w.x0 + 1;
+            ly = min(max(ly, 0), IH - 3); lx = min(max(lx, 0), IW - 3);          // (only pixels of phantom outputs are clamped)
+            const int o = ly * IW + lx;
+            float xb[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) xb[j] = ip[toff[j] >= 0 ? o + toff[j] : IH * IW];
+#pragma unroll
+            for (int cbk = 0; cbk < 4; ++cbk) {
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < 3; ++j) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cbk][j], xb[j], d, 0, 0, 0);
+                const int q = cbk * 4 + c1_kg;                     // this lane's channel quad
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(wl + 4 * q);
+                const f32x4 s4 = *reinterpret_cast<const f32x4*>(wl + 64 + 4 * q);
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(wl + 128 + 4 * q);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float a = d[e] + b4[e];
+                    if (BNF) a = fmaxf(a * s4[e] + t4[e], 0.f);
+                    else a = fmaxf(a, 0.f) * s4[e] + t4[e];
+                    v[e] = a;
+                }
+                if (f < NPIX) *reinterpret_cast<f32x4*>(S + ((long long)q * NPIX + f) * 4) = v;
+            }
+        }
+        __syncthreads();                                          // image patch and parameters are dead: the scratch is the transform's again
+    };
+
     // ---- prologue ----
     Where cur = decode(item);
+    if (F1) {
+        for (int f = tid; f < 9 * 64; f += 512) w1s[f] = p.w1[f];
+        __syncthreads();
+        conv1_item(cur, 0);
+        dma_wait();                                               // (vmcnt counts the stores too)
+        __syncthreads();                                          // scratch[0] is visible to every wave's DMA
+    }
     const float* rbase = raw_offsets(cur);
     const float* rsrc = rbase;               // the cursor's unit: rbase + ld_chunk * unit_stride
     Where ld_item = cur;
@@ -357,6 +454,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
             ld_chunk = 0;
             if (ld_next_item < item_end) {
                 ld_item = decode(ld_next_item);
+                ld_par ^= 1;
                 rbase = raw_offsets(ld_item);
                 ld_next_item += stride;
             }
@@ -386,6 +484,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     bf[1] = *reinterpret_cast<const f32x4*>(&Vs[b_base + 4]);
 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    int cur_par = 0;                  // F1: scratch buffer of the current item
 #ifdef MP_TIMING
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool t_on = ((POOL ? p.H : -p.H) == g_timing_q_sel);
@@ -398,6 +497,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
         const int next_slice = has_next ? (int)(item_next - (int)udiv((unsigned)item_next, p.magic_slices, (unsigned)p.nslices) * p.nslices)
                                         : cur.slice;
         const float* unext = u_ptr(next_slice);
+        // F1: the first block on the NEXT item's patch (its stores are older than every DMA of this item's loop, so the first
+        // unit barrier's vmcnt(2) has seen them land long before the last units fetch from there)
+        if (F1 && has_next) {
+            MPQ_T(t_c0);
+            conv1_item(decode(item_next), cur_par ^ 1);
+            MPQ_T(t_c1);
+            MPQ_ADD(5, t_c0, t_c1);                                        // first block on the next item's patch
+            MPQ_ADD(6, t_c0, c1_t1);                                       // ... of which: staging the image patch and the parameters
+        }
 
         // schedule of the input transform inside a unit (group g, slot e behind the e-th MFMA of the group)
         auto tf_at = [&](const int g, const int e, const int vb) __attribute__((always_inline)) {
@@ -605,11 +713,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
         }
         item = item_next;
         cur = decode(item);
+        cur_par ^= 1;
         up = unext;
     }
 }
 
-template <bool POOL, int TC4>
+template <bool POOL, int TC4, bool F1 = false>
 int launch_q(const ConvParams& p, hipStream_t s)
 {
     constexpr int OY = 4 * (32 / TC4), OX = 4 * TC4;
@@ -624,8 +733,8 @@ int launch_q(const ConvParams& p, hipStream_t s)
     q.nitems = (int)nitems;
     const unsigned grid = (unsigned)std::min<long long>(256, ((nitems + 7) / 8) * 8);
     const ConvParams& pp = q;
-    if (p.bn_first) hipLaunchKernelGGL((conv_wino43_kernel<POOL, true, TC4>), dim3(grid), dim3(512), 0, s, pp);
-    else hipLaunchKernelGGL((conv_wino43_kernel<POOL, false, TC4>), dim3(grid), dim3(512), 0, s, pp);
+    if (p.bn_first) hipLaunchKernelGGL((conv_wino43_kernel<POOL, true, TC4, F1>), dim3(grid), dim3(512), 0, s, pp);
+    else hipLaunchKernelGGL((conv_wino43_kernel<POOL, false, TC4, F1>), dim3(grid), dim3(512), 0, s, pp);
     return 0;
 }
 
@@ -646,8 +755,12 @@ bool conv_wino43_supports(const ConvParams& p)
     return !p.pad_zero && p.cin % 8 == 0 && p.cout % 4 == 0 && p.H % 4 == 0 && p.W % 4 == 0 && p.H >= 4 && p.W >= 4;
 }
 
-// p.wpack must point at the F(4x4,3x3) weights packed by pack_wino43_weights() (api.hip)
-int launch_conv_wino43(const ConvParams& p, bool pool, hipStream_t s)
+// p.wpack must point at the F(4x4,3x3) weights packed by pack_wino43_weights() (api.hip).  fuse_first: the input is the
+// first encoder block of p.img (p.w1 / b1 / s1 / t1, 64 channels), evaluated inside the kernel; p.scratch holds
+// conv_wino43_scratch_floats() floats; the layer must be the pooled 64 -> 64 one (enc.conv2)
+size_t conv_wino43_scratch_floats() { return (size_t)256 * 2 * 16 * NPIX * 4; }
+int launch_conv_wino43(const ConvParams& p, bool pool, hipStream_t s, bool fuse_first)
 {
+    if (fuse_first) return pool && p.cin == 64 ? launch_q<true, 8, true>(p, s) : 1;
     return pool ? launch_shape<true>(p, s) : launch_shape<false>(p, s);
 }

@@ -53,7 +53,7 @@ def test_forward_matches_oracle(oracle, shipped, B, H, W):
 @pytest.mark.parametrize('env', [{'MP_PERSIST_MIN_ITEMS': '1'}, {'MP_NO_PERSIST': '1'}, {'MP_NO_FUSE': '1'},
                                  {'MP_WINO_FUSE': '1'}, {'MP_NO_WINOGRAD': '1'}, {'MP_NO_WINOGRAD': '1', 'MP_NO_FUSE': '1'},
                                  {'MP_NO_HEAD_FUSE': '1'}, {'MP_WINO43': '0'}, {'MP_WINO43': '1'}, {'MP_NO_PLANAR': '1'},
-                                 {'MP_PLANAR': '2'}, {'MP_WINO43': '1', 'MP_PLANAR': '2'}])
+                                 {'MP_PLANAR': '2'}, {'MP_WINO43': '1', 'MP_PLANAR': '2'}, {'MP_NO_FUSE43': '1'}])
 @pytest.mark.parametrize('B,H,W', [(6, 120, 160), (3, 200, 328)])
 def test_forward_kernel_variants(oracle, monkeypatch, env, B, H, W):
     """Every convolution kernel variant against the oracle on the same inputs: the persistent one-workgroup-per-CU
@@ -95,6 +95,26 @@ def test_fused_first_block_equals_unfused(oracle, monkeypatch, upd, B, H, W):
     ref = oracle.forward(sd, img, cfg, is_optical=flags)
     assert (fp - ref['prob']).abs().max().item() <= PROB_TOL and (fd - ref['desc']).abs().max().item() <= DESC_TOL
     assert (fp - plain['prob'].cpu()).abs().max().item() <= 2e-6 and (fd - plain['desc'].cpu()).abs().max().item() <= 2e-6
+
+
+@pytest.mark.parametrize('upd', [{}, {'multispectral': True}, {'bn_first': True}])
+@pytest.mark.parametrize('B,H,W', [(3, 72, 104), (2, 16, 16), (1, 240, 320), (5, 40, 264), (2, 480, 640)])
+def test_first_block_inside_f43_equals_standalone(oracle, monkeypatch, upd, B, H, W):
+    """The first encoder block evaluated inside the F(4x4,3x3) conv2 kernel (default: per item on the matrix pipe into a
+    per-workgroup scratch the unit loop DMAs from) against the standalone first-block launch (MP_NO_FUSE43=1): the same nine
+    products per output summed in the MFMA's order instead of a multiply-add chain, so the network outputs agree to the last
+    bits of fp32 -- borders (two nested reflections), partial items, two encoders."""
+    cfg = dict(oracle.SHIPPED_MODEL_CONFIG); cfg.update(upd)
+    img = oracle.make_images(31 + W, B, H, W)
+    flags = torch.tensor([[i % 2 == 0] for i in range(B)])
+    net, sd = _net(oracle, cfg, seed=6)
+    a = net({'image': img.cuda(), 'is_optical': flags})
+    monkeypatch.setenv('MP_NO_FUSE43', '1')
+    net2, _ = _net(oracle, cfg, seed=6)
+    b = net2({'image': img.cuda(), 'is_optical': flags})
+    ref = oracle.forward(sd, img, cfg, is_optical=flags)
+    assert (a['prob'].cpu() - ref['prob']).abs().max().item() <= PROB_TOL and (a['desc'].cpu() - ref['desc']).abs().max().item() <= DESC_TOL
+    assert (a['prob'] - b['prob']).abs().max().item() <= 2e-6 and (a['desc'] - b['desc']).abs().max().item() <= 2e-6
 
 
 @pytest.mark.parametrize('upd', [{}, {'multispectral': True}, {'bn_first': True}])

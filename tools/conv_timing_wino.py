@@ -25,10 +25,10 @@ assert (lib.mp_debug_read_timing_wino43 if K43 else lib.mp_debug_read_timing_win
 t = np.frombuffer(buf, dtype=np.uint64).reshape(256, 8).astype(np.float64)
 t = t[(t[:, 7] > 0) & (t[:, 7] < 1e6)]
 n = t[:, 7]
-for i, nm in enumerate(['MFMA steps (all units)', 'unit barriers', 'epilogue', 'unit loop incl. barriers'] + (['s_barrier behind the DMA wait'] if K43 else [])):
+for i, nm in enumerate(['MFMA steps (all units)', 'unit barriers', 'epilogue', 'unit loop incl. barriers'] + (['s_barrier behind the DMA wait', 'fused first block (next item)', '... its staging part'] if K43 else [])):
     v = t[:, i] / n
     print('%-28s mean %8.0f  p10 %8.0f  p90 %8.0f cycles/item' % (nm, v.mean(), np.percentile(v, 10), np.percentile(v, 90)))
-layer = {480: 'enc.conv2', 240: 'enc.conv4', 120: 'enc.conv6', -240: 'enc.conv3', -120: 'enc.conv5', -60: 'heads.conv3x3'}.get(sel)
+layer = {480: 'enc.conv1+2' if ('enc.conv1+2' in prof) else 'enc.conv2', 240: 'enc.conv4', 120: 'enc.conv6', -240: 'enc.conv3', -120: 'enc.conv5', -60: 'heads.conv3x3'}.get(sel)
 nunits = {480: 8, 240: 8, 120: 16, -240: 8, -120: 8, -60: 16}.get(sel, 0)
 print('workgroups %d, items per workgroup %.1f; MFMA per item: %d units x 64 MFMA x 64 = %d cycles' % (len(t), n.mean(), nunits, nunits * 4096))
 if layer in prof:
