@@ -321,7 +321,7 @@ def main():
     roof = None
     wino = os.environ.get('MP_NO_WINOGRAD') != '1' and not c5
     # the library's choice for conv2 (api.hip uses_wino43): F(4x4,3x3) unless switched off, fused, or the frame is no multiple of 4
-    f43 = (wino and os.environ.get('MP_WINO43', '1') != '0' and os.environ.get('MP_WINO_FUSE') != '1'
+    f43 = (wino and os.environ.get('MP_WINO43', '2') != '0' and os.environ.get('MP_WINO_FUSE') != '1'
            and H % 4 == 0 and W % 4 == 0)
     dom = by_name.get('enc.conv1+2') or by_name.get('enc.conv2')
     n_launch = 1
@@ -346,9 +346,14 @@ def main():
                       '+ bias/ReLU/BN + 2x2 max-pool)') if fused else \
                      'conv_mfma_persist_kernel<9,32,true,false> (enc.conv2, direct convolution)'
         elif f43:
-            # Winograd F(4x4,3x3): 36 multiplies per 4x4 output tile and channel pair instead of 144 -> 4x fewer MFMA FLOPs
-            issued = flop / 4.0
-            kernel = ('conv_wino43_kernel<true,false,8> (enc.conv2 64->64 @480x640 by Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32, '
+            # Winograd F(4x4,3x3): 36 multiplies per 4x4 output tile and channel pair instead of 144 -> 4x fewer MFMA FLOPs.
+            # Fused first block: 468 v_mfma_f32_16x16x4_f32 (2048 FLOP each, K = 9 padded to 12) per item of 16 x 32 pixels
+            items = 2 * P * ((H + 15) // 16) * ((W + 31) // 32)
+            issued = (conv2_flop / 4.0 + items * 468 * 2048.0) if fused else flop / 4.0
+            kernel = ('conv_wino43_kernel<true,false,8,true> (encoder conv1 -- Cin = 1, evaluated per item on the matrix pipe and parked '
+                      'in an L2-resident scratch -- fused into enc.conv2 64->64 @480x640 by Winograd F(4x4,3x3) on '
+                      'v_mfma_f32_16x16x4_f32, weights and input patches staged by LDS-DMA, + bias/ReLU/BN + 2x2 max-pool)') if fused else \
+                     ('conv_wino43_kernel<true,false,8,false> (enc.conv2 64->64 @480x640 by Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32, '
                       'weights and channel-quad-planar input patches staged by LDS-DMA, + bias/ReLU/BN + 2x2 max-pool)')
         else:
             issued = (conv2_flop if fused else flop) / 2.25
@@ -366,7 +371,7 @@ def main():
                 'algorithmic_tflops': round(alg, 2),
                 'algorithmic_speedup_vs_direct_roofline': round(alg / peak, 4),
                 # the MFMA utilisation the F(2x2,3x3) kernel (2.25x fewer FLOPs than direct) would need for this launch time
-                'f22_equivalent_frac': round(alg / 2.25 / peak, 4) if f43 else None,
+                'f22_equivalent_frac': round((conv2_flop if fused else flop) / (ms * 1e-3) / 1e12 / 2.25 / peak, 4) if f43 else None,
                 'note': 'achieved/frac = MFMA FLOPs issued by the launch / hipEvent time on the launch stream inside the timed '
                         'region / dense MFMA peak (matrix-pipe utilisation; agrees with SQ_VALU_MFMA_BUSY_CYCLES in profiles/).  '
                         'algorithmic_* use the direct-convolution FLOP count 2*9*Cin*Cout per output pixel'

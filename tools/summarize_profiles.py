@@ -105,8 +105,8 @@ def summarize(prefix, suffix, dominant, nper, bench_cmd, layers_cmd):
     print(open(path).read())
 
 
-# the pooled layers enc.conv2, conv4 and conv6 run this instantiation: three launches per forward (conv2 is the dominant one)
-summarize('', '', 'conv_wino43_kernel<true, false, 8>', 3,
+# enc.conv1+2 (the first block fused into the pooled 64 -> 64 layer) is the only launch of this instantiation
+summarize('', '', 'conv_wino43_kernel<true, false, 8, true>', 1,
           'python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline', 'python3 tools/bench_layers.py 64')
 summarize('c5_', '_c5', 'conv_f16_kernel<9, 32, true, false>', 3,
           'python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --workload c5', 'python3 tools/bench_layers.py 16 1024 1280 f16')
