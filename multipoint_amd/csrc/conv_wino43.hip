@@ -373,15 +373,25 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
 #ifdef MP_TIMING
     unsigned long long c1_t1 = 0;
 #endif
+    // the image patch of an item, 720 pixels = 2 per thread: loaded into registers one epilogue ahead of the phase that stages
+    // them (they are first-touch HBM misses: 2-4 k cycles nothing else of the phase could hide)
+    float c1_px0 = 0.f, c1_px1 = 0.f;
+    auto conv1_load = [&](const Where& w) __attribute__((always_inline)) {
+        constexpr int IW = PX + 2, IH = PY + 2;
+        const float* const im = p.img + (long long)w.img * p.H * p.W;
+        { const int r = tid / IW, c = tid - r * IW;
+          c1_px0 = im[reflect_clamp_q(w.y0 + r - 2, p.H) * p.W + reflect_clamp_q(w.x0 + c - 2, p.W)]; }
+        if (tid + 512 < IH * IW) {
+            const int f = tid + 512, r = f / IW, c = f - r * IW;
+            c1_px1 = im[reflect_clamp_q(w.y0 + r - 2, p.H) * p.W + reflect_clamp_q(w.x0 + c - 2, p.W)];
+        }
+    };
     auto conv1_item = [&](const Where& w, int par) __attribute__((always_inline)) {
         constexpr int IW = PX + 2, IH = PY + 2;
         float* const ip = scr;                                    // the transform scratch is idle between two unit loops:
         float* const wl = scr + 768;                              // image patch (720 floats + a zero) + bias, scale, shift [3][64]
-        const float* const im = p.img + (long long)w.img * p.H * p.W;
-        for (int f = tid; f < IH * IW; f += 512) {
-            const int r = f / IW, c = f - r * IW;
-            ip[f] = im[reflect_clamp_q(w.y0 + r - 2, p.H) * p.W + reflect_clamp_q(w.x0 + c - 2, p.W)];
-        }
+        ip[tid] = c1_px0;
+        if (tid + 512 < IH * IW) ip[tid + 512] = c1_px1;
         if (tid == 0) ip[IH * IW] = 0.f;                          // what the padding taps 9..11 read
         if (tid < 192) wl[tid] = tid < 64 ? p.b1[tid] : tid < 128 ? p.s1[tid - 64] : p.t1[tid - 128];
         // A operand: weights of tap k = 4j + lane/16 (0 beyond tap 8), channel 16 * block + lane % 16
@@ -439,7 +449,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     if (F1) {
         for (int f = tid; f < 9 * 64; f += 512) w1s[f] = p.w1[f];
         __syncthreads();
+        conv1_load(cur);
         conv1_item(cur, 0);
+        if (item + stride < item_end) conv1_load(decode(item + stride));
         dma_wait();                                               // (vmcnt counts the stores too)
         __syncthreads();                                          // scratch[0] is visible to every wave's DMA
     }
@@ -607,6 +619,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
 
         MPQ_T(t_e0);
         MPQ_ADD(3, t_item, t_e0);                                      // whole unit loop of the item
+        // F1: the image patch of item k+2 (the phase at the top of the next item stages it) -- in flight across the epilogue
+        if (F1 && item_next + stride < item_end) conv1_load(decode(item_next + stride));
         // ---- output transform Y = A^T M A in registers, bias / ReLU / BN, [2x2 max-pool], store ----
         // lane = tile (lane & 15) of the wave's tile block, registers r = output channels 4 * (lane >> 4) + r of its channel block
         if (MPQX & 8) {
