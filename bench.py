@@ -371,6 +371,10 @@ def main():
                 'algorithmic_tflops': round(alg, 2),
                 'algorithmic_speedup_vs_direct_roofline': round(alg / peak, 4),
                 # the MFMA utilisation the F(2x2,3x3) kernel (2.25x fewer FLOPs than direct) would need for this launch time
+                # the fused launch parks the first block's 64-channel output in a per-workgroup scratch and DMAs it back (6 GB each
+                # way at the L2 boundary): the same bytes the two separate launches moved (5.3 + 7.6 GB), now inside one launch
+                'traffic_note': ('L2-boundary bytes incl. the round trip of the fused first block\'s output through the per-workgroup '
+                                 'scratch (the un-fused pair of launches moved 5.3 + 7.6 GB)') if (f43 and fused) else None,
                 'f22_equivalent_frac': round((conv2_flop if fused else flop) / (ms * 1e-3) / 1e12 / 2.25 / peak, 4) if f43 else None,
                 'note': 'achieved/frac = MFMA FLOPs issued by the launch / hipEvent time on the launch stream inside the timed '
                         'region / dense MFMA peak (matrix-pipe utilisation; agrees with SQ_VALU_MFMA_BUSY_CYCLES in profiles/).  '
