@@ -289,7 +289,11 @@ def test_bench_self_launches_ranks():
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0'],
                        capture_output=True, text=True, env=env, timeout=300)
     assert r.returncode != 0
-    assert (r.stdout + r.stderr).count('bench.py needs an MI355X') == 2
+    out = r.stdout + r.stderr
+    # every rank that got as far as its device check says so (torchrun tears the job down at the FIRST failing rank, so the second
+    # message is not guaranteed), and the failure is reported by the torchrun child job, not by a launcher-side check
+    assert 1 <= out.count('bench.py needs an MI355X') <= 2
+    assert 'torch.distributed.elastic' in out or 'ChildFailedError' in out
     env.update(WORLD_SIZE='2', RANK='0', LOCAL_RANK='0')
     r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '4'], capture_output=True, text=True,
                        env=env, timeout=300)
