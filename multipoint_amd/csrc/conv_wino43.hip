@@ -61,6 +61,7 @@ namespace {
 // an item's 32 tiles are 4 rows x 8 columns (16 x 32 output pixels, raw patch 18 x 34) or -- TC4 = 4 -- 8 rows x 4 columns (32 x 16
 // pixels, patch 34 x 18): launch_q picks the shape with fewer phantom tiles (60 x 80 layers: 8 instead of 12 items per image)
 constexpr int NPIX = 18 * 34;                      // 612 patch pixels = 16-byte granules (4 channels each), either shape
+constexpr int NPIXP = 624;                         // ... rounded up to blocks of 16: the plane stride of the fused first block's scratch
 constexpr int UC4 = 4;                             // input channels per unit
 constexpr int VB4 = UC4 * 32 * 36;                 // floats per V buffer  [ch][tile][pos]   (18 KiB)
 constexpr int UB4 = UC4 * 64 * 36;                 // floats per U buffer  [ch][cout][pos]   (36 KiB)
@@ -194,11 +195,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
 
     // ---- raw patch staging by DMA: granule f = block * 64 + lane = patch pixel f; this wave issues blocks wave, wave + 8 ----
     const int pix_stride = p.in_planar ? 4 : p.in_cstride;              // floats between horizontally adjacent pixels
-    const long long unit_stride = F1 ? NPIX * 4 : p.in_planar ? (long long)p.H * p.W * 4 : UC4;     // floats between consecutive units
+    const long long unit_stride = F1 ? NPIXP * 4 : p.in_planar ? (long long)p.H * p.W * 4 : UC4;     // floats between consecutive units
     unsigned rvoff[2];            // byte offset of the granule's source pixel (channel 0 of the unit)
     bool roff_rel = false;        // rvoff holds the item-invariant offsets of interior items
     int ld_par = 0;                   // F1: scratch buffer (item parity) of the cursor's item
-    float* const sbase = F1 ? p.scratch + (long long)blockIdx.x * (2 * 16 * NPIX * 4) : nullptr;
+    float* const sbase = F1 ? p.scratch + (long long)blockIdx.x * (2 * 16 * NPIXP * 4) : nullptr;
     auto raw_offsets = [&](const Where& w) __attribute__((always_inline)) -> const float* {
         if (F1) {                     // patch order in the scratch: granule f at byte 16 f of the unit's plane
 #pragma unroll
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                 const int f = (wave + 8 * j) * 64 + lane;
                 rvoff[j] = (f < NPIX) ? (unsigned)f * 16u : 0u;
             }
-            return sbase + ld_par * (16 * NPIX * 4);
+            return sbase + ld_par * (16 * NPIXP * 4);
         }
         const bool interior = (w.y0 >= 1) && (w.y0 + OY < p.H) && (w.x0 >= 1) && (w.x0 + OX < p.W);
         if (interior) {
@@ -408,16 +409,21 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
 #ifdef MP_TIMING
         c1_t1 = __builtin_amdgcn_s_memtime();
 #endif
-        float* const S = sbase + par * (16 * NPIX * 4);
+        float* const S = sbase + par * (16 * NPIXP * 4);
         // (one block at a time: the GEMM loop's state stays in registers across this phase, there is room for little else)
+        const bool inner = (w.y0 >= 1) && (w.y0 + OY < p.H) && (w.x0 >= 1) && (w.x0 + OX < p.W);     // no reflection anywhere in the patch
+        char* const Sb = reinterpret_cast<char*>(S);
 #pragma unroll 1
-        for (int blk = wave; blk < (NPIX + 15) / 16; blk += 8) {
+        for (int blk = wave; blk < NPIXP / 16; blk += 8) {
             const int f = blk * 16 + c1_lp;
             const int fc = f < NPIX ? f : NPIX - 1;
             const int py = fc / PX, px = fc - py * PX;
-            int ly = reflect_clamp_q(w.y0 + py - 1, p.H) - w.y0 + 1, lx = reflect_clamp_q(w.x0 + px - 1, p.W) - w.x0 + 1;
-            ly = min(max(ly, 0), IH - 3); lx = min(max(lx, 0), IW - 3);          // (only pixels of phantom outputs are clamped)
-            const int o = ly * IW + lx;
+            int o = py * IW + px;
+            if (!inner) {
+                int ly = reflect_clamp_q(w.y0 + py - 1, p.H) - w.y0 + 1, lx = reflect_clamp_q(w.x0 + px - 1, p.W) - w.x0 + 1;
+                ly = min(max(ly, 0), IH - 3); lx = min(max(lx, 0), IW - 3);      // (only pixels of phantom outputs are clamped)
+                o = ly * IW + lx;
+            }
             float xb[3];
 #pragma unroll
             for (int j = 0; j < 3; ++j) xb[j] = ip[toff[j] >= 0 ? o + toff[j] : IH * IW];
@@ -432,13 +438,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                 const f32x4 t4 = *reinterpret_cast<const f32x4*>(wl + 128 + 4 * q);
                 f32x4 v;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float a = d[e] + b4[e];
-                    if (BNF) a = fmaxf(a * s4[e] + t4[e], 0.f);
-                    else a = fmaxf(a, 0.f) * s4[e] + t4[e];
-                    v[e] = a;
+                for (int h2 = 0; h2 < 2; ++h2) {                   // channel pairs: packed add / multiply-add
+                    f32x2 a = f32x2{d[2 * h2], d[2 * h2 + 1]} + f32x2{b4[2 * h2], b4[2 * h2 + 1]};
+                    const f32x2 sc = {s4[2 * h2], s4[2 * h2 + 1]}, sh = {t4[2 * h2], t4[2 * h2 + 1]};
+                    if (BNF) { a = __builtin_elementwise_fma(a, sc, sh); a = f32x2{fmaxf(a[0], 0.f), fmaxf(a[1], 0.f)}; }
+                    else { a = f32x2{fmaxf(a[0], 0.f), fmaxf(a[1], 0.f)}; a = __builtin_elementwise_fma(a, sc, sh); }
+                    v[2 * h2] = a[0]; v[2 * h2 + 1] = a[1];
                 }
-                if (f < NPIX) *reinterpret_cast<f32x4*>(S + ((long long)q * NPIX + f) * 4) = v;
+                // (planes are padded to whole blocks: no bounds test; 32-bit offset from the uniform scratch base)
+                *reinterpret_cast<f32x4*>(Sb + (unsigned)(q * NPIXP + f) * 16u) = v;
             }
         }
         __syncthreads();                                          // image patch and parameters are dead: the scratch is the transform's again
@@ -772,7 +780,7 @@ bool conv_wino43_supports(const ConvParams& p)
 // p.wpack must point at the F(4x4,3x3) weights packed by pack_wino43_weights() (api.hip).  fuse_first: the input is the
 // first encoder block of p.img (p.w1 / b1 / s1 / t1, 64 channels), evaluated inside the kernel; p.scratch holds
 // conv_wino43_scratch_floats() floats; the layer must be the pooled 64 -> 64 one (enc.conv2)
-size_t conv_wino43_scratch_floats() { return (size_t)256 * 2 * 16 * NPIX * 4; }
+size_t conv_wino43_scratch_floats() { return (size_t)256 * 2 * 16 * NPIXP * 4; }
 int launch_conv_wino43(const ConvParams& p, bool pool, hipStream_t s, bool fuse_first)
 {
     if (fuse_first) return pool && p.cin == 64 ? launch_q<true, 8, true>(p, s) : 1;
