@@ -52,6 +52,11 @@ def check_dma_hazards(asm_path, wait_states=5):
         while j >= 0 and ws < wait_states:
             t = lines[j].strip()
             j -= 1
+            if t.endswith(':') and not t.startswith(('.Lfunc', ';')) and re.match(r'\.LBB\d+_\d+:', t):
+                # a branch target: predecessors other than the fall-through are not visible to this linear walk, so the
+                # wait states in front of the DMA must all lie INSIDE its own block
+                raise RuntimeError('%s:%d: LDS-DMA only %d wait states behind the branch target %s (needs %d inside the '
+                                   'block): open the asm statement with s_nop' % (asm_path, j + 2, ws, t, wait_states))
             if not t or t.startswith((';', '.')) or t.endswith(':'):
                 continue
             w = re.match(r'(v_readlane_b32|v_readfirstlane_b32) s(\d+),', t)
@@ -66,17 +71,24 @@ def check_dma_hazards(asm_path, wait_states=5):
 
 
 def _compile(src):
-    obj = os.path.join(OBJ_DIR, os.path.splitext(src)[0] + '.o')
+    """Compile one source.  The object only appears under its final name (which `_stale` looks at) AFTER the LDS-DMA hazard
+    check has passed: a failed check must not leave a fresh-looking object behind for the next build to link."""
+    stem = os.path.splitext(src)[0]
+    obj = os.path.join(OBJ_DIR, stem + '.o')
+    tmp_stem = stem + '.tmp%d' % os.getpid()
+    tmp = os.path.join(OBJ_DIR, tmp_stem + '.o')
     extra = ['-save-temps=obj'] if src in DMA_SOURCES else []
-    cmd = [HIPCC] + FLAGS + extra + ['-c', os.path.join(CSRC, src), '-o', obj]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, ' '.join(cmd), r.stderr))
-    if src in DMA_SOURCES:
-        stem = os.path.splitext(src)[0]
-        check_dma_hazards(os.path.join(OBJ_DIR, stem + '-hip-amdgcn-amd-amdhsa-gfx950.s'))
-        for f in os.listdir(OBJ_DIR):                      # -save-temps leftovers (19 MB): only the object is kept
-            if f.startswith(stem + '-') or f.startswith(stem + '.hip-'):
+    cmd = [HIPCC] + FLAGS + extra + ['-c', os.path.join(CSRC, src), '-o', tmp]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, ' '.join(cmd), r.stderr))
+        if src in DMA_SOURCES:
+            check_dma_hazards(os.path.join(OBJ_DIR, stem + '-hip-amdgcn-amd-amdhsa-gfx950.s'))   # named after the source
+        os.replace(tmp, obj)
+    finally:
+        for f in os.listdir(OBJ_DIR):                      # the temporary object and the -save-temps leftovers (19 MB)
+            if f.startswith(tmp_stem) or f.startswith(stem + '-') or f.startswith(stem + '.hip-'):
                 os.remove(os.path.join(OBJ_DIR, f))
     return obj
 

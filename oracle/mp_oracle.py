@@ -243,7 +243,7 @@ def forward(sd, image, cfg=None, is_optical=None, return_logits=False):
             # MultiPoint.py:107-122: route each image through encoder_optical / encoder_thermal
             B, _, H, W = image.shape
             ch, _ = _channels(cfg)
-            x = torch.zeros((B, ch[4], H // 8, W // 8), dtype=torch.float32)
+            x = torch.zeros((B, ch[4], H // 8, W // 8), dtype=image.dtype)
             opt = is_optical[:, 0].bool()
             if opt.sum() > 0:
                 x[opt] = encoder(image[opt], sd, cfg, 'encoder_optical')

@@ -177,3 +177,32 @@ def test_f16_error_distribution_is_unbiased_noise(oracle, f16):
     print('[f16 prob > 0.015, relative] %s' % pstats)
     assert pstats['median_abs_rel'] <= 1e-2 and pstats['p999_abs_rel'] <= 5e-2, pstats     # observed 4.9e-3 / 2.3e-2
     assert abs(pstats['mean_signed_rel']) <= 0.05 * pstats['mean_abs_rel'], pstats          # observed 3e-3 of it
+
+
+@pytest.mark.parametrize('c', ['a', 'b'])
+def test_f16_forward_against_reference_autocast_fixture(oracle, golden_dir, f16, c):
+    """The HIP fp16 path against the REFERENCE's own mixed_precision outputs (tests/golden/forward_f16.npz: the imported
+    reference under torch.autocast('cpu', float16), make_golden_f16.py) -- the same distributional bar that pins the oracle
+    to that fixture on the CPU side (tests/test_oracle_golden.py): fp16 steps of the quantity the network rounds."""
+    import os
+    from oracle import f16_stats as S
+    net, sd, cfg = f16
+    z = np.load(os.path.join(golden_dir, 'forward_f16.npz'))
+    assert int(z['weight_seed']) == 0
+    img = oracle.make_images(int(z[c + '_seed']), int(z[c + '_B']), int(z[c + '_H']), int(z[c + '_W']))
+    net.set_force_return_logits(True)
+    try:
+        lg = net({'image': img.cuda()})['logits'].cpu().numpy()
+    finally:
+        net.set_force_return_logits(False)
+    o = net({'image': img.cuda()})
+    out = {'logits': lg, 'prob': o['prob'].cpu().numpy(), 'desc': o['desc'].cpu().numpy()}
+    v, ax = S.fixture_views(z, out, c)
+    ls, ds, ps = S.logits_stats(*v['logits']), S.desc_stats(*v['desc'], channel_axis=ax), S.prob_rel_stats(*v['prob'])
+    print('\n[f16 vs reference fixture %s] logits %s\n desc %s\n prob %s' % (c, ls, ds, ps))
+    assert ls['median'] <= 0.5 and ls['p999'] <= 4.0 and ls['max'] <= 6.0, ls
+    assert ds['median'] <= 0.5 and ds['p999'] <= 4.0 and ds['max'] <= 6.0, ds
+    assert abs(ls['mean_signed']) <= 0.05 * ls['mean_abs'] and abs(ds['mean_signed']) <= 0.05 * ds['mean_abs'], (ls, ds)
+    assert ps['median_abs_rel'] <= 1e-2 and ps['p999_abs_rel'] <= 5e-2, ps
+    assert abs(ps['mean_signed_rel']) <= 0.1 * ps['mean_abs_rel'], ps
+    assert np.abs(v['prob'][0] - v['prob'][1]).max() <= PROB_TOL_F16

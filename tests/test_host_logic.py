@@ -326,3 +326,27 @@ def test_build_checks_dma_hazards(tmp_path):
     none.write_text('\ts_nop 0\n')
     with pytest.raises(RuntimeError, match='no global_load_lds'):
         b.check_dma_hazards(str(none))
+    # a DMA fewer than five wait states behind a branch target: a predecessor block the linear walk cannot see may end in
+    # the hazardous write, so the wait states must lie inside the DMA's own block
+    lab = tmp_path / 'label.s'
+    lab.write_text('\tv_readlane_b32 s12, v90, 3\n\ts_cbranch_scc1 .LBB3_7\n' + '\ts_nop 0\n' * 8 + '.LBB3_7:\n\ts_mov_b32 m0, s17\n'
+                   '\tglobal_load_lds_dwordx4 v48, s[12:13]\n')
+    with pytest.raises(RuntimeError, match='branch target'):
+        b.check_dma_hazards(str(lab))
+    lab.write_text('.LBB3_7:\n\ts_mov_b32 m0, s17\n\ts_nop 3\n\tglobal_load_lds_dwordx4 v48, s[12:13]\n')
+    assert b.check_dma_hazards(str(lab)) == 1
+
+
+def test_failed_hazard_check_leaves_no_object(tmp_path, monkeypatch):
+    """A source whose generated code fails the LDS-DMA hazard check must not leave `<stem>.o` behind: the next build would
+    see it as fresh, skip compile + check and link the hazardous object (round-2 advisor finding)."""
+    from multipoint_amd import build as b
+    monkeypatch.setattr(b, 'OBJ_DIR', str(tmp_path))
+    monkeypatch.setattr(b, 'CSRC', str(tmp_path))
+    monkeypatch.setattr(b, 'DMA_SOURCES', ('k.hip',))
+    (tmp_path / 'k.hip').write_text('#include <hip/hip_runtime.h>\n__global__ void k(float* p) { p[threadIdx.x] = 1.0f; }\n')
+    with pytest.raises(RuntimeError, match='no global_load_lds'):         # the check fails (no DMA in this file at all)
+        b._compile('k.hip')
+    assert [f for f in os.listdir(tmp_path) if f != 'k.hip'] == []        # no object, no -save-temps leftovers
+    monkeypatch.setattr(b, 'DMA_SOURCES', ())
+    assert os.path.exists(b._compile('k.hip'))

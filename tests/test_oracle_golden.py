@@ -161,3 +161,51 @@ def test_dataset_augmentation_golden(golden_dir):
         assert np.array_equal(g['single_%d_image' % i][0], img) and np.array_equal(g['single_%d_valid_mask' % i][0], mask.astype(bool))
         km = np.zeros((48, 64), bool); km[pts[:, 0], pts[:, 1]] = True
         assert np.array_equal(g['single_%d_keypoints' % i], km)
+
+
+# ------------------------------------------------------------------ fp16 (mixed_precision) oracle pinned to the reference
+def _f16_case(oracle, z, c):
+    cfg = dict(oracle.SHIPPED_MODEL_CONFIG); cfg['mixed_precision'] = True
+    sd = oracle.make_weights(int(z['weight_seed']), cfg)
+    img = oracle.make_images(int(z[c + '_seed']), int(z[c + '_B']), int(z[c + '_H']), int(z[c + '_W']))
+    return cfg, sd, img
+
+
+@pytest.mark.parametrize('c', ['a', 'b'])
+def test_f16_oracle_against_reference_autocast_fixture(oracle, golden_dir, c):
+    """tests/golden/forward_f16.npz = the imported reference with `mixed_precision: true`, run under
+    torch.autocast('cpu', float16) in place of torch.cuda.amp.autocast (make_golden_f16.py; MultiPoint.py:99-104).  Two
+    correct fp16 evaluations agree only to rounding flips that compound through 12 layers, so the oracle's restatement of
+    autocast's rounding points (mp_oracle._block/_head) is pinned DISTRIBUTIONALLY, in fp16 steps of the quantity the
+    network rounds: most elements within a step, a tail of a few steps, no bias.  Observed: logits median 0.25 / p99.9
+    2.0-2.5 / max 3 steps, descriptors 0.27 / 1.9-2.0 / 2.4, prob above threshold median rel 3.6e-3-5.9e-3, p99.9 2.3e-2."""
+    from oracle import f16_stats as S
+    z = np.load(os.path.join(golden_dir, 'forward_f16.npz'))
+    cfg, sd, img = _f16_case(oracle, z, c)
+    out = oracle.forward(sd, img, cfg)
+    out['logits'] = oracle.forward(sd, img, cfg, return_logits=True)['logits']
+    out = {k: v.numpy() for k, v in out.items() if v is not None}
+    v, ax = S.fixture_views(z, out, c)
+    ls, ds, ps = S.logits_stats(*v['logits']), S.desc_stats(*v['desc'], channel_axis=ax), S.prob_rel_stats(*v['prob'])
+    assert ls['median'] <= 0.5 and ls['p999'] <= 4.0 and ls['max'] <= 6.0, ls
+    assert ds['median'] <= 0.5 and ds['p999'] <= 4.0 and ds['max'] <= 6.0, ds
+    assert abs(ls['mean_signed']) <= 0.05 * ls['mean_abs'] and abs(ds['mean_signed']) <= 0.05 * ds['mean_abs'], (ls, ds)
+    assert ps['median_abs_rel'] <= 1e-2 and ps['p999_abs_rel'] <= 5e-2, ps
+    assert abs(ps['mean_signed_rel']) <= 0.1 * ps['mean_abs_rel'], ps
+    if c == 'b':
+        n = int((out['prob'] > 0.015).sum())
+        assert abs(n - int(z['b_n_above_thr'])) <= 0.01 * int(z['b_n_above_thr'])
+
+
+def test_f16_fixture_records_autocast_rounding_points(golden_dir):
+    """The dtype every leaf module of the reference returned under autocast is part of the fixture: the rounding points the
+    oracle restates (Conv2d -> fp16, BatchNorm2d -> fp16, pooling / ReLU on fp16) are the reference's, not an assumption."""
+    import json
+    z = np.load(os.path.join(golden_dir, 'forward_f16.npz'))
+    dt = json.loads(str(z['dtypes']))
+    kinds = {}
+    for name, (kind, dtype) in dt.items():
+        kinds.setdefault(kind, set()).add(dtype)
+    assert kinds['Conv2d'] == {'torch.float16'} and kinds['BatchNorm2d'] == {'torch.float16'}
+    assert kinds['ReLU'] == {'torch.float16'} and kinds['MaxPool2d'] == {'torch.float16'}
+    assert kinds['Softmax2d'] == {'torch.float32'}
