@@ -8,7 +8,7 @@
 
 One "step" = one pass of the full hot path (detect + describe + match) over one batch of synthetic
 pairs already resident in HBM:  BASELINE.json configs[2] -- 32 pairs (64 grayscale 480x640 images) per
-GPU: encoder + detector/descriptor heads (fp32; 3x3 layers as Winograd F(2x2,3x3) GEMMs on the fp32 MFMA) -> box-NMS (size 4, iou 0.1, thr 0.015) -> top-k 1000
+GPU: encoder + detector/descriptor heads (fp32; 3x3 layers as Winograd F(4x4,3x3) GEMMs on the fp32 MFMA) -> box-NMS (size 4, iou 0.1, thr 0.015) -> top-k 1000
 -> bilinear descriptor sampling + L2 norm -> mutual-NN match.  Pairs shard independently over ranks
 (weak scaling, no data-path collective); RCCL only gathers the per-pair metric records.
 
@@ -51,16 +51,21 @@ def conv_flops_per_image(h, w):
     return sum(2.0 * k * k * ci * co * (h // s) * (w // s) for ci, co, k, s in layers)
 
 
-def pmc_traffic(workload='c3'):
+def pmc_traffic(workload, instantiation):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (profiles/rNN_pmc_hbm_traffic
     [_c5].json of the newest round: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate passes of this same bench
-    command); None if no such file exists.  PMC counters cannot be collected from inside the timed run."""
+    command).  None if no such file exists OR if the committed counters belong to another kernel instantiation than the one
+    this run timed (an A/B variant selected by environment switches has no committed PMC pass): a traffic figure is only
+    reported next to the kernel it was measured on.  PMC counters cannot be collected from inside the timed run."""
     import glob
     suffix = '_c5' if workload == 'c5' else ''
     for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_hbm_traffic%s.json' % suffix)), reverse=True):
         try:
             with open(path) as f:
-                return float(json.load(f)['dominant_kernel_mean_traffic_bytes_per_launch'])
+                rec = json.load(f)
+            if rec.get('dominant_kernel', '').replace(' ', '') != instantiation.replace(' ', ''):
+                return None
+            return float(rec['dominant_kernel_mean_traffic_bytes_per_launch'])
         except (OSError, KeyError, ValueError):
             continue
     return None
@@ -141,8 +146,10 @@ def cpu_baseline(sd, cfg, n_pairs=16, H=H, W=W, PRED_CFG=PRED_CFG):
                              'keypoints+descriptor_sampling': round(t3 - t2, 3), 'mutual_nn_match': round(t4 - t3, 3)},
            'thread_probe_seconds_per_pair_forward': {str(k): round(v, 3) for k, v in probe.items()},
            'sample': '%d pairs %dx%d, full path (oracle: ATen-CPU forward%s, C greedy NMS, numpy sampling + NNMatcher), '
-                     '%.1f s on %d torch threads' % (n_pairs, H, W, ' with the fp16 rounding points of autocast emulated '
-                                                     'in fp32 arithmetic' if cfg.get('mixed_precision') else '', dt, threads)}
+                     '%.1f s on %d torch threads; %.0f %% of it is the box-NMS stage (the reference batches all images of a '
+                     'spectrum into ONE O(kept x candidates) torchvision call, utils.py:99-103), %.0f %% the forward'
+                     % (n_pairs, H, W, ' with the fp16 rounding points of autocast emulated in fp32 arithmetic'
+                        if cfg.get('mixed_precision') else '', dt, threads, 100 * (t2 - t1) / dt, 100 * (t1 - t0) / dt)}
     return rec, res, prob, desc
 
 
@@ -329,7 +336,7 @@ def main():
         # `frac` is a HARDWARE fraction: the FLOPs the launch actually issues on the matrix pipe / its hipEvent time / the
         # dense MFMA peak of the dtype.  For the direct and fp16 kernels issued == algorithmic (2*9*Cin*Cout per output
         # pixel); the Winograd kernel issues 2.25x fewer MFMA FLOPs than the direct algorithm for the same fp32 result, so
-        # its algorithmic rate is reported next to it as `algorithmic_speedup_vs_direct_roofline` (may exceed 1).
+        # its algorithmic rate is reported next to it as `frac_algorithmic` (may exceed 1).
         n_launch = max(1, int(round(len(dom) / float(args.steps))))
         ms = float(np.sum([m for m, _ in dom])) / args.steps / n_launch
         flop = float(np.sum([f for _, f in dom])) / args.steps / n_launch       # algorithmic FLOPs of the launch
@@ -338,10 +345,12 @@ def main():
         peak = PEAK_FP16_MFMA_TFLOPS if c5 else PEAK_FP32_MFMA_TFLOPS
         if c5:
             issued = flop
+            inst = 'conv_f16_kernel<9,32,true,false>'
             kernel = ('conv_f16_kernel<9,32,true,false> (enc.conv2 64->64 @1024x1280 on v_mfma_f32_32x32x16_f16 + bias/ReLU/BN '
                       '+ 2x2 max-pool)')
         elif not wino:
             issued = conv2_flop if fused else flop              # the fused first block (Cin = 1) runs on the vector ALU
+            inst = 'conv_mfma_kernel<9,32,true,true,false>' if fused else 'conv_mfma_persist_kernel<9,32,true,false>'
             kernel = ('conv_mfma_kernel<9,32,true,true,false> (encoder conv1 fused into conv2 64->64 @480x640, direct convolution '
                       '+ bias/ReLU/BN + 2x2 max-pool)') if fused else \
                      'conv_mfma_persist_kernel<9,32,true,false> (enc.conv2, direct convolution)'
@@ -350,6 +359,7 @@ def main():
             # Fused first block: 468 v_mfma_f32_16x16x4_f32 (2048 FLOP each, K = 9 padded to 12) per item of 16 x 32 pixels
             items = 2 * P * ((H + 15) // 16) * ((W + 31) // 32)
             issued = (conv2_flop / 4.0 + items * 468 * 2048.0) if fused else flop / 4.0
+            inst = 'conv_wino43_kernel<true,false,8,true>' if fused else 'conv_wino43_kernel<true,false,8,false>'
             kernel = ('conv_wino43_kernel<true,false,8,true> (encoder conv1 -- Cin = 1, evaluated per item on the matrix pipe and parked '
                       'in an L2-resident scratch -- fused into enc.conv2 64->64 @480x640 by Winograd F(4x4,3x3) on '
                       'v_mfma_f32_16x16x4_f32, weights and input patches staged by LDS-DMA, + bias/ReLU/BN + 2x2 max-pool)') if fused else \
@@ -357,6 +367,7 @@ def main():
                       'weights and channel-quad-planar input patches staged by LDS-DMA, + bias/ReLU/BN + 2x2 max-pool)')
         else:
             issued = (conv2_flop if fused else flop) / 2.25
+            inst = 'conv_wino_kernel<true,false,true,false,8>' if fused else 'conv_wino_kernel<true,false,false,false,8>'
             kernel = ('conv_wino_kernel<true,false,true,false,8> (encoder conv1 -- Cin = 1, computed on the vector pipe inside the loader '
                       '-- fused into enc.conv2 64->64 @480x640 by Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32 + bias/ReLU/BN '
                       '+ 2x2 max-pool)') if fused else \
@@ -364,12 +375,19 @@ def main():
                       'v_mfma_f32_32x32x2_f32, operands staged by LDS-DMA, + bias/ReLU/BN + 2x2 max-pool)')
         ach = issued / (ms * 1e-3) / 1e12
         alg = flop / (ms * 1e-3) / 1e12
+        traffic = pmc_traffic(args.workload, inst)
         roof = {'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                'traffic': pmc_traffic(args.workload) if (wino or c5) else None, 'kernel': kernel,
+                # SURVEY.md 8(d)'s formula next to the hardware fraction: ALGORITHMIC (direct-convolution) FLOPs of the launch /
+                # its time / peak.  Above 1 for the Winograd kernels (they issue 2.25x / 4x fewer MFMA FLOPs for the same fp32
+                # convolution), equal to `frac` for the direct and fp16 kernels.
+                'frac_algorithmic': round(alg / peak, 4),
+                'traffic': traffic,
+                # bytes at the L2 boundary per second of the launch (Infinity Cache hits and HBM are not separable by the counters)
+                'fabric_tb_s': round(traffic / (ms * 1e-3) / 1e12, 3) if traffic else None,
+                'kernel': kernel, 'instantiation': inst,
                 'launches_per_step': n_launch, 'ms_per_launch': round(ms, 4),
                 'mfma_flop_issued_per_launch': issued, 'algorithmic_flop_per_launch': flop,
                 'algorithmic_tflops': round(alg, 2),
-                'algorithmic_speedup_vs_direct_roofline': round(alg / peak, 4),
                 # the MFMA utilisation the F(2x2,3x3) kernel (2.25x fewer FLOPs than direct) would need for this launch time
                 # the fused launch parks the first block's 64-channel output in a per-workgroup scratch and DMAs it back (6 GB each
                 # way at the L2 boundary): the same bytes the two separate launches moved (5.3 + 7.6 GB), now inside one launch
@@ -378,7 +396,7 @@ def main():
                 'f22_equivalent_frac': round((conv2_flop if fused else flop) / (ms * 1e-3) / 1e12 / 2.25 / peak, 4) if f43 else None,
                 'note': 'achieved/frac = MFMA FLOPs issued by the launch / hipEvent time on the launch stream inside the timed '
                         'region / dense MFMA peak (matrix-pipe utilisation; agrees with SQ_VALU_MFMA_BUSY_CYCLES in profiles/).  '
-                        'algorithmic_* use the direct-convolution FLOP count 2*9*Cin*Cout per output pixel'
+                        'frac_algorithmic / algorithmic_* use the direct-convolution FLOP count 2*9*Cin*Cout per output pixel'
                         + (' (conv1 + conv2)' if fused else '') + '; Winograd F(2x2,3x3) issues 2.25x fewer, F(4x4,3x3) 4x fewer.  Timed while '
                         'the previous batch\'s NMS/top-k/sampling/matching kernels run on the side stream.'}
     conv_ms = sum(float(np.sum([m for m, _ in v])) / args.steps for k, v in by_name.items())
@@ -407,7 +425,9 @@ def main():
         'input': 'pinned host memory, uploaded every step on a copy stream (PCIe-inclusive, secondary measurement)'
                  if args.host_input else 'resident in HBM',
         'roofline': roof,
-        'conv_mfma_frac_whole_path': round(value / world * gflop_pair / 1e3 / peak, 4),
+        # whole path, SURVEY.md 8(d): pairs/s x algorithmic conv GFLOP per pair / dense MFMA peak (a speed-up over the
+        # direct-convolution roofline, not a utilisation: > 1 with Winograd layers)
+        'whole_path_algorithmic_vs_direct_mfma_roofline': round(value / world * gflop_pair / 1e3 / peak, 4),
         'forward_tflops': round(conv_flop / (conv_ms * 1e-3) / 1e12, 2) if conv_ms > 0 else None,
         'layer_ms': layers,
     }

@@ -71,6 +71,10 @@ int mp_create(mp_handle** out, int device);
 void mp_destroy(mp_handle* h);
 const char* mp_last_error(const mp_handle* h);      /* h may be NULL: error of the last mp_create */
 const char* mp_version(void);
+/* The machine shape the handle's persistent kernels are sized for, derived from the device in mp_create (compute units;
+ * XCDs = L2 domains the work items are cut into; workgroups of a one-per-CU persistent launch).  No reference counterpart: the
+ * reference leaves scheduling to ATen.  mp_create fails with MP_EINVAL on a shape the kernels cannot be scheduled on. */
+int mp_device_shape(const mp_handle* h, int* compute_units, int* xcds, int* persistent_workgroups);
 
 /* replaces MultiPoint.__init__ + load_state_dict (MultiPoint.py:25-91,
  * predict_align_image_pair.py:57-62): validates the key set strictly, repacks conv weights into

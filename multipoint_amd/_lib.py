@@ -34,6 +34,7 @@ SIGNATURES = {
     'mp_destroy': (None, [c_void_p]),
     'mp_last_error': (ctypes.c_char_p, [c_void_p]),
     'mp_version': (ctypes.c_char_p, []),
+    'mp_device_shape': (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     'mp_load_weights': (c_int, [c_void_p, ctypes.POINTER(ModelConfig), ctypes.POINTER(Tensor), c_int]),
     'mp_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                            c_void_p, c_void_p]),
@@ -141,6 +142,12 @@ class Handle:
 
     def check(self, rc):
         check(rc, self.ptr)
+
+    def device_shape(self):
+        """(compute units, XCDs, workgroups of a one-per-CU persistent launch) the handle derived from the device."""
+        a, b, c = c_int(), c_int(), c_int()
+        self.check(self.lib.mp_device_shape(self.ptr, ctypes.byref(a), ctypes.byref(b), ctypes.byref(c)))
+        return a.value, b.value, c.value
 
     def __del__(self):
         try:

@@ -52,6 +52,7 @@ struct ProfEntry {
 
 struct mp_handle {
     int device = 0;
+    int ncu = 256, xcd_shift = 3;   // machine shape derived in mp_create: compute units, log2(XCDs) (MP_NCU / MP_NXCD override)
     std::string err;
     bool loaded = false;
     mp_model_config cfg{};
@@ -280,15 +281,22 @@ void pack_wino_weights(const std::vector<const float*>& srcs, const std::vector<
                         }
 }
 
-// Winograd F(4x4,3x3) weights for conv_wino43_kernel: U[pos = 6a+b] = (G g G^T)[a][b] with
-// G = [[1/4,0,0],[-1/6,-1/6,-1/6],[-1/6,1/6,-1/6],[1/24,1/12,1/6],[1/24,-1/12,1/6],[0,0,1]], evaluated in double and rounded to
-// fp32 ONCE (1/6 and 1/24 are not binary fractions).  Layout = the LDS image of a unit of 4 input channels:
+// Winograd F(4x4,3x3) weights for conv_wino43_kernel: U[pos = 6i+j] = (G g G^T)[i][j] for the interpolation points
+// {0, +a, -a, +b, -b, inf} (a = MP_W43_A, b = MP_W43_B, mp_common.h): row of point p = [1, p, p^2] / prod_{q != p} (p - q), last
+// row [0, 0, 1]; evaluated in double and rounded to fp32 ONCE.  Layout = the LDS image of a unit of 4 input channels:
 //   [slice64][unit = cin/4][ch(4)][cout(64)][pos(36)]
 void pack_wino43_weights(const std::vector<const float*>& srcs, const std::vector<int>& couts, int cin, int cin_real,
                          std::vector<float>& out)
 {
-    static const double G[6][3] = {{0.25, 0, 0}, {-1.0 / 6, -1.0 / 6, -1.0 / 6}, {-1.0 / 6, 1.0 / 6, -1.0 / 6},
-                                   {1.0 / 24, 1.0 / 12, 1.0 / 6}, {1.0 / 24, -1.0 / 12, 1.0 / 6}, {0, 0, 1}};
+    const double pts[5] = {0.0, MP_W43_A, -MP_W43_A, MP_W43_B, -MP_W43_B};
+    double G[6][3];
+    for (int k = 0; k < 5; ++k) {
+        double n = 1.0;
+        for (int q = 0; q < 5; ++q)
+            if (q != k) n *= pts[k] - pts[q];
+        G[k][0] = 1.0 / n; G[k][1] = pts[k] / n; G[k][2] = pts[k] * pts[k] / n;
+    }
+    G[5][0] = 0.0; G[5][1] = 0.0; G[5][2] = 1.0;
     int cout = 0;
     for (int c : couts) cout += c;
     const int nslices = (cout + 63) / 64, nunits = cin / 4;
@@ -526,6 +534,7 @@ int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, 
     p.bn_first = h->cfg.bn_first;
     p.relu = L.relu ? 1 : 0;
     p.persist = h->persist;
+    p.ncu = h->ncu; p.xcd_shift = h->xcd_shift;
     int mbw = 32;
     if (L.taps == 9) {
         mbw = pick_mbw(H, W);
@@ -542,7 +551,7 @@ int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, 
         p.wpack = L.u43pack; p.in_planar = in_planar; p.out_planar = out_planar;
         if (fuse) {
             int rc;
-            if ((rc = ensure(h, h->fuse43_ws, conv_wino43_scratch_floats() * 4))) return rc;
+            if ((rc = ensure(h, h->fuse43_ws, conv_wino43_scratch_floats(h->ncu) * 4))) return rc;
             p.scratch = static_cast<float*>(h->fuse43_ws.p);
         }
         big = launch_conv_wino43(p, L.pool, s, fuse != nullptr);
@@ -569,6 +578,7 @@ int run_conv_h(mp_handle* h, const ConvLayer& L, const _Float16* in, int in_cstr
     p.pad_zero = h->cfg.reflection_pad ? 0 : 1;
     p.bn_first = h->cfg.bn_first;
     p.dummy = static_cast<_Float16*>(h->dummy);
+    p.ncu = h->ncu; p.xcd_shift = h->xcd_shift;
     int mbw = 32;
     if (L.taps == 9) {
         mbw = pick_mbw(H, W);
@@ -729,11 +739,47 @@ int nms_common(mp_handle* h, const float* prob, const unsigned char* mask, int B
 }  // namespace
 
 // =============================================================================================
+namespace {
+// XCC (= XCD) count of the KFD topology node whose PCI location matches `bus_id` ("dddd:bb:dd.f"); 0 if the topology is not
+// readable (containers without /sys/class/kfd): the caller then falls back to compute units / 32
+int kfd_num_xcc(const char* bus_id)
+{
+    unsigned dom = 0, bus = 0, dev = 0, fn = 0;
+    if (sscanf(bus_id, "%x:%x:%x.%x", &dom, &bus, &dev, &fn) != 4) return 0;
+    const unsigned long long want = ((unsigned long long)bus << 8) | (dev << 3) | fn;
+    for (int node = 0; node < 64; ++node) {
+        char path[128];
+        snprintf(path, sizeof path, "/sys/class/kfd/kfd/topology/nodes/%d/properties", node);
+        FILE* f = fopen(path, "r");
+        if (!f) { if (node > 8) break; else continue; }
+        char key[64]; unsigned long long val = 0, loc = ~0ull, domain = 0, xcc = 0, simd = 0;
+        while (fscanf(f, "%63s %llu", key, &val) == 2) {
+            if (!strcmp(key, "location_id")) loc = val;
+            else if (!strcmp(key, "domain")) domain = val;
+            else if (!strcmp(key, "num_xcc")) xcc = val;
+            else if (!strcmp(key, "simd_count")) simd = val;
+        }
+        fclose(f);
+        if (simd > 0 && loc == want && domain == dom) return (int)xcc;
+    }
+    return 0;
+}
+}  // namespace
+
 extern "C" {
 
 const char* mp_version(void) { return "multipoint_hip 0.1 (gfx950)"; }
 
 const char* mp_last_error(const mp_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int mp_device_shape(const mp_handle* h, int* compute_units, int* xcds, int* persistent_workgroups)
+{
+    if (!h) return MP_EINVAL;
+    if (compute_units) *compute_units = h->ncu;
+    if (xcds) *xcds = 1 << h->xcd_shift;
+    if (persistent_workgroups) *persistent_workgroups = (int)persistent_grid(1ll << 40, h->ncu, h->xcd_shift);
+    return MP_OK;
+}
 
 int mp_create(mp_handle** out, int device)
 {
@@ -751,8 +797,27 @@ int mp_create(mp_handle** out, int device)
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(h, MP_EINVAL, std::string("mp_create: kernels are built for gfx950 only, device is ") +
                                       prop.gcnArchName);
+    // Machine shape: every persistent kernel launches one (fp16: two) workgroup(s) per compute unit and walks, per XCD, a
+    // contiguous share of the work items (workgroup b is dispatched to XCD b mod nxcd; each XCD has its own L2).  Both numbers
+    // come from the device: multiProcessorCount, and the XCC count of the KFD topology node at the device's PCI address
+    // (a partitioned MI355X -- DPX / QPX / CPX -- reports 4 / 2 / 1 XCDs with 128 / 64 / 32 CUs).  MP_NCU / MP_NXCD override
+    // (tests emulate smaller partitions on the full device: fewer workgroups, same results).
+    int ncu = prop.multiProcessorCount, nxcd = 0;
+    {
+        char bus[64] = {0};
+        if (hipDeviceGetPCIBusId(bus, sizeof bus, device) == hipSuccess) nxcd = kfd_num_xcc(bus);
+        if (nxcd <= 0) nxcd = ncu >= 32 ? ncu / 32 : 1;           // gfx950: 32 active CUs per XCD
+        if (const char* e = getenv("MP_NCU")) { const int v = atoi(e); if (v > 0 && v <= ncu) ncu = v; }
+        if (const char* e = getenv("MP_NXCD")) { const int v = atoi(e); if (v > 0) nxcd = v; }
+    }
+    if (ncu < 1 || nxcd < 1 || (nxcd & (nxcd - 1)) != 0 || nxcd > ncu)
+        return fail(h, MP_EINVAL, "mp_create: unsupported machine shape: " + std::to_string(ncu) + " compute units in " +
+                                      std::to_string(nxcd) + " XCDs (the XCD count must be a power of two <= the CU count)");
     mp_handle* hh = new mp_handle();
     hh->device = device;
+    hh->ncu = ncu;
+    hh->xcd_shift = 0;
+    while ((1 << hh->xcd_shift) < nxcd) ++hh->xcd_shift;
     { const char* e = getenv("MP_NO_FUSE"); hh->fuse_first = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_NO_WINOGRAD"); hh->wino = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_WINO_FUSE"); hh->wino_fuse = (e && e[0] == '1'); }
@@ -956,6 +1021,7 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
     if (h->head_fuse) {
         // both 1x1 convolutions + BN + softmax / shuffle + normalisation in ONE launch that reads P once (head_tail.hip)
         HeadTailParams t{};
+        t.ncu = h->ncu;
         t.x = P; t.xstride = headc; t.K = hc;
         t.wdet = h->det1.wpack; t.bdet = h->det1.bias; t.sdet = h->det1.scale; t.tdet = h->det1.shift;
         t.wdesc = h->desc1.wpack; t.bdesc = h->desc1.bias; t.sdesc = h->desc1.scale; t.tdesc = h->desc1.shift;

@@ -114,11 +114,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvParamsH p)
     // ---- persistent workgroup: walks work items (tile, slice) of its XCD's contiguous eighth of the item space,
     //      gridDim.x/8 items apart, and fetches the NEXT item's activation tile while multiplying the current one
     //      (an fp16 tile is only ~4.6 k cycles of MFMA: without the prefetch the HBM latency of every tile is exposed)
-    const int per_xcd = (p.nitems + 7) >> 3;
-    const int stride = gridDim.x >> 3;                     // gridDim.x is a multiple of 8
-    const int xcd = blockIdx.x & 7;
-    const int item_end = min((xcd + 1) * per_xcd, p.nitems);
-    int item = xcd * per_xcd + (blockIdx.x >> 3);
+    const XcdRange xr = xcd_range(p.nitems, p.xcd_shift);
+    const int stride = xr.stride, item_end = xr.item_end;
+    int item = xr.item;
 
     auto udiv = [](unsigned n, unsigned magic, unsigned d) -> unsigned { return d == 1 ? n : __umulhi(n, magic); };
     struct Where { int slice, img, y0, x0; long long px0; const _Float16* in_base; };
@@ -497,8 +495,8 @@ int launch_h(const ConvParamsH& p, hipStream_t s)
     const long long dmax = std::max(std::max(p.nslices, p.tiles_x), p.tiles_y);
     if (nitems * dmax >= 0x100000000ll) return 1;      // beyond the 32-bit tile decode: reported as MP_EINVAL
     q.nitems = (int)nitems;
-    // persistent workgroups: two per CU (256 CUs), a multiple of the 8 XCDs
-    const long long nblk = std::min<long long>(512, ((nitems + 7) / 8) * 8);
+    // persistent workgroups: two per CU, a multiple of the XCD count
+    const long long nblk = persistent_grid(nitems, p.ncu, p.xcd_shift, 2);
     const ConvParamsH& pp = q;
     if (p.bn_first)
         hipLaunchKernelGGL((conv_f16_kernel<TAPS, MBW, POOL, true>), dim3((unsigned)nblk), dim3(256), 0, s, pp);

@@ -128,8 +128,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     //      consecutive logical ids (neighbouring tiles, same slice set) share one XCD's L2 ----
     int logical;
     {
-        const int nblk = gridDim.x, bid = blockIdx.x;
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, pos = bid >> 3;
+        const int nblk = gridDim.x, bid = blockIdx.x, nx = 1 << p.xcd_shift;
+        const int q = nblk >> p.xcd_shift, r = nblk & (nx - 1), xcd = bid & (nx - 1), pos = bid >> p.xcd_shift;
         logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + pos;
     }
     // exact division by multiply-high with host-computed magic numbers: stays on the scalar unit (a
@@ -523,11 +523,9 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_persist_kernel(const ConvPar
     const int half = lane >> 5;
     const int li = lane & 31;
 
-    const int per_xcd = (p.nitems + 7) >> 3;
-    const int stride = gridDim.x >> 3;                     // gridDim.x is a multiple of 8
-    const int xcd = blockIdx.x & 7;
-    const int item_end = min((xcd + 1) * per_xcd, p.nitems);
-    int item = xcd * per_xcd + (blockIdx.x >> 3);
+    const XcdRange xr = xcd_range(p.nitems, p.xcd_shift);
+    const int stride = xr.stride, item_end = xr.item_end;
+    int item = xr.item;
 
     auto udiv = [](unsigned n, unsigned magic, unsigned d) -> unsigned { return d == 1 ? n : __umulhi(n, magic); };
     struct Where { int slice, img, y0, x0; long long px0; const float* in_base; };
@@ -898,11 +896,12 @@ int launch_t(const ConvParams& p, hipStream_t s)
         if constexpr (TAPS == 9) {
             // persistent workgroups, ONE per CU, when every workgroup gets enough items (p.persist, default 8) for the
             // tail not to matter
-            if (p.persist && nblk >= 256ll * p.persist) {
+            if (p.persist && nblk >= (long long)p.ncu * p.persist) {
+                const unsigned grid = persistent_grid(nblk, p.ncu, p.xcd_shift);
                 if (p.bn_first)
-                    hipLaunchKernelGGL((conv_mfma_persist_kernel<TAPS, MBW, POOL, true>), dim3(256), dim3(256), 0, s, pp);
+                    hipLaunchKernelGGL((conv_mfma_persist_kernel<TAPS, MBW, POOL, true>), dim3(grid), dim3(256), 0, s, pp);
                 else
-                    hipLaunchKernelGGL((conv_mfma_persist_kernel<TAPS, MBW, POOL, false>), dim3(256), dim3(256), 0, s, pp);
+                    hipLaunchKernelGGL((conv_mfma_persist_kernel<TAPS, MBW, POOL, false>), dim3(grid), dim3(256), 0, s, pp);
                 return 0;
             }
         }

@@ -169,11 +169,9 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
     const int NC = p.cin / UC;                           // units per item
 
     // ---- work items: (tile, slice) of this XCD's contiguous eighth ----
-    const int per_xcd = (p.nitems + 7) >> 3;
-    const int stride = gridDim.x >> 3;
-    const int xcd = blockIdx.x & 7;
-    const int item_end = min((xcd + 1) * per_xcd, p.nitems);
-    int item = xcd * per_xcd + (blockIdx.x >> 3);
+    const XcdRange xr = xcd_range(p.nitems, p.xcd_shift);
+    const int stride = xr.stride, item_end = xr.item_end;
+    int item = xr.item;
     if (item >= item_end) return;
 
     auto udiv = [](unsigned n, unsigned magic, unsigned d) -> unsigned { return d == 1 ? n : __umulhi(n, magic); };
@@ -735,7 +733,7 @@ int launch_w(const ConvParams& p, hipStream_t s)
     const long long dmax = std::max(std::max(p.nslices, q.tiles_x), q.tiles_y);
     if (nitems * dmax >= 0x100000000ll) return 1;      // beyond the 32-bit tile decode: reported as MP_EINVAL
     q.nitems = (int)nitems;
-    const unsigned grid = (unsigned)std::min<long long>(256, ((nitems + 7) / 8) * 8);
+    const unsigned grid = persistent_grid(nitems, p.ncu, p.xcd_shift);
     const ConvParams& pp = q;
     if (!FUSE && p.pad_zero) {
         if (p.bn_first) hipLaunchKernelGGL((conv_wino_kernel<POOL, true, false, true, TC>), dim3(grid), dim3(256), 0, s, pp);

@@ -3,9 +3,9 @@
 // per 4x4 output pixels -- 2.25 multiplications per output against 4 for F(2x2,3x3) (conv_wino.hip) and 9 for the direct
 // form: 1.78x fewer MFMAs than conv_wino.hip for the same ReflectionPad -> Conv2d -> ReLU -> BN [-> MaxPool] block
 // (multipoint/models/MultiPoint.py:143-148).  fp32 throughout; U = G g G^T is computed once on the host (in double, rounded
-// once: G holds 1/6 and 1/24), V = B^T d B and Y = A^T M A are short fixed-order multiply-add chains with the small integer
-// coefficients of B and A.  Measured against the CPU restatement (tests/) with every 3x3 layer of the network in this form:
-// prob 1.7e-5, descriptors 2.0e-6 at 480x640 (the same noise class as F(2x2,3x3): 9e-6 / 1e-6; tolerances unchanged).
+// once), V = B^T d B and Y = A^T M A are short fixed-order multiply-add chains whose coefficients are exact binary fractions.
+// Interpolation points {0, +-3/4, +-3/2, inf} instead of the textbook {0, +-1, +-2, inf}: same instruction count, 3.4x smaller
+// maximum error (mp_common.h; measured on trained-like statistics in DESIGN.md section 4).
 //
 // Structure (the round-2 lessons of conv_wino.hip apply unchanged: every operand through LDS, filled by LDS-DMA; ONE counted
 // wait + barrier per unit; no control flow inside a unit; vector work clustered):
@@ -92,54 +92,56 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 
 // Packed fp32 arithmetic as explicit instructions: hipcc scalarises a third of the transform's packed multiply-adds (4 v_fma_f32
 // for 2 v_pk_fma_f32 per pass), and next to an MFMA stream every vector instruction costs matrix-pipe time.
-// K = 2.0 / 4.0 are inline constants (op_sel_hi 0: the low half feeds both lanes); 5.0 comes in a scalar register pair.
-#define MPQ_PK_FMA(K)                                                                                              \
-    __device__ __forceinline__ f32x2 pk_fma_##K(f32x2 a, f32x2 c) {      /* a * K + c */                           \
-        f32x2 d; asm("v_pk_fma_f32 %0, %1, " #K ".0, %2 op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "v"(c)); return d; } \
-    __device__ __forceinline__ f32x2 pk_fnma_##K(f32x2 a, f32x2 c) {     /* c - a * K */                           \
-        f32x2 d; asm("v_pk_fma_f32 %0, %1, " #K ".0, %2 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "v"(c)); return d; }
-MPQ_PK_FMA(2)
-MPQ_PK_FMA(4)
-__device__ __forceinline__ f32x2 pk_fnma_5(f32x2 a, f32x2 c)             // c - a * 5
+// The transform coefficients come in scalar register pairs (the value in both halves; VOP3P takes no literal on gfx950).
+constexpr unsigned long long pk_const(double v)
 {
-    f32x2 d;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "s"(0x40A0000040A00000ull), "v"(c));
-    return d;
+    return (unsigned long long)__builtin_bit_cast(unsigned, (float)v) * 0x100000001ull;
 }
-__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) { f32x2 d; asm("v_pk_add_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
-__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b)
+constexpr double W43A = MP_W43_A, W43B = MP_W43_B;                  // interpolation points {0, +-a, +-b, inf} (mp_common.h)
+constexpr unsigned long long K_A = pk_const(W43A), K_B = pk_const(W43B), K_A2 = pk_const(W43A * W43A), K_B2 = pk_const(W43B * W43B),
+                             K_P = pk_const(W43A * W43A * W43B * W43B), K_S = pk_const(W43A * W43A + W43B * W43B);
+static_assert((double)(float)(W43A * W43A * W43B * W43B) == W43A * W43A * W43B * W43B && (double)(float)(W43A * W43A + W43B * W43B) ==
+              W43A * W43A + W43B * W43B, "the transform coefficients must be exact in fp32");
+__device__ __forceinline__ f32x2 pk_fma_k(f32x2 a, unsigned long long k, f32x2 c)      // a * k + c
 {
-    f32x2 d; asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d) : "v"(a), "v"(b)); return d;
+    f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c)); return d;
 }
-// 1-D input transform B^T d (6 -> 6), packed over two channels: 12 instructions.  B^T =
-//   [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+__device__ __forceinline__ f32x2 pk_fnma_k(f32x2 a, unsigned long long k, f32x2 c)     // c - a * k
+{
+    f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "s"(k), "v"(c)); return d;
+}
+// 1-D input transform B^T d (6 -> 6), packed over two channels: 12 multiply-adds.  Row of point p = the coefficients of
+// x (x^2 - a^2)(x^2 - b^2) / (x - p), last row the polynomial itself:
+//   B^T = [a^2 b^2, 0, -(a^2+b^2), 0, 1, 0;  0, -+a b^2, -b^2, +-a, 1, 0 (p = +-a);  0, -+b a^2, -a^2, +-b, 1, 0 (p = +-b);
+//          0, a^2 b^2, 0, -(a^2+b^2), 0, 1]
 __device__ __forceinline__ void bt6(const f32x2 d[6], f32x2 r[6])
 {
 #if defined(MPQX) && (MPQX & 131072)
     for (int i = 0; i < 6; ++i) r[i] = d[i];        // timing only: no arithmetic
     return;
 #endif
-    const f32x2 t0 = pk_fnma_4(d[2], d[4]);        // d4 - 4 d2
-    const f32x2 t1 = pk_fnma_4(d[1], d[3]);        // d3 - 4 d1
-    const f32x2 t2 = pk_sub(d[4], d[2]);
-    const f32x2 t3 = pk_sub(d[3], d[1]);
-    r[0] = pk_fma_4(d[0], pk_fnma_5(d[2], d[4]));  // 4 d0 + (d4 - 5 d2)
-    r[1] = pk_add(t0, t1);
-    r[2] = pk_sub(t0, t1);
-    r[3] = pk_fma_2(t3, t2);                       // t2 + 2 t3
-    r[4] = pk_fnma_2(t3, t2);                      // t2 - 2 t3
-    r[5] = pk_fma_4(d[1], pk_fnma_5(d[3], d[5]));  // 4 d1 + (d5 - 5 d3)
+    const f32x2 t0 = pk_fnma_k(d[2], K_B2, d[4]);       // d4 - b^2 d2      (even part of the +-a rows)
+    const f32x2 t1 = pk_fnma_k(d[1], K_B2, d[3]);       // d3 - b^2 d1      (odd part / a)
+    const f32x2 t2 = pk_fnma_k(d[2], K_A2, d[4]);       // d4 - a^2 d2      (+-b rows)
+    const f32x2 t3 = pk_fnma_k(d[1], K_A2, d[3]);       // d3 - a^2 d1
+    r[0] = pk_fma_k(d[0], K_P, pk_fnma_k(d[2], K_S, d[4]));      // a^2 b^2 d0 + (d4 - (a^2+b^2) d2)
+    r[1] = pk_fma_k(t1, K_A, t0);                       // t0 + a t1
+    r[2] = pk_fnma_k(t1, K_A, t0);                      // t0 - a t1
+    r[3] = pk_fma_k(t3, K_B, t2);                       // t2 + b t3
+    r[4] = pk_fnma_k(t3, K_B, t2);                      // t2 - b t3
+    r[5] = pk_fma_k(d[1], K_P, pk_fnma_k(d[3], K_S, d[5]));      // a^2 b^2 d1 + (d5 - (a^2+b^2) d3)
 }
-// 1-D output transform A^T m (6 -> 4), packed over two output channels.  A^T =
-//   [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// 1-D output transform A^T m (6 -> 4), packed over two output channels.  A^T[i][p] = p^i:
+//   [1 1 1 1 1 0; 0 a -a b -b 0; 0 a^2 a^2 b^2 b^2 0; 0 a^3 -a^3 b^3 -b^3 1]
 __device__ __forceinline__ void at6(const f32x2 m[6], f32x2 y[4])
 {
-    const f32x2 c2 = {2.f, 2.f}, c4 = {4.f, 4.f}, c8 = {8.f, 8.f};
+    constexpr float a1 = (float)W43A, b1 = (float)W43B, a2 = (float)(W43A * W43A), b2 = (float)(W43B * W43B),
+                    a3 = (float)(W43A * W43A * W43A), b3 = (float)(W43B * W43B * W43B);
     const f32x2 s1 = m[1] + m[2], d1 = m[1] - m[2], s2 = m[3] + m[4], d2 = m[3] - m[4];
     y[0] = (m[0] + s1) + s2;
-    y[1] = d1 + c2 * d2;
-    y[2] = s1 + c4 * s2;
-    y[3] = (d1 + c8 * d2) + m[5];
+    y[1] = __builtin_elementwise_fma(d2, f32x2{b1, b1}, d1 * f32x2{a1, a1});
+    y[2] = __builtin_elementwise_fma(s2, f32x2{b2, b2}, s1 * f32x2{a2, a2});
+    y[3] = __builtin_elementwise_fma(d2, f32x2{b3, b3}, d1 * f32x2{a3, a3}) + m[5];
 }
 
 // F1: the layer's input is the first encoder block (Cin = 1 -> 64, conv_first.hip's arithmetic) of p.img, computed by this
@@ -168,11 +170,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     const int NC = p.cin / UC4;                          // units per item (even: cin is a multiple of 8)
 
     // ---- work items: (tile block, slice) of this XCD's contiguous eighth ----
-    const int per_xcd = (p.nitems + 7) >> 3;
-    const int stride = gridDim.x >> 3;
-    const int xcd = blockIdx.x & 7;
-    const int item_end = min((xcd + 1) * per_xcd, p.nitems);
-    int item = xcd * per_xcd + (blockIdx.x >> 3);
+    const XcdRange xr = xcd_range(p.nitems, p.xcd_shift);
+    const int stride = xr.stride, item_end = xr.item_end;
+    int item = xr.item;
     if (item >= item_end) return;
 
     auto udiv = [](unsigned n, unsigned magic, unsigned d) -> unsigned { return d == 1 ? n : __umulhi(n, magic); };
@@ -753,7 +753,7 @@ int launch_q(const ConvParams& p, hipStream_t s)
     const long long dmax = std::max(std::max(p.nslices, q.tiles_x), q.tiles_y);
     if (nitems * dmax >= 0x100000000ll) return 1;
     q.nitems = (int)nitems;
-    const unsigned grid = (unsigned)std::min<long long>(256, ((nitems + 7) / 8) * 8);
+    const unsigned grid = persistent_grid(nitems, p.ncu, p.xcd_shift);
     const ConvParams& pp = q;
     if (p.bn_first) hipLaunchKernelGGL((conv_wino43_kernel<POOL, true, TC4, F1>), dim3(grid), dim3(512), 0, s, pp);
     else hipLaunchKernelGGL((conv_wino43_kernel<POOL, false, TC4, F1>), dim3(grid), dim3(512), 0, s, pp);
@@ -779,8 +779,8 @@ bool conv_wino43_supports(const ConvParams& p)
 
 // p.wpack must point at the F(4x4,3x3) weights packed by pack_wino43_weights() (api.hip).  fuse_first: the input is the
 // first encoder block of p.img (p.w1 / b1 / s1 / t1, 64 channels), evaluated inside the kernel; p.scratch holds
-// conv_wino43_scratch_floats() floats; the layer must be the pooled 64 -> 64 one (enc.conv2)
-size_t conv_wino43_scratch_floats() { return (size_t)256 * 2 * 16 * NPIXP * 4; }
+// conv_wino43_scratch_floats(p.ncu) floats; the layer must be the pooled 64 -> 64 one (enc.conv2)
+size_t conv_wino43_scratch_floats(int ncu) { return (size_t)ncu * 2 * 16 * NPIXP * 4; }
 int launch_conv_wino43(const ConvParams& p, bool pool, hipStream_t s, bool fuse_first)
 {
     if (fuse_first) return pool && p.cin == 64 ? launch_q<true, 8, true>(p, s) : 1;

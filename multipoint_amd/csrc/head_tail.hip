@@ -254,7 +254,7 @@ int launch_head_tail(const HeadTailParams& p, hipStream_t s)
     if (p.K % 64 != 0 || p.npx <= 0) return 1;
     const int D = p.desc ? p.D : 0;
     const long long tiles = (p.npx + 127) / 128;                  // one workgroup per CU walks them
-    const dim3 grid((unsigned)(tiles < 256 ? tiles : 256)), block(256);
+    const dim3 grid((unsigned)(tiles < p.ncu ? tiles : p.ncu)), block(256);
     switch (D) {
     case 0: hipLaunchKernelGGL(head_tail_kernel<0>, grid, block, 0, s, p); return 0;
     case 64: hipLaunchKernelGGL(head_tail_kernel<2>, grid, block, 0, s, p); return 0;

@@ -46,7 +46,35 @@ struct ConvParams {
     // buffers of 16 channel quads x 612 patch pixels x 4 floats that the block's output of an item is parked in (L2 / Infinity
     // Cache resident: 2 x 157 KB x 256 workgroups)
     float* scratch;
+    // machine shape (api.hip: mp_create derives it from the device, run_conv copies it into every launch): compute units of
+    // the device = workgroups of a one-per-CU persistent grid, and log2 of its XCD count (workgroup b runs on XCD b mod nxcd;
+    // each XCD has its own L2, so a persistent workgroup walks a contiguous share of ITS XCD's items)
+    int ncu, xcd_shift;
 };
+
+// persistent schedule shared by the persistent kernels: the items are cut into one contiguous range per XCD, and the
+// workgroups of an XCD (blockIdx mod nxcd, gridDim a multiple of nxcd) walk that range with the stride of their number
+struct XcdRange { int item, item_end, stride; };
+__device__ __forceinline__ XcdRange xcd_range(int nitems, int xcd_shift)
+{
+    const int nxcd = 1 << xcd_shift;
+    const int per_xcd = (nitems + nxcd - 1) >> xcd_shift;
+    const int xcd = (int)blockIdx.x & (nxcd - 1);
+    XcdRange r;
+    r.stride = (int)gridDim.x >> xcd_shift;
+    r.item_end = min((xcd + 1) * per_xcd, nitems);
+    r.item = xcd * per_xcd + ((int)blockIdx.x >> xcd_shift);
+    return r;
+}
+// host side: workgroups of a persistent launch with `per_cu` workgroups per CU -- never more than the items rounded up to a
+// multiple of the XCD count (every XCD gets the same number of workgroups)
+inline unsigned persistent_grid(long long nitems, int ncu, int xcd_shift, int per_cu = 1)
+{
+    const long long nxcd = 1ll << xcd_shift;
+    const long long full = ((long long)ncu * per_cu) / nxcd * nxcd;
+    const long long need = (nitems + nxcd - 1) / nxcd * nxcd;
+    return (unsigned)(need < full ? need : full);
+}
 
 // first layer (Cin = 1, direct VALU conv, HBM-write bound)
 struct Conv1Params {
@@ -68,9 +96,22 @@ void launch_conv_first(const Conv1Params& p, hipStream_t s);
 // Winograd F(2x2,3x3) flavour of the 3x3 layers (conv_wino.hip); p.wpack = weights packed by pack_wino_weights()
 int launch_conv_wino(const ConvParams& p, bool pool, bool fuse1, hipStream_t s);
 // Winograd F(4x4,3x3) (conv_wino43.hip): p.wpack = pack_wino43_weights() output; supports() says whether the shape is covered
+// Interpolation points of the F(4x4,3x3) transforms: {0, +-a, +-b, inf}.  The textbook choice a = 1, b = 2 (Lavin & Gray) has
+// integer transform matrices but the worst conditioning of the family: its fp32 error is ~20x that of a direct fp32
+// convolution.  The same set scaled by 3/4 -- a = 3/4, b = 3/2 -- keeps every transform coefficient an exact binary
+// fraction (a^2 = 9/16, b^2 = 9/4, a^2 b^2 = 81/64, a^2 + b^2 = 45/16), keeps the even/odd structure (12 multiply-adds per
+// 1-D input transform, as before) and cuts the maximum error 3.4x and the rms error 2x (CPU emulation over a grid of dyadic
+// (a, b): the minimum is broad around a b ~ 1, b / a ~ 2).  Shared by the kernel and the host-side
+// weight transform U = G g G^T (api.hip).
+#ifndef MP_W43_A
+#define MP_W43_A 0.75
+#endif
+#ifndef MP_W43_B
+#define MP_W43_B 1.5
+#endif
 bool conv_wino43_supports(const ConvParams& p);
 int launch_conv_wino43(const ConvParams& p, bool pool, hipStream_t s, bool fuse_first = false);
-size_t conv_wino43_scratch_floats();       // ConvParams::scratch of a fuse_first launch
+size_t conv_wino43_scratch_floats(int ncu);       // ConvParams::scratch of a fuse_first launch (one slot per persistent workgroup)
 
 // fp16 path (mixed_precision: activations and packed weights fp16, fp32 accumulate; conv_f16.hip).
 // Same tiling as ConvParams; a chunk is 64 input channels, so cin must be a multiple of 64.
@@ -91,6 +132,7 @@ struct ConvParamsH {
     unsigned magic_slices, magic_tx, magic_ty;
     int nitems;           // work items (tile, slice) of the launch (filled in by the launcher)
     _Float16* dummy;      // >= 1 KiB scratch line that masked-off store lanes write to
+    int ncu, xcd_shift;   // machine shape, as in ConvParams
 };
 struct Conv1ParamsH {
     const float* in;      // [B][H][W] fp32 image (rounded to fp16 on load)
@@ -123,6 +165,7 @@ struct HeadTailParams {
     float* desc;                // [npx][D] or nullptr
     int softmax_mode;           // 0: Softmax2d, 1: SuperPointMagicLeap heat map
     int normalize;              // F.normalize the descriptors
+    int ncu;                    // compute units of the device: one persistent workgroup each
 };
 int launch_head_tail(const HeadTailParams& p, hipStream_t s);      // 0: launched, 1: shape not covered (use the separate kernels)
 void launch_det_post(const float* logits, int lstride, int B, int Hc, int Wc, float* prob,

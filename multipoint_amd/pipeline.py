@@ -177,17 +177,23 @@ class PairPipeline:
             is_optical = (torch.arange(B) % 2 == 0).reshape(B, 1)
         out = self.net({'image': images, 'is_optical': is_optical})
         res = self._post(out, valid_mask, dev, B, H, W)
-        redo_nms = self.nms > 0 and U.nms_unresolved(dev)
-        K = res.kp_yx.shape[1]
-        need = int(res.kp_count.max()) if B else 0
-        overflow = need > K and not self._capacity_is_exact(K)
-        if redo_nms or overflow:
+        for _ in range(4):
+            # both conditions are re-evaluated after EVERY pass: the exact NMS of a redone pass can keep more keypoints than
+            # the asynchronous rounds left, i.e. overflow lists that fitted before
+            redo_nms = self.nms > 0 and U.nms_unresolved(dev)
+            K = res.kp_yx.shape[1]
+            # (no device-to-host read of the counts when top-k bounds them by the capacity anyway)
+            need = 0 if (self._capacity_is_exact(K) or not B) else int(res.kp_count.max())
+            overflow = need > K
+            if not (redo_nms or overflow):
+                break
             # lists that overflowed their capacity (topk == 0: the reference keeps EVERY keypoint, utils.py:109-116) are
             # rebuilt with the exact size -- dropping the row-major tail would silently change nn_map / m_score
             res = self._post(out, valid_mask, dev, B, H, W, nms_rounds=0 if redo_nms else None,
-                             capacity=((need + 255) // 256) * 256 if overflow else None)
-            if overflow and int(res.kp_count.max()) > res.kp_yx.shape[1]:
-                raise RuntimeError('keypoint lists still overflow after regrowing to %d slots' % res.kp_yx.shape[1])
+                             capacity=((need + 255) // 256) * 256 if overflow else K)
+        else:
+            raise RuntimeError('run_converged: keypoint lists / NMS did not settle after 4 passes (capacity %d)' % res.kp_yx.shape[1])
+        self._last = res
         return res
 
     def check_converged(self, device=None):

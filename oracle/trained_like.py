@@ -169,16 +169,16 @@ def case(severity, seed, B, H, W, cfg=None):
     par = SEVERITIES[severity]
     sd = O.make_weights(seed, cfg) if par is None else trained_like_weights(seed, cfg, **par)
     img = O.make_images(seed + 3, B, H, W) if par is None else structured_images(seed + 3, B, H, W)
-    r32 = O.forward(sd, img, cfg)
-    r32['logits'] = O.forward(sd, img, cfg, return_logits=True)['logits']
-    r64 = forward64(sd, img, cfg)
-    r64['logits'] = forward64_logits(sd, img, cfg)
+    r32 = _with_prob(O.forward(sd, img, cfg, return_logits=True))
+    sd64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in sd.items()}
+    r64 = _with_prob(O.forward(sd64, img.double(), cfg, return_logits=True))
     return cfg, sd, img, r32, r64
 
 
-def forward64_logits(sd, image, cfg=None):
-    sd64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in sd.items()}
-    return O.forward(sd64, image.double(), cfg, return_logits=True)['logits']
+def _with_prob(out):
+    """prob from the logits with the ops MultiPoint.forward applies (Softmax2d, drop the dustbin, PixelShuffle(8))."""
+    out['prob'] = O.depth_to_space(torch.softmax(out['logits'], dim=1)[:, :-1], 8)
+    return out
 
 
 def gpu_outputs(cfg, sd, img, env):

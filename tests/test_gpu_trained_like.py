@@ -1,0 +1,60 @@
+"""GPU (MI355X): every convolution family on TRAINED-LIKE statistics (round-2 verdict, "What's missing" 1).
+
+All other parity inputs are white noise through benign synthetic weights.  oracle/trained_like.py builds the hard case:
+structured images (polygons, ramps, saturated regions, DC offsets, periodic texture) through weights whose BatchNorm
+statistics are calibrated on such images, with running_var log-uniform over [1e-3, 1e2], |gamma| log-uniform over [0.1, 10]
+(15 % negative) and -- 'wide+hot' -- three filters per layer x10 outside their statistics.  The reference's pretrained blob
+(model_weights/multipoint/latest.model, MultiPoint.py:143-148 is the block it parameterises) is not shipped, so this is
+the closest available stand-in for it.
+
+What is asserted, per severity and for F(4x4,3x3) (default), F(2x2,3x3) and the direct kernel on the SAME inputs:
+  * descriptors within 1e-4 of the fp32 CPU oracle (north_star's bar) -- observed <= 5e-5 everywhere;
+  * prob: within max(1e-4, 4 x the error the fp32 CPU oracle ITSELF has against an fp64 evaluation): on 'wide+hot' ATen's
+    own fp32 result is 5.5e-4 from the truth, so no fp32 implementation can be held to 1e-4 there; observed F(4x4,3x3)
+    <= 2.9x, direct <= 2.2x, F(2x2,3x3) <= 1.4x ATen's error;
+  * every keypoint that differs from the oracle's list is an explained fp32-noise flip (oracle/flip_accounting.py).  On
+    exactly piecewise-constant images the CPU map holds EXACT ties (ATen evaluates equal patches equally); F(4x4,3x3)
+    evaluates the 16 outputs of a tile by 16 different formulas, so it breaks those ties by rounding noise where the direct
+    kernel and F(2x2,3x3) keep them -- 110 of 2 055 keypoints on the 'wide' case, margin 0, all explained.
+The interpolation points of the F(4x4,3x3) transforms were changed from the textbook {0, +-1, +-2} to {0, +-3/4, +-3/2} on
+this evidence: 3.3x smaller error on every severity (csrc/mp_common.h; the table is in DESIGN.md section 4)."""
+import json
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+H, W, B = 480, 640, 2
+_cases = {}
+
+
+def _case(sev):
+    from oracle import trained_like as T
+    if sev not in _cases:
+        _cases[sev] = T.case(sev, 11, B, H, W)
+    return _cases[sev]
+
+
+@pytest.mark.parametrize('variant', ['F(4x4,3x3)', 'F(2x2,3x3)', 'direct'])
+@pytest.mark.parametrize('sev', ['mild', 'wide', 'wide+hot'])
+def test_conv_families_on_trained_like_statistics(oracle, sev, variant):
+    from oracle import trained_like as T
+    from oracle import flip_accounting as FA
+    cfg, sd, img, r32, r64 = _case(sev)
+    aten = {k: float((r32[k].double() - r64[k]).abs().max()) for k in ('prob', 'desc', 'logits')}
+    got = T.gpu_outputs(cfg, sd, img, T.VARIANT_ENV[variant])
+    e = T.errors(got, r32, r64)
+    nms = lambda m: oracle.box_nms(m, 4, 0.015, keep_top_k=0)
+    s, _ = FA.account_batch(r32['prob'].numpy(), got['prob'].numpy(), nms, 4, 0.015, 0.1, 1000)
+    print('\n[trained-like %s %s] %s | ATen fp32 vs fp64: %s | keypoints %d differing %d unexplained %d'
+          % (sev, variant, json.dumps(e), json.dumps(aten), s['keypoints_total'], s['keypoints_differing'], s['unexplained']))
+    assert e['desc_vs_cpu32'] <= 1e-4, e
+    assert e['prob_vs_f64'] <= max(1e-4, 4.0 * aten['prob']), (e, aten)
+    assert e['logits_vs_f64'] <= max(1e-3, 5.0 * aten['logits']), (e, aten)
+    assert s['unexplained'] == 0 and s['max_unexplained_margin'] == 0.0, s
+    assert s['roots_within_measured_noise']
+    if variant != 'F(4x4,3x3)':
+        # these two evaluate equal patches equally: the exact ties of piecewise-constant images survive
+        assert s['keypoints_differing'] <= 0.01 * s['keypoints_total'], s
+    else:
+        assert s['keypoints_differing'] <= 0.08 * s['keypoints_total'], s

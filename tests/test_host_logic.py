@@ -350,3 +350,11 @@ def test_failed_hazard_check_leaves_no_object(tmp_path, monkeypatch):
     assert [f for f in os.listdir(tmp_path) if f != 'k.hip'] == []        # no object, no -save-temps leftovers
     monkeypatch.setattr(b, 'DMA_SOURCES', ())
     assert os.path.exists(b._compile('k.hip'))
+
+
+def test_hardware_queue_default_is_set_by_the_package():
+    """GPU_MAX_HW_QUEUES must be in the environment before the runtime initialises, for every user of the package (not only
+    bench.py): multipoint_amd/__init__.py sets it."""
+    r = subprocess.run([__import__('sys').executable, '-c', 'import os; os.environ.pop("GPU_MAX_HW_QUEUES", None); import multipoint_amd; '
+                        'print(os.environ["GPU_MAX_HW_QUEUES"])'], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == '8', r.stderr[-500:]
