@@ -82,6 +82,7 @@ struct mp_handle {
                                     // standalone first block + Winograd conv2 with LDS-DMA staging -- 6.50 vs 6.84 ms per 64 images)
     int* pinned = nullptr;          // small pinned host scratch (img lists, counters)
     bool prof = false;
+    bool head_fallback_noted = false;
     std::vector<ProfEntry> prof_entries;
     size_t prof_used = 0;
 };
@@ -508,14 +509,25 @@ int too_large(mp_handle* h, const char* name, int B, int H, int W)
                                   "): split the batch");
 }
 
+// launcher return codes: 0 launched; 1 more work items than the 32-bit tile decode addresses; 2 a layer shape the selected
+// kernel is not instantiated for (a dispatch bug: run_conv only selects kernels whose *_supports() said yes)
+int launch_failed(mp_handle* h, int code, const char* name, int B, int H, int W)
+{
+    if (code == 1) return too_large(h, name, B, H, W);
+    return fail(h, MP_EINVAL, std::string("mp_forward: layer ") + name + ": the selected convolution kernel does not cover this "
+                                  "layer shape (" + std::to_string(H) + "x" + std::to_string(W) + ")");
+}
+
 // does run_conv() send this 3x3 layer at H x W to the F(4x4,3x3) kernel?
-bool uses_wino43(const mp_handle* h, const ConvLayer& L, int H, int W, bool fuse)
+bool uses_wino43(const mp_handle* h, const ConvLayer& L, int H, int W, bool fuse, int in_cstride = 0, int in_coff = 0,
+                 int out_cstride = 0, int out_coff = 0)
 {
     // fuse: the first block is evaluated by the layer's kernel -- with F(4x4,3x3) only by the pooled 64 -> 64 layer, 64 real channels
     if (fuse && !(h->fuse43 && !h->wino_fuse && L.pool && L.cin == 64 && L.cout == 64 && h->cfg.channel_version == 0)) return false;
     if (!(L.taps == 9 && L.u43pack && h->wino && (h->wino43 == 2 || L.cin == 64))) return false;
     ConvParams q{};
     q.pad_zero = h->cfg.reflection_pad ? 0 : 1; q.cin = L.cin; q.cout = L.cout; q.H = H; q.W = W;
+    q.in_cstride = in_cstride; q.in_coff = in_coff; q.out_cstride = out_cstride; q.out_coff = out_coff;
     return conv_wino43_supports(q);
 }
 
@@ -543,17 +555,18 @@ int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, 
     } else {
         p.total_px = (long long)B * H * W;
     }
+    const bool f43 = uses_wino43(h, L, H, W, fuse != nullptr, in_cstride, in_coff, out_cstride, out_coff);
+    if (f43 && fuse) {              // (allocations before prof_begin: a failure must not leave an open profile entry)
+        int rc;
+        if ((rc = ensure(h, h->fuse43_ws, conv_wino43_scratch_floats(h->ncu) * 4))) return rc;
+        p.scratch = static_cast<float*>(h->fuse43_ws.p);
+    }
     prof_begin(h, fuse ? "enc.conv1+2" : L.name,
                2.0 * L.taps * L.cin * L.cout * (double)B * H * W + (fuse ? 2.0 * 9 * 64 * (double)B * H * W : 0.0), s);
     if (fuse) { p.img = images; p.w1 = fuse->w; p.b1 = fuse->bias; p.s1 = fuse->scale; p.t1 = fuse->shift; }
     int big;
-    if (uses_wino43(h, L, H, W, fuse != nullptr)) {
+    if (f43) {
         p.wpack = L.u43pack; p.in_planar = in_planar; p.out_planar = out_planar;
-        if (fuse) {
-            int rc;
-            if ((rc = ensure(h, h->fuse43_ws, conv_wino43_scratch_floats(h->ncu) * 4))) return rc;
-            p.scratch = static_cast<float*>(h->fuse43_ws.p);
-        }
         big = launch_conv_wino43(p, L.pool, s, fuse != nullptr);
     } else if (L.taps == 9 && L.upack && h->wino && (!fuse || (L.pool && L.cin == 64))) {
         p.wpack = L.upack;
@@ -562,7 +575,7 @@ int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, 
         big = launch_conv_mfma(p, L.taps, mbw, L.pool, fuse != nullptr, s);
     }
     prof_end(h, s);
-    return big ? too_large(h, L.name, B, H, W) : MP_OK;
+    return big ? launch_failed(h, big, L.name, B, H, W) : MP_OK;
 }
 
 int run_conv_h(mp_handle* h, const ConvLayer& L, const _Float16* in, int in_cstride, int in_coff, _Float16* out,
@@ -1036,6 +1049,11 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
             return MP_OK;
         }
         if (h->prof) --h->prof_used;    // not covered: fall through to the separate kernels
+        if (!h->head_fallback_noted) {  // ... visibly: once per handle on stderr, and the profile then lists "det.conv1x1" etc.
+            h->head_fallback_noted = true;
+            fprintf(stderr, "[multipoint_hip] note: fused head tail not instantiated for %d head channels / descriptor size %d: "
+                            "using the separate 1x1 convolution, softmax and normalisation launches\n", hc, D);
+        }
     }
     if ((rc = run_conv(h, h->det1, P, headc, 0, Lg, 80, 0, B, Hc, Wc, nullptr, s))) return rc;
     if (prob || logits) {

@@ -727,7 +727,7 @@ int launch_w(const ConvParams& p, hipStream_t s)
     q.tiles_x = (p.W + WTX - 1) / WTX; q.tiles_y = (p.H + WTY - 1) / WTY;
     const long long nitems = (long long)p.B * q.tiles_x * q.tiles_y * p.nslices;
     if (nitems <= 0) return 0;
-    if (p.cin % (2 * UC) != 0) return 1;        // units are unrolled in pairs (api.hip pads cin to a multiple of 32)
+    if (p.cin % (2 * UC) != 0) return 2;        // shape not covered: units are unrolled in pairs (api.hip pads cin to a multiple of 32)
     auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ull / (unsigned)d) + 1ull); };
     q.magic_slices = magic(p.nslices); q.magic_tx = magic(q.tiles_x); q.magic_ty = magic(q.tiles_y);
     const long long dmax = std::max(std::max(p.nslices, q.tiles_x), q.tiles_y);

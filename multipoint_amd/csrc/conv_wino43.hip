@@ -774,7 +774,9 @@ int launch_shape(const ConvParams& p, hipStream_t s)
 // channels a multiple of 8 (units of 4, unrolled in pairs), spatial size a multiple of the 4x4 tile
 bool conv_wino43_supports(const ConvParams& p)
 {
-    return !p.pad_zero && p.cin % 8 == 0 && p.cout % 4 == 0 && p.H % 4 == 0 && p.W % 4 == 0 && p.H >= 4 && p.W >= 4;
+    // (the patch DMAs and the f32x4 stores move 16-byte granules: channel offsets and strides must be multiples of 4 floats)
+    return !p.pad_zero && p.cin % 8 == 0 && p.cout % 4 == 0 && p.H % 4 == 0 && p.W % 4 == 0 && p.H >= 4 && p.W >= 4 &&
+           p.in_cstride % 4 == 0 && p.in_coff % 4 == 0 && p.out_cstride % 4 == 0 && p.out_coff % 4 == 0;
 }
 
 // p.wpack must point at the F(4x4,3x3) weights packed by pack_wino43_weights() (api.hip).  fuse_first: the input is the
@@ -783,6 +785,6 @@ bool conv_wino43_supports(const ConvParams& p)
 size_t conv_wino43_scratch_floats(int ncu) { return (size_t)ncu * 2 * 16 * NPIXP * 4; }
 int launch_conv_wino43(const ConvParams& p, bool pool, hipStream_t s, bool fuse_first)
 {
-    if (fuse_first) return pool && p.cin == 64 ? launch_q<true, 8, true>(p, s) : 1;
+    if (fuse_first) return pool && p.cin == 64 ? launch_q<true, 8, true>(p, s) : 2;          // 2: shape not covered
     return pool ? launch_shape<true>(p, s) : launch_shape<false>(p, s);
 }

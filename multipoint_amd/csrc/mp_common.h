@@ -155,7 +155,10 @@ void launch_conv_first_f16(const Conv1ParamsH& p, hipStream_t s);
 struct HeadTailParams {
     const float* x;             // [npx][xstride] output of the 3x3 head convolution: detector channels [0,K), descriptor [K,2K)
     int xstride, K;             // K = head channels (multiple of 32)
-    const float *wdet, *bdet, *sdet, *tdet;       // detector 1x1: pack_conv_weights(taps = 1) fragments, bias / BN scale / shift
+    const float *wdet, *bdet, *sdet, *tdet;       // detector 1x1: pack_conv_weights(taps = 1) fragments, bias / BN scale / shift.
+                                                  // The kernel reads entries [0, 96) of bdet / sdet / tdet (three 32-channel blocks for the 65
+                                                  // detector channels) and [0, D) of the descriptor arrays: api.hip's build_conv pads every
+                                                  // per-channel array to nslices * 64 >= 128 entries (zeros / identity BatchNorm)
     const float *wdesc, *bdesc, *sdesc, *tdesc;   // descriptor 1x1 (unused when desc == nullptr)
     int D;                      // descriptor size (64, 128 or 256)
     long long npx;              // B * Hc * Wc
