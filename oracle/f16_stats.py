@@ -33,7 +33,14 @@ def prob_rel_stats(got, ref, thr=0.015):
     m = rp > thr
     rel = (p[m] - rp[m]) / rp[m]
     return dict(n=int(m.sum()), median_abs_rel=float(np.median(np.abs(rel))), p999_abs_rel=float(np.percentile(np.abs(rel), 99.9)),
-                max_abs_rel=float(np.abs(rel).max()), mean_signed_rel=float(rel.mean()), mean_abs_rel=float(np.abs(rel).mean()))
+                max_abs_rel=float(np.abs(rel).max()), mean_signed_rel=float(rel.mean()), mean_abs_rel=float(np.abs(rel).mean()),
+                # standard error of the signed mean: a bias test on a few hundred samples must allow for it
+                sem_rel=float(rel.std() / np.sqrt(max(rel.size, 1))))
+
+
+def unbiased(ps, frac=0.1, sigmas=4.0):
+    """|signed mean| is a small fraction of the mean |error|, up to the sampling noise of the mean itself."""
+    return abs(ps['mean_signed_rel']) <= frac * ps['mean_abs_rel'] + sigmas * ps['sem_rel']
 
 
 def fixture_views(z, out, which):
