@@ -16,10 +16,12 @@ Pinning status (see tests/test_oracle_vs_reference.py and tests/golden/make_gold
   * box_nms (torchvision.ops.nms / batched_nms) and cv2.BFMatcher: third-party code absent from
     /root/reference and not installable here -> "PARITY UNPINNED" at those two boundaries; the
     published algorithms are restated (oracle/nms_greedy.c, ``bf_match_crosscheck``).
-  * ``mixed_precision: true`` (forward under torch.cuda.amp.autocast, MultiPoint.py:99-103): autocast needs a
-    CUDA device, so the reference cannot produce vectors here -> "PARITY UNPINNED" for this mode; its
-    rounding points are restated in ``_block`` / ``_head`` (fp16 conv in/out with fp32 accumulation, fp32
-    BatchNorm arithmetic with fp16 results, fp32 softmax and normalisation).
+  * ``mixed_precision: true`` (forward under torch.cuda.amp.autocast, MultiPoint.py:99-103): PINNED (round 3) against
+    tests/golden/forward_f16.npz, which tests/golden/make_golden_f16.py generates by running the imported reference under
+    torch.autocast('cpu', dtype=torch.float16) -- the same context manager for the CPU backend; the fixture also records the
+    dtype every leaf module returned.  The rounding points are restated in ``_block`` / ``_head`` (fp16 conv in/out with fp32
+    accumulation, fp32 BatchNorm arithmetic with fp16 results, fp32 softmax and normalisation); two correct fp16 evaluations
+    agree to rounding flips, so the pin is distributional (tests/test_oracle_golden.py, oracle/f16_stats.py).
 """
 import collections
 import ctypes
@@ -186,8 +188,8 @@ def _h(t):
 def _block(x, sd, cfg, conv_key, bn_key):
     # MultiPoint.py:143-148 + :137-141
     if cfg.get('mixed_precision'):
-        # MultiPoint.py:99-103: forward under torch.cuda.amp.autocast (CUDA only -- cannot run here; PARITY
-        # UNPINNED for this mode).  Restated autocast semantics: Conv2d casts input, weight and bias to fp16,
+        # MultiPoint.py:99-103: forward under torch.cuda.amp.autocast (pinned against the reference run under CPU
+        # autocast, tests/golden/forward_f16.npz).  Restated autocast semantics: Conv2d casts input, weight and bias to fp16,
         # accumulates in fp32 and returns fp16; ReLU / pad / max-pool are exact on fp16; BatchNorm2d(eval) on an
         # fp16 tensor evaluates its affine form in fp32 and returns fp16.  x arrives holding fp16 values.
         x = _h(F.conv2d(_pad(x, cfg), _h(sd[conv_key + '.weight']), _h(sd[conv_key + '.bias'])))
