@@ -81,6 +81,7 @@ struct mp_handle {
     bool wino_fuse = false;         // MP_WINO_FUSE=1: first block computed inside the Winograd conv2 loader (default since round 2:
                                     // standalone first block + Winograd conv2 with LDS-DMA staging -- 6.50 vs 6.84 ms per 64 images)
     int* pinned = nullptr;          // small pinned host scratch (img lists, counters)
+    bool f16_res = true;            // MP_F16_NO_RES=1: the streaming kernel (conv_f16.hip) also for the 64 -> 64 layers
     bool prof = false;
     bool head_fallback_noted = false;
     std::vector<ProfEntry> prof_entries;
@@ -601,7 +602,8 @@ int run_conv_h(mp_handle* h, const ConvLayer& L, const _Float16* in, int in_cstr
         p.total_px = (long long)B * H * W;
     }
     prof_begin(h, L.name, 2.0 * L.taps * L.cin * L.cout * (double)B * H * W, s);
-    const int big = launch_conv_f16(p, L.taps, mbw, L.pool, s);
+    const int big = (h->f16_res && conv_f16_res_supports(p, L.taps)) ? launch_conv_f16_res(p, mbw, L.pool, s)
+                                                                     : launch_conv_f16(p, L.taps, mbw, L.pool, s);
     prof_end(h, s);
     return big ? too_large(h, L.name, B, H, W) : MP_OK;
 }
@@ -836,6 +838,7 @@ int mp_create(mp_handle** out, int device)
     { const char* e = getenv("MP_WINO_FUSE"); hh->wino_fuse = (e && e[0] == '1'); }
     { const char* e = getenv("MP_NO_FUSE43"); hh->fuse43 = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_NO_HEAD_FUSE"); hh->head_fuse = !(e && e[0] == '1'); }
+    { const char* e = getenv("MP_F16_NO_RES"); hh->f16_res = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_NO_PLANAR"); if (e && e[0] == '1') hh->planar = 0; }
     { const char* e = getenv("MP_PLANAR"); if (e && e[0] >= '0' && e[0] <= '2') hh->planar = e[0] - '0'; }
     { const char* e = getenv("MP_WINO43"); if (e && e[0] >= '0' && e[0] <= '2') hh->wino43 = e[0] - '0'; }

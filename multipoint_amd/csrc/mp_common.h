@@ -144,6 +144,9 @@ struct Conv1ParamsH {
     int pad_zero, bn_first;
 };
 int launch_conv_f16(const ConvParamsH& p, int taps, int mbw, bool pool, hipStream_t s);
+// 64 -> 64 3x3 layers with the packed weights resident in LDS (conv_f16_res.hip)
+bool conv_f16_res_supports(const ConvParamsH& p, int taps);
+int launch_conv_f16_res(const ConvParamsH& p, int mbw, bool pool, hipStream_t s);
 void launch_conv_first_f16(const Conv1ParamsH& p, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------
