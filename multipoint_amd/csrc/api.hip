@@ -82,6 +82,7 @@ struct mp_handle {
                                     // standalone first block + Winograd conv2 with LDS-DMA staging -- 6.50 vs 6.84 ms per 64 images)
     int* pinned = nullptr;          // small pinned host scratch (img lists, counters)
     bool f16_res = true;            // MP_F16_NO_RES=1: the streaming kernel (conv_f16.hip) also for the 64 -> 64 layers
+    bool f16_fuse1 = true;          // MP_F16_NO_FUSE1=1: the first block of the fp16 path as its own launch
     bool prof = false;
     bool head_fallback_noted = false;
     std::vector<ProfEntry> prof_entries;
@@ -580,7 +581,8 @@ int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, 
 }
 
 int run_conv_h(mp_handle* h, const ConvLayer& L, const _Float16* in, int in_cstride, int in_coff, _Float16* out,
-                int out_cstride, int out_coff, int B, int H, int W, const int* img_list, hipStream_t s)
+                int out_cstride, int out_coff, int B, int H, int W, const int* img_list, hipStream_t s,
+                const FirstLayer* fuse = nullptr, const float* images = nullptr)
 {
     ConvParamsH p{};
     p.in = in; p.out = out; p.wpack = L.wpack_h; p.bias = L.bias_h; p.scale = L.scale; p.shift = L.shift;
@@ -601,11 +603,13 @@ int run_conv_h(mp_handle* h, const ConvLayer& L, const _Float16* in, int in_cstr
     } else {
         p.total_px = (long long)B * H * W;
     }
-    prof_begin(h, L.name, 2.0 * L.taps * L.cin * L.cout * (double)B * H * W, s);
+    if (fuse) { p.img = images; p.w1 = fuse->w_h; p.b1 = fuse->bias_h; p.s1 = fuse->scale; p.t1 = fuse->shift; }
+    prof_begin(h, fuse ? "enc.conv1+2" : L.name,
+               2.0 * L.taps * L.cin * L.cout * (double)B * H * W + (fuse ? 2.0 * 9 * 64 * (double)B * H * W : 0.0), s);
     const int big = (h->f16_res && conv_f16_res_supports(p, L.taps)) ? launch_conv_f16_res(p, mbw, L.pool, s)
                                                                      : launch_conv_f16(p, L.taps, mbw, L.pool, s);
     prof_end(h, s);
-    return big ? too_large(h, L.name, B, H, W) : MP_OK;
+    return big ? launch_failed(h, big, L.name, B, H, W) : MP_OK;
 }
 
 // mixed_precision forward: fp16 activations end to end, fp32 softmax / descriptor normalisation
@@ -631,19 +635,25 @@ int forward_f16(mp_handle* h, const float* images, int B, int H, int W, int nset
         const int nb = counts[e];
         if (nb == 0) continue;
         const Encoder& E = h->enc[e];
-        Conv1ParamsH c1{};
-        c1.in = images; c1.out = P; c1.w = E.first.w_h; c1.bias = E.first.bias_h; c1.scale = E.first.scale;
-        c1.shift = E.first.shift; c1.img_list = lptr[e]; c1.B = nb; c1.H = H; c1.W = W;
-        c1.pad_zero = h->cfg.reflection_pad ? 0 : 1; c1.bn_first = h->cfg.bn_first;
-        prof_begin(h, "enc.conv1", 2.0 * 9 * 64 * (double)nb * H * W, s);
-        launch_conv_first_f16(c1, s);
-        prof_end(h, s);
+        // the first block inside the conv2 launch (conv_f16_res.hip F1): reflection padding, the LDS-resident-weights kernel
+        const bool fuse1 = h->f16_res && h->f16_fuse1 && h->cfg.reflection_pad && E.conv[0].pool && E.conv[0].cin == 64 &&
+                           E.conv[0].cout == 64 && E.conv[0].nslices == 1;
+        if (!fuse1) {
+            Conv1ParamsH c1{};
+            c1.in = images; c1.out = P; c1.w = E.first.w_h; c1.bias = E.first.bias_h; c1.scale = E.first.scale;
+            c1.shift = E.first.shift; c1.img_list = lptr[e]; c1.B = nb; c1.H = H; c1.W = W;
+            c1.pad_zero = h->cfg.reflection_pad ? 0 : 1; c1.bn_first = h->cfg.bn_first;
+            prof_begin(h, "enc.conv1", 2.0 * 9 * 64 * (double)nb * H * W, s);
+            launch_conv_first_f16(c1, s);
+            prof_end(h, s);
+        }
         int hh = H, ww = W;
         _Float16* src = P;
         _Float16* dst = Q;
         for (int i = 0; i < 7; ++i) {
             const ConvLayer& L = E.conv[i];
-            if ((rc = run_conv_h(h, L, src, L.cin, 0, i == 6 ? X : dst, L.cout, 0, nb, hh, ww, lptr[e], s))) return rc;
+            if ((rc = run_conv_h(h, L, src, L.cin, 0, i == 6 ? X : dst, L.cout, 0, nb, hh, ww, lptr[e], s,
+                                 (i == 0 && fuse1) ? &E.first : nullptr, images))) return rc;
             if (L.pool) { hh /= 2; ww /= 2; }
             _Float16* t = src; src = dst; dst = t;
         }
@@ -839,6 +849,7 @@ int mp_create(mp_handle** out, int device)
     { const char* e = getenv("MP_NO_FUSE43"); hh->fuse43 = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_NO_HEAD_FUSE"); hh->head_fuse = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_F16_NO_RES"); hh->f16_res = !(e && e[0] == '1'); }
+    { const char* e = getenv("MP_F16_NO_FUSE1"); hh->f16_fuse1 = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_NO_PLANAR"); if (e && e[0] == '1') hh->planar = 0; }
     { const char* e = getenv("MP_PLANAR"); if (e && e[0] >= '0' && e[0] <= '2') hh->planar = e[0] - '0'; }
     { const char* e = getenv("MP_WINO43"); if (e && e[0] >= '0' && e[0] <= '2') hh->wino43 = e[0] - '0'; }

@@ -83,7 +83,14 @@ __device__ __forceinline__ void group_barrier(lds_u32* ctr, unsigned& target, in
     asm volatile("" ::: "memory");
 }
 
-template <int MBW, bool POOL, bool BNF, int NG>
+// F1: the layer's input is the first encoder block (Cin = 1 -> 64: Conv2d + ReLU + BatchNorm of p.img with p.w1 / b1 / s1 / t1,
+// conv_f16.hip's conv_first_f16_kernel) and is never materialised in HBM: a group builds each 32-channel chunk of its activation
+// tile straight into LDS, on the matrix pipe -- D[channel][pixel] = W1[channel][tap] X[tap][pixel], K = 9 taps padded to 16, one
+// MFMA per 32 pixels and chunk; a lane gathers its pixel's taps from a (TH+4) x (TW+4) fp16 image patch in LDS whose rows and
+// columns are staged already reflected (the block's own ReflectionPad2d), at a window origin reflected by THIS layer's padding.
+// The launch then reads 2.6 MB of image per 16 frames instead of a 2.7 GB tensor that a separate HBM-write-bound launch had
+// to produce.  Reflection padding only (zero-padding models keep the two launches).
+template <int MBW, bool POOL, bool BNF, int NG, bool F1>
 __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvParamsH p)
 {
     using G = GeoR<MBW>;
@@ -92,6 +99,12 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
     __shared__ __attribute__((aligned(16))) _Float16 tiles[NG][G::NPIX * PSR];
     __shared__ __attribute__((aligned(16))) float prm[3 * 64];
     __shared__ unsigned gctr[NG];
+    // F1: image patches (two per group: the current item's and the next one's) + a zero tail that the padding taps read
+    constexpr int IW = G::LW + 2, IH = G::LH + 2, NIP = IW * IH;
+    constexpr int NIPB = ((NIP + 2 * IW + 3 + 7) / 8) * 8;          // halfs per patch buffer incl. the zero tail
+    constexpr int NIPR = (NIP + 255) / 256;                          // patch pixels per thread
+    __shared__ __attribute__((aligned(16))) _Float16 ipatch[F1 ? NG * 2 * NIPB : 8];
+    __shared__ __attribute__((aligned(16))) float prm1[F1 ? 3 * 64 : 4];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -108,6 +121,11 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
         for (int f = tid; f < WRES / 8; f += 256 * NG) reinterpret_cast<h8*>(wl)[f] = src[f];
         if (tid < 64) { prm[tid] = p.bias[tid]; prm[64 + tid] = p.scale[tid]; prm[128 + tid] = p.shift[tid]; }
         if (tid < NG) gctr[tid] = 0u;
+        if constexpr (F1) {
+            // the tails stay as written here: zeros, and a 1.0 where the lanes that hold taps 8..15 read "tap 9" (the bias)
+            for (int f = tid; f < NG * 2 * NIPB; f += 256 * NG) ipatch[f] = (f % NIPB == NIP + 1) ? (_Float16)1.f : (_Float16)0.f;
+            if (tid < 64) { prm1[64 + tid] = p.s1[tid]; prm1[128 + tid] = p.t1[tid]; }
+        }
     }
     __syncthreads();                                              // the only workgroup barrier
     unsigned bar_target = 0u;
@@ -184,6 +202,123 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
         return w.in_base;
     };
 
+
+    // ---------------- F1: first encoder block evaluated into the tile ----------------
+    _Float16* const ipg = ipatch + (F1 ? grp * 2 * NIPB : 0);     // this group's two patch buffers
+    float ipx[NIPR];                                              // the NEXT item's patch pixels, loaded one item ahead
+    h8 w1f[2];                                                    // A operands: W1[channel 32c + li][tap 8 half + e], 0 beyond tap 8
+    constexpr int NMB1 = (G::NPIX + 31) / 32;                     // M-blocks of 32 tile pixels
+    constexpr int NJ = (NMB1 + 3) / 4;                            // ... per wave
+    int va1[NJ], vb1[NJ], wa1[NJ];                                // gather bases (halfs into a patch buffer), tile write offset (halfs; -1: phantom pixels)
+    bool f1_rel = false;
+    auto patch_load = [&](const Where& w) __attribute__((always_inline)) {
+        const float* const im = p.img + (long long)w.img * p.H * p.W;
+#pragma unroll
+        for (int i = 0; i < NIPR; ++i) {
+            const int f = min(gt + i * 256, NIP - 1);
+            const int r = f / IW, c = f - r * IW;
+            ipx[i] = im[reflect_clamp_r(w.y0 - 2 + r, p.H) * p.W + reflect_clamp_r(w.x0 - 2 + c, p.W)];
+        }
+    };
+    auto patch_write = [&](int par) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < NIPR; ++i) {
+            const int f = gt + i * 256;
+            if (f < NIP) ipg[par * NIPB + f] = (_Float16)ipx[i];         // autocast rounds the convolution's input to fp16
+        }
+    };
+    // window origins of this lane's pixels for item w: staged row r holds image row reflect(y0 - 2 + r), so the 3x3 window of the
+    // tile pixel at frame position (gy, gx) -- reflected into the frame by this layer's padding -- starts at staged (gy' - y0 + 1,
+    // gx' - x0 + 1); interior items share one item-invariant set
+    auto f1_offsets = [&](const Where& w) __attribute__((always_inline)) {
+        const bool interior = (w.y0 >= 1) && (w.y0 + G::TH < p.H) && (w.x0 >= 1) && (w.x0 + G::TW < p.W);
+        if (interior && f1_rel) return;
+        f1_rel = interior;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int pix = (wave + 4 * j) * 32 + li;
+            const int pc = min(pix, G::NPIX - 1);
+            const int ly = pc / G::LW, lx = pc - ly * G::LW;
+            int oy = ly, ox = lx;
+            if (!interior) {
+                oy = reflect_clamp_r(w.y0 + ly - 1, p.H) - w.y0 + 1;
+                ox = reflect_clamp_r(w.x0 + lx - 1, p.W) - w.x0 + 1;
+                oy = min(max(oy, 0), IH - 3); ox = min(max(ox, 0), IW - 3);      // (only pixels of phantom outputs are clamped)
+            }
+            const int base = oy * IW + ox;
+            va1[j] = half ? base + 2 * IW + 2 : base;              // element 0: tap 0 (half 0) or tap 8 (half 1)
+            vb1[j] = half ? NIP : base;                            // elements 1..7: taps 1..7, or the zero tail
+            wa1[j] = pix < G::NPIX ? pc * PSR + 4 * half : -1;
+        }
+    };
+    // One pass per item: gather the taps of this wave's pixels once, evaluate BOTH 32-channel chunks (two MFMAs per 32 pixels;
+    // the bias rides in the GEMM as tap 9 against a 1.0 in the patch tail), apply ReLU / BatchNorm, write chunk 0 into the tile
+    // and keep chunk 1 packed in registers (8 per M-block) until chunk 0 has been multiplied (tile_chunk1).
+    h4 keep1[NJ][4];
+    auto act_nb = [](float a0, float a1, f32x2 scale, f32x2 shift) __attribute__((always_inline)) -> h2 {
+        h2 h = __builtin_convertvector(f32x2{a0, a1}, h2);        // conv output (bias included) -> fp16
+        const h2 zero = {0, 0};
+        if (!BNF) h = __builtin_elementwise_max(h, zero);
+        const f32x2 y = __builtin_convertvector(h, f32x2) * scale + shift;
+        h2 o = __builtin_convertvector(y, h2);
+        if (BNF) o = __builtin_elementwise_max(o, zero);
+        return o;
+    };
+    auto build_tile = [&](const int par) __attribute__((always_inline)) {
+        const _Float16* const ip = ipg + par * NIPB;
+        const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        h8 x[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            x[j][0] = ip[va1[j]];
+            x[j][1] = ip[vb1[j] + 1]; x[j][2] = ip[vb1[j] + 2];
+            x[j][3] = ip[vb1[j] + IW]; x[j][4] = ip[vb1[j] + IW + 1]; x[j][5] = ip[vb1[j] + IW + 2];
+            x[j][6] = ip[vb1[j] + 2 * IW]; x[j][7] = ip[vb1[j] + 2 * IW + 1];
+        }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f32x4 s4[4], t4[4];                                     // BN scale / shift of this lane's 16 channels of the chunk
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg) {
+                const int cl = 32 * c + rg * 8 + half * 4;
+                s4[rg] = *reinterpret_cast<const f32x4*>(&prm1[64 + cl]);
+                t4[rg] = *reinterpret_cast<const f32x4*>(&prm1[128 + cl]);
+            }
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if ((wave + 4 * j) * 32 >= G::NPIX) continue;       // (wave-uniform)
+                const f32x16 d = __builtin_amdgcn_mfma_f32_32x32x16_f16(w1f[c], x[j], z16, 0, 0, 0);
+                // lane = pixel, register r = channel 32c + (r&3) + 8*(r>>2) + 4*half: quads of 4 consecutive channels
+#pragma unroll
+                for (int rg = 0; rg < 4; ++rg) {
+                    const h2 lo = act_nb(d[rg * 4], d[rg * 4 + 1], f32x2{s4[rg][0], s4[rg][1]}, f32x2{t4[rg][0], t4[rg][1]});
+                    const h2 hi = act_nb(d[rg * 4 + 2], d[rg * 4 + 3], f32x2{s4[rg][2], s4[rg][3]}, f32x2{t4[rg][2], t4[rg][3]});
+                    const h4 v = h4{lo[0], lo[1], hi[0], hi[1]};
+                    if (c == 0) { if (wa1[j] >= 0) *reinterpret_cast<h4*>(&lds[wa1[j] + rg * 8]) = v; }
+                    else keep1[j][rg] = v;
+                }
+            }
+        }
+    };
+    auto tile_chunk1 = [&]() __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            if ((wave + 4 * j) * 32 >= G::NPIX) continue;
+#pragma unroll
+            for (int rg = 0; rg < 4; ++rg)
+                if (wa1[j] >= 0) *reinterpret_cast<h4*>(&lds[wa1[j] + rg * 8]) = keep1[j][rg];
+        }
+    };
+    if constexpr (F1) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = 8 * half + e;
+                w1f[c][e] = k < 9 ? (_Float16)p.w1[k * 64 + 32 * c + li] : k == 9 ? (_Float16)p.b1[32 * c + li] : (_Float16)0.f;
+            }
+    }
+
     const int a_base = (((2 * wave) * G::MBH + li / MBW) * G::LW + (li % MBW)) * PSR + half * 8;
     constexpr int A_MB = G::MBH * G::LW * PSR;
     constexpr int RA = (NG == 2) ? 3 : 2;                // operand rings: fragments are fetched RA - 1 steps ahead (168 registers with three groups)
@@ -199,11 +334,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
     };
 
     Where cur = decode(item);
-    const _Float16* src = offsets(cur);
-    cur_pad = !goff_rel;
-#pragma unroll
-    for (int j = 0; j < G::NITER; ++j)
-        stg[j] = *reinterpret_cast<const h8*>(src + (goff[j] >= 0 ? goff[j] : 0));
+    const _Float16* src = nullptr;
     auto lds_write = [&]() __attribute__((always_inline)) {
 #pragma unroll
         for (int j = 0; j < G::NITER; ++j) {
@@ -218,7 +349,22 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
             }
         }
     };
-    lds_write();
+    int par = 0;                                               // F1: patch buffer of the current item
+    if constexpr (F1) {
+        patch_load(cur);
+        patch_write(0);
+        f1_offsets(cur);
+        if (item + stride < item_end) patch_load(decode(item + stride));
+        group_barrier(ctr, bar_target, lane);                  // patch visible to the group
+        build_tile(0);
+    } else {
+        src = offsets(cur);
+        cur_pad = !goff_rel;
+#pragma unroll
+        for (int j = 0; j < G::NITER; ++j)
+            stg[j] = *reinterpret_cast<const h8*>(src + (goff[j] >= 0 ? goff[j] : 0));
+        lds_write();
+    }
     group_barrier(ctr, bar_target, lane);
 
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -234,8 +380,10 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
         auto chunk_body = [&](auto c_tag) __attribute__((always_inline)) {
             constexpr int C = decltype(c_tag)::value;
             constexpr bool LAST = (C == 1);
-            const _Float16* in_next;
-            if (!LAST) {
+            const _Float16* in_next = nullptr;
+            if constexpr (F1) {
+                if (LAST && has_next) nxt = decode(item_next);
+            } else if (!LAST) {
                 in_next = cur_src + CKR;
             } else {
                 if (has_next) {
@@ -267,7 +415,12 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
                 __builtin_amdgcn_sched_barrier(0);
                 acc[0][1] = mma(af[s % RA][0], bf[s % RA][1], (Z && s == 0) ? zero16 : acc[0][1]);
                 __builtin_amdgcn_sched_barrier(0);
-                {
+                if constexpr (F1) {
+                    // the next item's image patch: registers -> LDS (the other patch buffer: last read two barriers ago), then
+                    // the patch of the item after it -> registers
+                    if (LAST && s == 2 && has_next) patch_write(par ^ 1);
+                    if (LAST && s == 4 && item_next + stride < item_end) patch_load(decode(item_next + stride));
+                } else {
                     const int j = s - S0;
                     if (s >= S0 && j < G::NITER)      // unconditional load: keeps the compiler's vmcnt counting exact
                         stg[j] = *reinterpret_cast<const h8*>(in_next + (goff[j] >= 0 ? goff[j] : 0));
@@ -285,8 +438,17 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
                 __builtin_amdgcn_sched_barrier(0);
             }
             group_barrier(ctr, bar_target, lane);              // this chunk's tile fully consumed by the group
-            if (LAST) cur_pad = nxt_pad;
-            if (!LAST || has_next) lds_write();                // staged registers are free again before the epilogue
+            if constexpr (F1) {
+                if (!LAST) {
+                    tile_chunk1();
+                } else if (has_next) {
+                    f1_offsets(nxt);
+                    build_tile(par ^ 1);
+                }
+            } else {
+                if (LAST) cur_pad = nxt_pad;
+                if (!LAST || has_next) lds_write();            // staged registers are free again before the epilogue
+            }
             if (!LAST) group_barrier(ctr, bar_target, lane);
         };
         chunk_body(std::integral_constant<int, 0>{});
@@ -382,10 +544,11 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
         group_barrier(ctr, bar_target, lane);                  // next item's tile complete
         item = item_next;
         cur = nxt;
+        par ^= 1;
     }
 }
 
-template <int MBW, bool POOL, int NG>
+template <int MBW, bool POOL, int NG, bool F1 = false>
 int launch_res(const ConvParamsH& p, hipStream_t s)
 {
     const long long nitems = (long long)p.B * p.tiles_x * p.tiles_y;
@@ -399,8 +562,8 @@ int launch_res(const ConvParamsH& p, hipStream_t s)
     // persistent workgroups, ONE per CU, each running NG groups (= virtual workgroups) over its XCD's share
     const unsigned grid = persistent_grid((nitems + NG - 1) / NG, p.ncu, p.xcd_shift);
     const ConvParamsH& pp = q;
-    if (p.bn_first) hipLaunchKernelGGL((conv_f16_res_kernel<MBW, POOL, true, NG>), dim3(grid), dim3(256 * NG), 0, s, pp);
-    else hipLaunchKernelGGL((conv_f16_res_kernel<MBW, POOL, false, NG>), dim3(grid), dim3(256 * NG), 0, s, pp);
+    if (p.bn_first) hipLaunchKernelGGL((conv_f16_res_kernel<MBW, POOL, true, NG, F1>), dim3(grid), dim3(256 * NG), 0, s, pp);
+    else hipLaunchKernelGGL((conv_f16_res_kernel<MBW, POOL, false, NG, F1>), dim3(grid), dim3(256 * NG), 0, s, pp);
     return 0;
 }
 
@@ -415,6 +578,12 @@ bool conv_f16_res_supports(const ConvParamsH& p, int taps)
 int launch_conv_f16_res(const ConvParamsH& p, int mbw, bool pool, hipStream_t s)
 {
     static const int ng = [] { const char* e = getenv("MP_F16_RES_GROUPS"); return (e && e[0] == '2') ? 2 : 3; }();
+    if (p.img) {           // first encoder block fused in: the pooled 64 -> 64 layer (enc.conv2), reflection padding
+        if (!pool || p.pad_zero) return 2;
+        if (mbw == 32) return launch_res<32, true, 2, true>(p, s);
+        if (mbw == 16) return launch_res<16, true, 2, true>(p, s);
+        return launch_res<8, true, 2, true>(p, s);
+    }
     if (ng == 2) {
         if (mbw == 32) return pool ? launch_res<32, true, 2>(p, s) : launch_res<32, false, 2>(p, s);
         if (mbw == 16) return pool ? launch_res<16, true, 2>(p, s) : launch_res<16, false, 2>(p, s);

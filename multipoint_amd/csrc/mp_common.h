@@ -133,6 +133,10 @@ struct ConvParamsH {
     int nitems;           // work items (tile, slice) of the launch (filled in by the launcher)
     _Float16* dummy;      // >= 1 KiB scratch line that masked-off store lanes write to
     int ncu, xcd_shift;   // machine shape, as in ConvParams
+    // conv_f16_res.hip with the first encoder block fused in: the fp32 image [B][H][W] and the Cin = 1 layer's parameters
+    // ([9][64] tap-major fp16-representable weights, bias, BN scale / shift); img == nullptr: p.in is read
+    const float* img;
+    const float *w1, *b1, *s1, *t1;
 };
 struct Conv1ParamsH {
     const float* in;      // [B][H][W] fp32 image (rounded to fp16 on load)

@@ -206,3 +206,30 @@ def test_f16_forward_against_reference_autocast_fixture(oracle, golden_dir, f16,
     assert ps['median_abs_rel'] <= 1e-2 and ps['p999_abs_rel'] <= 5e-2, ps
     assert S.unbiased(ps), ps
     assert np.abs(v['prob'][0] - v['prob'][1]).max() <= PROB_TOL_F16
+
+
+@pytest.mark.parametrize('env', [{'MP_F16_NO_FUSE1': '1'}, {'MP_F16_NO_RES': '1'}, {'MP_F16_RES_GROUPS': '2'}])
+@pytest.mark.parametrize('upd', [{}, {'bn_first': True}, {'multispectral': True}])
+@pytest.mark.parametrize('B,H,W', [(3, 72, 104), (2, 16, 16), (1, 240, 320), (2, 480, 640), (5, 40, 264)])
+def test_f16_kernel_variants_agree(oracle, monkeypatch, env, upd, B, H, W):
+    """The default fp16 path (64 -> 64 layers on the LDS-resident-weights kernel, three groups per CU, the first encoder block
+    evaluated inside the conv2 launch on the matrix pipe) against: the first block as its own launch (MP_F16_NO_FUSE1), the
+    streaming kernel on every layer (MP_F16_NO_RES), two groups per CU -- same rounding points, fp32 accumulation in another
+    order, so the outputs agree to rounding flips: borders (two nested reflections), partial tiles (all three tile shapes),
+    bn_first, two encoders.  Both sides also match the fp16 oracle."""
+    from oracle import f16_stats as S
+    img = oracle.make_images(41 + W, B, H, W)
+    flags = torch.tensor([[i % 2 == 0] for i in range(B)])
+    net, sd, cfg = _net(oracle, upd, seed=5)
+    a = net({'image': img.cuda(), 'is_optical': flags})
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    net2, _, _ = _net(oracle, upd, seed=5)
+    b = net2({'image': img.cuda(), 'is_optical': flags})
+    ref = oracle.forward(sd, img, cfg, is_optical=flags)
+    for out in (a, b):
+        assert (out['prob'].cpu() - ref['prob']).abs().max().item() <= PROB_TOL_F16
+        assert (out['desc'].cpu() - ref['desc']).abs().max().item() <= DESC_TOL_F16
+    ds = S.desc_stats(a['desc'].cpu().numpy(), b['desc'].cpu().numpy(), channel_axis=1)
+    assert ds['median'] <= 0.5 and ds['p999'] <= 4.0 and ds['max'] <= 8.0, ds
+    assert (a['prob'] - b['prob']).abs().max().item() <= PROB_TOL_F16
