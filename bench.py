@@ -242,7 +242,7 @@ def main():
         cfg['mixed_precision'] = True
     sd = make_weights(0, cfg)
     net = models.MultiPoint(cfg); net.load_state_dict(sd); net.to(device); net.eval()
-    pipe = PairPipeline(net, PRED, capacity=PRED['topk'], nms_rounds=8)
+    pipe = PairPipeline(net, PRED, capacity=PRED['topk'], nms_rounds=int(os.environ.get('MP_BENCH_NMS_ROUNDS', '8')))   # (developer A/B only)
     P = args.pairs_per_gpu
     pair_ids = shard_pairs(P * world, rank, world)              # pair p -> rank p mod world
     images = make_batch(pair_ids, device, H, W)
@@ -341,13 +341,25 @@ def main():
         ms = float(np.sum([m for m, _ in dom])) / args.steps / n_launch
         flop = float(np.sum([f for _, f in dom])) / args.steps / n_launch       # algorithmic FLOPs of the launch
         fused = 'enc.conv1+2' in by_name
-        conv2_flop = 2.0 * 9 * 64 * 64 * H * W * 2 * P          # the MFMA part of a fused conv1+conv2 launch
+        conv2_flop = 2.0 * 9 * 64 * 64 * H * W * 2 * P          # the conv2 part of a fused conv1+conv2 launch
         peak = PEAK_FP16_MFMA_TFLOPS if c5 else PEAK_FP32_MFMA_TFLOPS
         if c5:
-            issued = flop
-            inst = 'conv_f16_kernel<9,32,true,false>'
-            kernel = ('conv_f16_kernel<9,32,true,false> (enc.conv2 64->64 @1024x1280 on v_mfma_f32_32x32x16_f16 + bias/ReLU/BN '
-                      '+ 2x2 max-pool)')
+            res = os.environ.get('MP_F16_NO_RES') != '1'
+            if fused:
+                # first block inside the launch: per 8 x 32-pixel item 11 blocks of 32 tile pixels x 2 chunks of 32 channels, one
+                # v_mfma_f32_32x32x16_f16 (32768 FLOP, K = 9 taps + bias padded to 16) each
+                items = 2 * P * ((H + 7) // 8) * ((W + 31) // 32)
+                issued = conv2_flop + items * 22 * 32768.0
+                inst = 'conv_f16_res_kernel<32,true,false,2,true>'
+                kernel = ('conv_f16_res_kernel<32,true,false,2,true> (encoder conv1 -- Cin = 1, evaluated per item on the matrix pipe '
+                          'straight into the LDS activation tile -- fused into enc.conv2 64->64 @1024x1280 on '
+                          'v_mfma_f32_32x32x16_f16 with the layer\'s 72 KiB of weights resident in LDS, + bias/ReLU/BN + 2x2 max-pool)')
+            else:
+                issued = flop
+                inst = 'conv_f16_res_kernel<32,true,false,3,false>' if res else 'conv_f16_kernel<9,32,true,false>'
+                kernel = inst + (' (enc.conv2 64->64 @1024x1280 on v_mfma_f32_32x32x16_f16, %s, + bias/ReLU/BN + 2x2 max-pool)'
+                                 % ('weights resident in LDS, three groups of four waves per CU' if res else
+                                    'weights streamed through the vector L1 per wave'))
         elif not wino:
             issued = conv2_flop if fused else flop              # the fused first block (Cin = 1) runs on the vector ALU
             inst = 'conv_mfma_kernel<9,32,true,true,false>' if fused else 'conv_mfma_persist_kernel<9,32,true,false>'

@@ -76,7 +76,13 @@ __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work
 
     if (tid < 2) cnt[tid] = 0;
     __syncthreads();
-    for (int f = tid; f < LW * LW; f += 256) {
+    auto place = [&](int f, float v) __attribute__((always_inline)) {
+        const int ly = f / LW, lx = f - ly * LW;
+        t[f] = v;
+        if (v > 0.f && ly >= R && ly < R + NT && lx >= R && lx < R + NT)
+            list[0][atomicAdd(&cnt[0], 1)] = (unsigned short)f;
+    };
+    auto fetch = [&](int f) __attribute__((always_inline)) -> float {
         const int ly = f / LW, lx = f - ly * LW;
         const int gy = y0 + ly - R, gx = x0 + lx - R;
         float v = 0.f;
@@ -90,9 +96,19 @@ __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work
                 v = work[gi];
             }
         }
-        t[f] = v;
-        if (v > 0.f && ly >= R && ly < R + NT && lx >= R && lx < R + NT)
-            list[0][atomicAdd(&cnt[0], 1)] = (unsigned short)f;
+        return v;
+    };
+    if constexpr (RT > 0) {
+        // the tile + halo is (NT + 2 RT)^2 values, a fixed number per thread: ALL loads are issued before the first value is
+        // used (the kernel is latency-bound: one trip to memory per workgroup instead of one per loop iteration)
+        constexpr int LWC = NT + 2 * RT, NL = (LWC * LWC + 255) / 256;
+        float v[NL];
+#pragma unroll
+        for (int k = 0; k < NL; ++k) { const int f = tid + k * 256; v[k] = f < LWC * LWC ? fetch(f) : 0.f; }
+#pragma unroll
+        for (int k = 0; k < NL; ++k) { const int f = tid + k * 256; if (f < LWC * LWC) place(f, v[k]); }
+    } else {
+        for (int f = tid; f < LW * LW; f += 256) place(f, fetch(f));
     }
     __syncthreads();
 
