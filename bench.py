@@ -344,7 +344,7 @@ def main():
         conv2_flop = 2.0 * 9 * 64 * 64 * H * W * 2 * P          # the conv2 part of a fused conv1+conv2 launch
         peak = PEAK_FP16_MFMA_TFLOPS if c5 else PEAK_FP32_MFMA_TFLOPS
         if c5:
-            res = os.environ.get('MP_F16_NO_RES') != '1'
+            res_kernel = os.environ.get('MP_F16_NO_RES') != '1'
             if fused:
                 # first block inside the launch: per 8 x 32-pixel item 11 blocks of 32 tile pixels x 2 chunks of 32 channels, one
                 # v_mfma_f32_32x32x16_f16 (32768 FLOP, K = 9 taps + bias padded to 16) each
@@ -356,9 +356,9 @@ def main():
                           'v_mfma_f32_32x32x16_f16 with the layer\'s 72 KiB of weights resident in LDS, + bias/ReLU/BN + 2x2 max-pool)')
             else:
                 issued = flop
-                inst = 'conv_f16_res_kernel<32,true,false,3,false>' if res else 'conv_f16_kernel<9,32,true,false>'
+                inst = 'conv_f16_res_kernel<32,true,false,3,false>' if res_kernel else 'conv_f16_kernel<9,32,true,false>'
                 kernel = inst + (' (enc.conv2 64->64 @1024x1280 on v_mfma_f32_32x32x16_f16, %s, + bias/ReLU/BN + 2x2 max-pool)'
-                                 % ('weights resident in LDS, three groups of four waves per CU' if res else
+                                 % ('weights resident in LDS, three groups of four waves per CU' if res_kernel else
                                     'weights streamed through the vector L1 per wave'))
         elif not wino:
             issued = conv2_flop if fused else flop              # the fused first block (Cin = 1) runs on the vector ALU

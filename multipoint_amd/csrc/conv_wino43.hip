@@ -92,23 +92,35 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(
 
 // Packed fp32 arithmetic as explicit instructions: hipcc scalarises a third of the transform's packed multiply-adds (4 v_fma_f32
 // for 2 v_pk_fma_f32 per pass), and next to an MFMA stream every vector instruction costs matrix-pipe time.
-// The transform coefficients come in scalar register pairs (the value in both halves; VOP3P takes no literal on gfx950).
-constexpr unsigned long long pk_const(double v)
+// The transform coefficients come in scalar register pairs (VOP3P takes no literal on gfx950).
+// Two coefficients share one scalar register pair (low / high half, picked by op_sel: the selected half feeds both lanes), so the
+// six coefficients of the input transform occupy three pairs instead of six (SGPRs are what the fused-first-block instantiation
+// is shortest of).
+constexpr unsigned long long pk_const2(double lo, double hi)
 {
-    return (unsigned long long)__builtin_bit_cast(unsigned, (float)v) * 0x100000001ull;
+    return (unsigned long long)__builtin_bit_cast(unsigned, (float)lo) | ((unsigned long long)__builtin_bit_cast(unsigned, (float)hi) << 32);
 }
 constexpr double W43A = MP_W43_A, W43B = MP_W43_B;                  // interpolation points {0, +-a, +-b, inf} (mp_common.h)
-constexpr unsigned long long K_A = pk_const(W43A), K_B = pk_const(W43B), K_A2 = pk_const(W43A * W43A), K_B2 = pk_const(W43B * W43B),
-                             K_P = pk_const(W43A * W43A * W43B * W43B), K_S = pk_const(W43A * W43A + W43B * W43B);
+constexpr unsigned long long K_AB = pk_const2(W43A, W43B), K_A2B2 = pk_const2(W43A * W43A, W43B * W43B),
+                             K_PS = pk_const2(W43A * W43A * W43B * W43B, W43A * W43A + W43B * W43B);
 static_assert((double)(float)(W43A * W43A * W43B * W43B) == W43A * W43A * W43B * W43B && (double)(float)(W43A * W43A + W43B * W43B) ==
               W43A * W43A + W43B * W43B, "the transform coefficients must be exact in fp32");
+// HI = 0: the low half of k, 1: the high half
+template <int HI>
 __device__ __forceinline__ f32x2 pk_fma_k(f32x2 a, unsigned long long k, f32x2 c)      // a * k + c
 {
-    f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c)); return d;
+    f32x2 d;
+    if (HI) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(d) : "v"(a), "s"(k), "v"(c));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(d) : "v"(a), "s"(k), "v"(c));
+    return d;
 }
+template <int HI>
 __device__ __forceinline__ f32x2 pk_fnma_k(f32x2 a, unsigned long long k, f32x2 c)     // c - a * k
 {
-    f32x2 d; asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "s"(k), "v"(c)); return d;
+    f32x2 d;
+    if (HI) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "s"(k), "v"(c));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(d) : "v"(a), "s"(k), "v"(c));
+    return d;
 }
 // 1-D input transform B^T d (6 -> 6), packed over two channels: 12 multiply-adds.  Row of point p = the coefficients of
 // x (x^2 - a^2)(x^2 - b^2) / (x - p), last row the polynomial itself:
@@ -120,16 +132,16 @@ __device__ __forceinline__ void bt6(const f32x2 d[6], f32x2 r[6])
     for (int i = 0; i < 6; ++i) r[i] = d[i];        // timing only: no arithmetic
     return;
 #endif
-    const f32x2 t0 = pk_fnma_k(d[2], K_B2, d[4]);       // d4 - b^2 d2      (even part of the +-a rows)
-    const f32x2 t1 = pk_fnma_k(d[1], K_B2, d[3]);       // d3 - b^2 d1      (odd part / a)
-    const f32x2 t2 = pk_fnma_k(d[2], K_A2, d[4]);       // d4 - a^2 d2      (+-b rows)
-    const f32x2 t3 = pk_fnma_k(d[1], K_A2, d[3]);       // d3 - a^2 d1
-    r[0] = pk_fma_k(d[0], K_P, pk_fnma_k(d[2], K_S, d[4]));      // a^2 b^2 d0 + (d4 - (a^2+b^2) d2)
-    r[1] = pk_fma_k(t1, K_A, t0);                       // t0 + a t1
-    r[2] = pk_fnma_k(t1, K_A, t0);                      // t0 - a t1
-    r[3] = pk_fma_k(t3, K_B, t2);                       // t2 + b t3
-    r[4] = pk_fnma_k(t3, K_B, t2);                      // t2 - b t3
-    r[5] = pk_fma_k(d[1], K_P, pk_fnma_k(d[3], K_S, d[5]));      // a^2 b^2 d1 + (d5 - (a^2+b^2) d3)
+    const f32x2 t0 = pk_fnma_k<1>(d[2], K_A2B2, d[4]);      // d4 - b^2 d2      (even part of the +-a rows)
+    const f32x2 t1 = pk_fnma_k<1>(d[1], K_A2B2, d[3]);      // d3 - b^2 d1      (odd part / a)
+    const f32x2 t2 = pk_fnma_k<0>(d[2], K_A2B2, d[4]);      // d4 - a^2 d2      (+-b rows)
+    const f32x2 t3 = pk_fnma_k<0>(d[1], K_A2B2, d[3]);      // d3 - a^2 d1
+    r[0] = pk_fma_k<0>(d[0], K_PS, pk_fnma_k<1>(d[2], K_PS, d[4]));      // a^2 b^2 d0 + (d4 - (a^2+b^2) d2)
+    r[1] = pk_fma_k<0>(t1, K_AB, t0);                       // t0 + a t1
+    r[2] = pk_fnma_k<0>(t1, K_AB, t0);                      // t0 - a t1
+    r[3] = pk_fma_k<1>(t3, K_AB, t2);                       // t2 + b t3
+    r[4] = pk_fnma_k<1>(t3, K_AB, t2);                      // t2 - b t3
+    r[5] = pk_fma_k<0>(d[1], K_PS, pk_fnma_k<1>(d[3], K_PS, d[5]));      // a^2 b^2 d1 + (d5 - (a^2+b^2) d3)
 }
 // 1-D output transform A^T m (6 -> 4), packed over two output channels.  A^T[i][p] = p^i:
 //   [1 1 1 1 1 0; 0 a -a b -b 0; 0 a^2 a^2 b^2 b^2 0; 0 a^3 -a^3 b^3 -b^3 1]

@@ -58,3 +58,33 @@ def test_conv_families_on_trained_like_statistics(oracle, sev, variant):
         assert s['keypoints_differing'] <= 0.01 * s['keypoints_total'], s
     else:
         assert s['keypoints_differing'] <= 0.08 * s['keypoints_total'], s
+
+
+def test_f16_path_on_trained_like_statistics(oracle):
+    """The fp16 MFMA path (mixed_precision) on the 'mild' trained-like weights and structured images: nothing overflows fp16,
+    and the HIP path stays within the fp16 noise floor of the oracle's autocast restatement -- measured, as everywhere for this
+    mode, in fp16 steps of the quantity the network rounds (tests/test_gpu_f16.py).  The wider activation range of calibrated
+    BatchNorm statistics (|gamma| up to 3, running_var over three decades) is what distinguishes this from the benign case."""
+    import numpy as np
+    import torch
+    import multipoint_amd.models as M
+    from oracle import trained_like as T
+    from oracle import f16_stats as S
+    cfg32 = dict(oracle.SHIPPED_MODEL_CONFIG)
+    sd = T.trained_like_weights(11, cfg32, **T.SEVERITIES['mild'])
+    img = T.structured_images(14, 2, 240, 320)
+    cfg = dict(cfg32); cfg['mixed_precision'] = True
+    ref = oracle.forward(sd, img, cfg)
+    ref_l = oracle.forward(sd, img, cfg, return_logits=True)['logits']
+    assert torch.isfinite(ref['desc']).all() and torch.isfinite(ref_l).all()
+    net = M.MultiPoint(dict(cfg)); net.load_state_dict(sd); net.to('cuda'); net.eval()
+    out = net({'image': img.cuda()})
+    net.set_force_return_logits(True)
+    lg = net({'image': img.cuda()})['logits'].cpu().numpy()
+    assert np.isfinite(lg).all() and torch.isfinite(out['desc']).all() and torch.isfinite(out['prob']).all()
+    ls = S.logits_stats(lg, ref_l.numpy())
+    ds = S.desc_stats(out['desc'].cpu().numpy(), ref['desc'].numpy(), channel_axis=1)
+    print('\n[f16 trained-like mild] logits %s\n desc %s' % (ls, ds))
+    assert ls['median'] <= 1.0 and ls['p999'] <= 8.0, ls
+    assert ds['median'] <= 1.0 and ds['p999'] <= 8.0, ds
+    assert abs(ls['mean_signed']) <= 0.05 * ls['mean_abs'] and abs(ds['mean_signed']) <= 0.05 * ds['mean_abs'], (ls, ds)
