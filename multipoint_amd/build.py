@@ -43,7 +43,7 @@ def check_dma_hazards(asm_path, wait_states=5):
     lines = open(asm_path).read().split('\n')
     n = 0
     for i, l in enumerate(lines):
-        m = re.search(r'global_load_lds_dwordx4 v\d+, s\[(\d+):(\d+)\]', l)
+        m = re.search(r'global_load_lds_dword(?:x4)? v\d+, s\[(\d+):(\d+)\]', l)
         if not m:
             continue
         n += 1

@@ -63,7 +63,6 @@ struct mp_handle {
     DevBuf ws2;                     // NMS work map + kept lists
     DevBuf ws3;                     // matching arg-min arrays
     DevBuf ws4;                     // pair metrics: warped keypoints + inverse match map
-    DevBuf fuse43_ws;               // conv_wino43.hip with the first block fused in: per-workgroup patch scratch (80 MB)
     DevBuf nms_state;               // 64 round counters + tile flags
     DevBuf kp_scratch;              // segment counts + list totals of the keypoint compaction
     int* nms_total = nullptr;       // device: undecided candidates summed over all calls since the last read
@@ -558,11 +557,6 @@ int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, 
         p.total_px = (long long)B * H * W;
     }
     const bool f43 = uses_wino43(h, L, H, W, fuse != nullptr, in_cstride, in_coff, out_cstride, out_coff);
-    if (f43 && fuse) {              // (allocations before prof_begin: a failure must not leave an open profile entry)
-        int rc;
-        if ((rc = ensure(h, h->fuse43_ws, conv_wino43_scratch_floats(h->ncu) * 4))) return rc;
-        p.scratch = static_cast<float*>(h->fuse43_ws.p);
-    }
     prof_begin(h, fuse ? "enc.conv1+2" : L.name,
                2.0 * L.taps * L.cin * L.cout * (double)B * H * W + (fuse ? 2.0 * 9 * 64 * (double)B * H * W : 0.0), s);
     if (fuse) { p.img = images; p.w1 = fuse->w; p.b1 = fuse->bias; p.s1 = fuse->scale; p.t1 = fuse->shift; }
@@ -872,7 +866,6 @@ void mp_destroy(mp_handle* h)
     if (h->ws2.p) (void)hipFree(h->ws2.p);
     if (h->ws3.p) (void)hipFree(h->ws3.p);
     if (h->ws4.p) (void)hipFree(h->ws4.p);
-    if (h->fuse43_ws.p) (void)hipFree(h->fuse43_ws.p);
     if (h->nms_state.p) (void)hipFree(h->nms_state.p);
     if (h->kp_scratch.p) (void)hipFree(h->kp_scratch.p);
     if (h->nms_total) (void)hipFree(h->nms_total);

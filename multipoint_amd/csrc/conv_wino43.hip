@@ -61,7 +61,7 @@ namespace {
 // an item's 32 tiles are 4 rows x 8 columns (16 x 32 output pixels, raw patch 18 x 34) or -- TC4 = 4 -- 8 rows x 4 columns (32 x 16
 // pixels, patch 34 x 18): launch_q picks the shape with fewer phantom tiles (60 x 80 layers: 8 instead of 12 items per image)
 constexpr int NPIX = 18 * 34;                      // 612 patch pixels = 16-byte granules (4 channels each), either shape
-constexpr int NPIXP = 624;                         // ... rounded up to blocks of 16: the plane stride of the fused first block's scratch
+constexpr int NPIXP = 624;                         // ... rounded up to blocks of 16
 constexpr int UC4 = 4;                             // input channels per unit
 constexpr int VB4 = UC4 * 32 * 36;                 // floats per V buffer  [ch][tile][pos]   (18 KiB)
 constexpr int UB4 = UC4 * 64 * 36;                 // floats per U buffer  [ch][cout][pos]   (36 KiB)
@@ -85,6 +85,13 @@ __device__ __forceinline__ void dma16(const float* sbase, unsigned voff_bytes, u
     if (MPQX & 2) return;
     unsigned keep;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff_bytes), "s"(sbase), "s"(lds_byte) : "memory");
+}
+// 4 bytes per lane: 64 lanes x 4 bytes from (uniform base + per-lane byte offset) to LDS [lds_byte + 4 * lane, + 4)
+__device__ __forceinline__ void dma4(const float* sbase, unsigned voff_bytes, unsigned lds_byte)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff_bytes), "s"(sbase), "s"(lds_byte) : "memory");
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -157,10 +164,15 @@ __device__ __forceinline__ void at6(const f32x2 m[6], f32x2 y[4])
 }
 
 // F1: the layer's input is the first encoder block (Cin = 1 -> 64, conv_first.hip's arithmetic) of p.img, computed by this
-// kernel itself: at the start of an item the workgroup evaluates the block on the NEXT item's 18 x 34 patch (vector pipe, no
-// MFMAs in flight: ~5 k cycles of an item's ~60 k) and parks the result in its own global scratch, patch order, channel quads
-// planar -- the unit loop then DMAs its raw patches from there (L2 / Infinity Cache hits, 1 KiB contiguous per instruction,
-// no reflection cases) instead of from a 5 GB tensor that a separate HBM-write-bound launch would have to produce.
+// kernel itself, PER UNIT and straight into the raw LDS ring (round 3; round 2 evaluated it per item into a global scratch that
+// the unit loop DMA'd back: 12 GB of fabric traffic per launch and a phase of 11 k cycles per item with the matrix pipe idle --
+// an L2-resident scratch would have been 7 % faster, the phase-free bound 22 %).  While unit n is multiplied, the 4 channels of
+// unit n + 2 are produced for the item's 18 x 34 patch by v_mfma_f32_4x4x1_16b_f32: 16 blocks of D[4 channels][4 pixels] +=
+// W[4][1] X[1][4] per instruction, nine taps = nine instructions per 64 pixels, the bias as the accumulator's initial value.  A
+// lane supplies ITS pixel's tap value (gathered from a 20 x 36 fp32 image patch in LDS whose rows and columns are staged
+// already reflected) and the weight of channel lane & 3, and receives the 4 channels of its own pixel -- exactly one raw
+// granule, written after ReLU / BatchNorm with one ds_write_b128.  Nothing of the block ever leaves the CU; the image patch of
+// item k + 2 arrives by 4-byte LDS-DMA during the epilogue of item k.
 template <bool POOL, bool BNF, int TC4, bool F1>
 __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
 {
@@ -173,7 +185,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     __shared__ __attribute__((aligned(16))) float raw[3 * RB4 + 256];
     __shared__ __attribute__((aligned(16))) float scr[8 * SW4];
     __shared__ __attribute__((aligned(16))) float prm[3 * 64];
-    __shared__ float w1s[F1 ? 9 * 64 : 1];               // F1: the first block's weights [tap][channel], loaded once
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -207,20 +218,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
 
     // ---- raw patch staging by DMA: granule f = block * 64 + lane = patch pixel f; this wave issues blocks wave, wave + 8 ----
     const int pix_stride = p.in_planar ? 4 : p.in_cstride;              // floats between horizontally adjacent pixels
-    const long long unit_stride = F1 ? NPIXP * 4 : p.in_planar ? (long long)p.H * p.W * 4 : UC4;     // floats between consecutive units
+    const long long unit_stride = p.in_planar ? (long long)p.H * p.W * 4 : UC4;     // floats between consecutive units
     unsigned rvoff[2];            // byte offset of the granule's source pixel (channel 0 of the unit)
     bool roff_rel = false;        // rvoff holds the item-invariant offsets of interior items
-    int ld_par = 0;                   // F1: scratch buffer (item parity) of the cursor's item
-    float* const sbase = F1 ? p.scratch + (long long)blockIdx.x * (2 * 16 * NPIXP * 4) : nullptr;
     auto raw_offsets = [&](const Where& w) __attribute__((always_inline)) -> const float* {
-        if (F1) {                     // patch order in the scratch: granule f at byte 16 f of the unit's plane
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int f = (wave + 8 * j) * 64 + lane;
-                rvoff[j] = (f < NPIX) ? (unsigned)f * 16u : 0u;
-            }
-            return sbase + ld_par * (16 * NPIXP * 4);
-        }
         const bool interior = (w.y0 >= 1) && (w.y0 + OY < p.H) && (w.x0 >= 1) && (w.x0 + OX < p.W);
         if (interior) {
             if (!roff_rel) {
@@ -373,109 +374,150 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     const int b_base = ((lane >> 4) * 32 + tb * 16 + (lane & 15)) * 36;    // V[ch = lane>>4][tile][pos]
     f32x4 af[3], bf[3];                                                     // rings over position groups of 4
 
-    // ---- F1: the first encoder block on an item's patch -> scratch[par] ----
-    // Patch pixel (py, px) is the block's output at (reflect(y0 + py - 1), reflect(x0 + px - 1)) -- THIS layer's reflection
-    // padding -- whose own 3x3 window reads the image with the block's reflection padding: the image patch staged in LDS
-    // holds rows reflect(y0 - 2 + r), so a window is always three consecutive staged rows / columns.
-    // The block is a GEMM D[channel][pixel] = W[channel][tap] * X[tap][pixel] with K = 9 taps padded to 12 on the matrix pipe,
-    // which idles between two unit loops (the vector form cost 15 k cycles per item): per block of 16 pixels and 16 channels
-    // three v_mfma_f32_16x16x4_f32; a lane gathers its pixel's taps k = 4j + lane/16 from the LDS image, and the result
-    // registers of a lane are 4 consecutive channels of one pixel = one 16-byte store into the quad-planar scratch.
-    // (Same products as conv_first.hip, summed by the MFMA in its own order: equal to the standalone launch to 1-2 ulp.)
-    const int c1_kg = lane >> 4, c1_lp = lane & 15;
-#ifdef MP_TIMING
-    unsigned long long c1_t1 = 0;
-#endif
-    // the image patch of an item, 720 pixels = 2 per thread: loaded into registers one epilogue ahead of the phase that stages
-    // them (they are first-touch HBM misses: 2-4 k cycles nothing else of the phase could hide)
-    float c1_px0 = 0.f, c1_px1 = 0.f;
-    auto conv1_load = [&](const Where& w) __attribute__((always_inline)) {
-        constexpr int IW = PX + 2, IH = PY + 2;
-        const float* const im = p.img + (long long)w.img * p.H * p.W;
-        { const int r = tid / IW, c = tid - r * IW;
-          c1_px0 = im[reflect_clamp_q(w.y0 + r - 2, p.H) * p.W + reflect_clamp_q(w.x0 + c - 2, p.W)]; }
-        if (tid + 512 < IH * IW) {
-            const int f = tid + 512, r = f / IW, c = f - r * IW;
-            c1_px1 = im[reflect_clamp_q(w.y0 + r - 2, p.H) * p.W + reflect_clamp_q(w.x0 + c - 2, p.W)];
-        }
-    };
-    auto conv1_item = [&](const Where& w, int par) __attribute__((always_inline)) {
-        constexpr int IW = PX + 2, IH = PY + 2;
-        float* const ip = scr;                                    // the transform scratch is idle between two unit loops:
-        float* const wl = scr + 768;                              // image patch (720 floats + a zero) + bias, scale, shift [3][64]
-        ip[tid] = c1_px0;
-        if (tid + 512 < IH * IW) ip[tid + 512] = c1_px1;
-        if (tid == 0) ip[IH * IW] = 0.f;                          // what the padding taps 9..11 read
-        if (tid < 192) wl[tid] = tid < 64 ? p.b1[tid] : tid < 128 ? p.s1[tid - 64] : p.t1[tid - 128];
-        // A operand: weights of tap k = 4j + lane/16 (0 beyond tap 8), channel 16 * block + lane % 16
-        float wa[4][3];
-        int toff[3];                                              // tap k's offset inside a window (the zero cell for the padding taps)
+    // ---- F1: the first encoder block, produced per unit into the raw ring ----
+    // LDS: the raw ring needs only TWO buffers here (nothing is in flight from memory); the third buffer's 10 KiB hold two image
+    // patches (item k's and item k+1's: 20 x 36 fp32, rows / columns already reflected) and bias | BN scale | BN shift per unit;
+    // w1s holds the weights as [unit][tap][channel of the unit].
+    constexpr int IW1 = PX + 2, IH1 = PY + 2;                 // image patch: the receptive field of the 18 x 34 raw patch
+    constexpr int IPB = 768;                                  // floats per patch buffer (IH1 * IW1 = 720, rounded up to whole 64-lane DMA blocks)
+    static_assert(!F1 || (IH1 * IW1 <= IPB && 2 * IPB + 16 * 12 + 16 * 4 * 12 <= RB4), "F1: patches + parameters + weights must fit the third raw buffer");
+    const unsigned ip_lds = raw_lds + 2u * RB4 * 4u;          // ipatch[2][IPB]
+    const unsigned bst_lds = ip_lds + 2u * IPB * 4u;          // bst[16][bias4 | scale4 | shift4]
+    const unsigned w1_lds = bst_lds + 16u * 12u * 4u;         // w1u[16 units][4 channels][12: taps 0..8, 3 unused]
+    typedef const __attribute__((address_space(3))) float* lds_f32_ptr;
+    typedef const __attribute__((address_space(3))) f32x4* lds_f32x4_ptr;
+    typedef __attribute__((address_space(3))) f32x4* lds_f32x4_wptr;
+    // this lane's pixels: granule f = (wave + 8 j) * 64 + lane (j = 1: waves 0, 1 only).  pg_x: absolute LDS byte address of the
+    // pixel's window origin in the CURSOR item's patch buffer; pg_w: byte offset of the granule in a raw buffer (granules 612..639
+    // of the last block land in the buffer's slack, never read)
+    unsigned pg_x[2] = {0u, 0u}, pg_w[2] = {0u, 0u};
+    bool pg_rel = false;
+    int pc_par = 0;                                           // patch buffer of the cursor's item
+    auto prod_offsets = [&](const Where& w) __attribute__((always_inline)) {
+        const bool interior = (w.y0 >= 1) && (w.y0 + OY < p.H) && (w.x0 >= 1) && (w.x0 + OX < p.W);     // no reflection anywhere in the patch
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int k = 4 * j + c1_kg;
-            toff[j] = k < 9 ? (k / 3) * IW + (k % 3) : -1;
-#pragma unroll
-            for (int cbk = 0; cbk < 4; ++cbk) wa[cbk][j] = k < 9 ? w1s[k * 64 + cbk * 16 + c1_lp] : 0.f;
-        }
-        __syncthreads();
-#ifdef MP_TIMING
-        c1_t1 = __builtin_amdgcn_s_memtime();
-#endif
-        float* const S = sbase + par * (16 * NPIXP * 4);
-        // (one block at a time: the GEMM loop's state stays in registers across this phase, there is room for little else)
-        const bool inner = (w.y0 >= 1) && (w.y0 + OY < p.H) && (w.x0 >= 1) && (w.x0 + OX < p.W);     // no reflection anywhere in the patch
-        char* const Sb = reinterpret_cast<char*>(S);
-#pragma unroll 1
-        for (int blk = wave; blk < NPIXP / 16; blk += 8) {
-            const int f = blk * 16 + c1_lp;
+        for (int j = 0; j < 2; ++j) {
+            const int f = (wave + 8 * j) * 64 + lane;
             const int fc = f < NPIX ? f : NPIX - 1;
             const int py = fc / PX, px = fc - py * PX;
-            int o = py * IW + px;
-            if (!inner) {
-                int ly = reflect_clamp_q(w.y0 + py - 1, p.H) - w.y0 + 1, lx = reflect_clamp_q(w.x0 + px - 1, p.W) - w.x0 + 1;
-                ly = min(max(ly, 0), IH - 3); lx = min(max(lx, 0), IW - 3);      // (only pixels of phantom outputs are clamped)
-                o = ly * IW + lx;
+            int oy = py, ox = px;
+            if (!interior) {
+                // the raw pixel is the block's output at the frame position reflected by THIS layer's padding; its window starts
+                // one row / column before it, and staged row r holds image row reflect(y0 - 2 + r)
+                oy = reflect_clamp_q(w.y0 + py - 1, p.H) - w.y0 + 1; ox = reflect_clamp_q(w.x0 + px - 1, p.W) - w.x0 + 1;
+                oy = min(max(oy, 0), IH1 - 3); ox = min(max(ox, 0), IW1 - 3);      // (only pixels of phantom outputs are clamped)
             }
-            float xb[3];
+            pg_x[j] = ip_lds + (unsigned)(pc_par * IPB + oy * IW1 + ox) * 4u;
+            pg_w[j] = (unsigned)f * 16u;
+        }
+        pg_rel = interior;
+    };
+    // image patch of item w -> patch buffer par: 720 pixels, one 4-byte DMA granule each (waves 0..3 issue two blocks)
+    auto patch_dma = [&](const Where& w, int par) __attribute__((always_inline)) {
+        const float* const im = p.img + (long long)w.img * p.H * p.W;
 #pragma unroll
-            for (int j = 0; j < 3; ++j) xb[j] = ip[toff[j] >= 0 ? o + toff[j] : IH * IW];
+        for (int j = 0; j < 2; ++j) {
+            if (wave * 64 + 512 * j >= IH1 * IW1) continue;       // (wave-uniform)
+            const int q = min(tid + 512 * j, IH1 * IW1 - 1);
+            const int r = q / IW1, c = q - r * IW1;
+            const unsigned off = (unsigned)(reflect_clamp_q(w.y0 - 2 + r, p.H) * p.W + reflect_clamp_q(w.x0 - 2 + c, p.W)) * 4u;
+            dma4(im, off, ip_lds + (unsigned)(par * IPB + wave * 64 + 512 * j) * 4u);
+        }
+    };
+    // the cursor: unit pc_unit of item pc_item is what the next produce() makes; LDS byte addresses of its weights / parameters
+    int pc_unit = 0, pc_next_item = item + stride;
+    unsigned pc_wv = w1_lds + (unsigned)(lane & 3) * 48u;     // w1u[unit][lane & 3][0..11]
+    unsigned pc_bv = bst_lds;                                 // bst[unit * 12]
+    // 64 pixels x 4 channels of the cursor's unit -> raw buffer at byte wbuf: nine rank-1 MFMAs on the lane's own pixel.  In steps, so
+    // that the unit body can thread them through the gaps of its own MFMA stream (the nine small MFMAs depend on each other):
+    //   step 0: issue the reads (9 taps of the pixel, 9 weights, the bias as the accumulator's initial value)
+    //   steps 1..9: one v_mfma_f32_4x4x1_16b_f32 each; step 8 also fetches the BatchNorm terms
+    //   step 10: ReLU / BatchNorm and the 16-byte store
+    // The nine tap values of a pixel are the same for all 16 units of an item: block 0's (every wave) stay in registers (px_, loaded
+    // when the cursor enters an item); the second block of waves 0, 1 gathers them per unit.
+    float px_[9];
+    f32x4 pw_[3], pd_, psc_, psh_;
+    auto gather_x = [&](float (&x)[9], const int j) __attribute__((always_inline)) {
+        const lds_f32_ptr xp = reinterpret_cast<lds_f32_ptr>(pg_x[j]);
 #pragma unroll
-            for (int cbk = 0; cbk < 4; ++cbk) {
-                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < 9; ++t) x[t] = (MPQX & 16777216) ? 1.f : xp[(t / 3) * IW1 + (t % 3)];
+    };
+    auto prod_step = [&](const int k, const unsigned wbuf, const int j, const float (&x)[9]) __attribute__((always_inline)) {
+        const lds_f32x4_ptr wp = reinterpret_cast<lds_f32x4_ptr>(pc_wv);
+        const lds_f32x4_ptr bp = reinterpret_cast<lds_f32x4_ptr>(pc_bv);
+        if (k == 0) {
+            pd_ = bp[0];
+            pw_[0] = wp[0]; pw_[1] = wp[1]; pw_[2] = wp[2];
+        } else if (k <= 9) {
+            if (MPQX & 8388608) asm volatile("" :: "v"(pw_[(k - 1) >> 2][(k - 1) & 3]), "v"(x[k - 1]));       // (timing only: no small MFMAs)
+            else pd_ = __builtin_amdgcn_mfma_f32_4x4x1f32(pw_[(k - 1) >> 2][(k - 1) & 3], x[k - 1], pd_, 0, 0, 0);
+            if (k == 8) { psc_ = bp[1]; psh_ = bp[2]; }
+        } else {
+            f32x4 v;
 #pragma unroll
-                for (int j = 0; j < 3; ++j) d = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[cbk][j], xb[j], d, 0, 0, 0);
-                const int q = cbk * 4 + c1_kg;                     // this lane's channel quad
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(wl + 4 * q);
-                const f32x4 s4 = *reinterpret_cast<const f32x4*>(wl + 64 + 4 * q);
-                const f32x4 t4 = *reinterpret_cast<const f32x4*>(wl + 128 + 4 * q);
-                f32x4 v;
+            for (int h2 = 0; h2 < 2; ++h2) {
+                f32x2 a = f32x2{pd_[2 * h2], pd_[2 * h2 + 1]};
+                const f32x2 s2 = {psc_[2 * h2], psc_[2 * h2 + 1]}, t2 = {psh_[2 * h2], psh_[2 * h2 + 1]};
+                if (BNF) { a = __builtin_elementwise_fma(a, s2, t2); a = f32x2{relu_q(a[0]), relu_q(a[1])}; }
+                else { a = f32x2{relu_q(a[0]), relu_q(a[1])}; a = __builtin_elementwise_fma(a, s2, t2); }
+                v[2 * h2] = a[0]; v[2 * h2 + 1] = a[1];
+            }
+            *reinterpret_cast<lds_f32x4_wptr>(raw_lds + wbuf + pg_w[j]) = v;
+        }
+    };
+    auto produce = [&](const unsigned wbuf, const int j) __attribute__((always_inline)) {       // all steps at once
+        if (j == 0) {
 #pragma unroll
-                for (int h2 = 0; h2 < 2; ++h2) {                   // channel pairs: packed add / multiply-add
-                    f32x2 a = f32x2{d[2 * h2], d[2 * h2 + 1]} + f32x2{b4[2 * h2], b4[2 * h2 + 1]};
-                    const f32x2 sc = {s4[2 * h2], s4[2 * h2 + 1]}, sh = {t4[2 * h2], t4[2 * h2 + 1]};
-                    if (BNF) { a = __builtin_elementwise_fma(a, sc, sh); a = f32x2{fmaxf(a[0], 0.f), fmaxf(a[1], 0.f)}; }
-                    else { a = f32x2{fmaxf(a[0], 0.f), fmaxf(a[1], 0.f)}; a = __builtin_elementwise_fma(a, sc, sh); }
-                    v[2 * h2] = a[0]; v[2 * h2 + 1] = a[1];
+            for (int k = 0; k <= 10; ++k) prod_step(k, wbuf, 0, px_);
+        } else {
+            float qx[9];
+            gather_x(qx, 1);
+#pragma unroll
+            for (int k = 0; k <= 10; ++k) prod_step(k, wbuf, 1, qx);
+        }
+    };
+    auto prod_advance = [&]() __attribute__((always_inline)) {
+        pc_wv += 4u * 12u * 4u; pc_bv += 12u * 4u;
+        if (++pc_unit == NC) {
+            pc_unit = 0;
+            pc_wv -= (unsigned)NC * 4u * 12u * 4u; pc_bv -= (unsigned)NC * 12u * 4u;
+            if (pc_next_item < item_end) {
+                const Where w = decode(pc_next_item);
+                pc_par ^= 1;
+                if (!(pg_rel && (w.y0 >= 1) && (w.y0 + OY < p.H) && (w.x0 >= 1) && (w.x0 + OX < p.W))) prod_offsets(w);
+                else {                                            // interior -> interior: only the patch buffer changes
+                    const unsigned flip = pc_par ? (unsigned)IPB * 4u : 0u - (unsigned)IPB * 4u;
+                    pg_x[0] += flip; pg_x[1] += flip;
                 }
-                // (planes are padded to whole blocks: no bounds test; 32-bit offset from the uniform scratch base)
-                *reinterpret_cast<f32x4*>(Sb + (unsigned)(q * NPIXP + f) * 16u) = v;
+                gather_x(px_, 0);                                 // (the patch landed and was fenced by a unit barrier long ago)
+                pc_next_item += stride;
             }
         }
-        __syncthreads();                                          // image patch and parameters are dead: the scratch is the transform's again
     };
 
     // ---- prologue ----
     Where cur = decode(item);
-    if (F1) {
-        for (int f = tid; f < 9 * 64; f += 512) w1s[f] = p.w1[f];
-        __syncthreads();
-        conv1_load(cur);
-        conv1_item(cur, 0);
-        if (item + stride < item_end) conv1_load(decode(item + stride));
-        dma_wait();                                               // (vmcnt counts the stores too)
-        __syncthreads();                                          // scratch[0] is visible to every wave's DMA
+    if constexpr (F1) {
+        for (int f = tid; f < 16 * 4 * 12; f += 512) {            // w1u[unit][channel of the unit][tap] <- p.w1 [tap][64]
+            const int ch = f / 12, t = f - ch * 12;
+            (raw + 2 * RB4 + 2 * IPB + 16 * 12)[f] = t < 9 ? p.w1[t * 64 + ch] : 0.f;
+        }
+        if (tid < 16 * 12) {
+            const int u = tid / 12, r = tid - u * 12, k = r >> 2, i = r & 3;
+            (raw + 2 * RB4 + 2 * IPB)[tid] = (k == 0 ? p.b1 : k == 1 ? p.s1 : p.t1)[4 * u + i];
+        }
+        patch_dma(cur, 0);
+        if (item + stride < item_end) patch_dma(decode(item + stride), 1);
+        prod_offsets(cur);
+        dma_wait();
+        __syncthreads();                                          // patches, weights and parameters visible
+        gather_x(px_, 0);
+        produce(0u, 0); if (wave + 8 < NRB) produce(0u, 1);       // raw(0) -> buffer 0
+        prod_advance();
+        produce(RB4 * 4u, 0); if (wave + 8 < NRB) produce(RB4 * 4u, 1);       // raw(1) -> buffer 1
+        prod_advance();
     }
-    const float* rbase = raw_offsets(cur);
+    const float* rbase = F1 ? p.in : raw_offsets(cur);
     const float* rsrc = rbase;               // the cursor's unit: rbase + ld_chunk * unit_stride
     Where ld_item = cur;
     int ld_chunk = 0;
@@ -486,7 +528,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
             ld_chunk = 0;
             if (ld_next_item < item_end) {
                 ld_item = decode(ld_next_item);
-                ld_par ^= 1;
                 rbase = raw_offsets(ld_item);
                 ld_next_item += stride;
             }
@@ -495,9 +536,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     };
     const float* up = u_ptr(cur.slice);
     // raw(k) lives in raw buffer k % 3: unit n transforms raw(n+1) and sends raw(n+3) over raw(n)
-    raw_dma(rsrc, 0u, 0); raw_dma(rsrc, 0u, 1); ld_advance();                                       // raw(0)
-    raw_dma(rsrc, RB4 * 4u, 0); raw_dma(rsrc, RB4 * 4u, 1); ld_advance();                           // raw(1)
-    raw_dma(rsrc, 2u * RB4 * 4u, 0); raw_dma(rsrc, 2u * RB4 * 4u, 1); ld_advance();                 // raw(2)
+    if constexpr (!F1) {
+        raw_dma(rsrc, 0u, 0); raw_dma(rsrc, 0u, 1); ld_advance();                                       // raw(0)
+        raw_dma(rsrc, RB4 * 4u, 0); raw_dma(rsrc, RB4 * 4u, 1); ld_advance();                           // raw(1)
+        raw_dma(rsrc, 2u * RB4 * 4u, 0); raw_dma(rsrc, 2u * RB4 * 4u, 1); ld_advance();                 // raw(2)
+    }
     unsigned rd_byte = 0u, rt_byte = RB4 * 4u;           // byte offsets of the raw buffer unit n DMAs into / transforms from
 #pragma unroll
     for (int i = 0; i < 5; ++i) u_dma(up, 0, i);                                       // U(0)
@@ -516,7 +559,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     bf[1] = *reinterpret_cast<const f32x4*>(&Vs[b_base + 4]);
 
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-    int cur_par = 0;                  // F1: scratch buffer of the current item
+    int cur_par = 0;                  // F1: patch buffer of the current item
 #ifdef MP_TIMING
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool t_on = ((POOL ? p.H : -p.H) == g_timing_q_sel);
@@ -529,26 +572,28 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
         const int next_slice = has_next ? (int)(item_next - (int)udiv((unsigned)item_next, p.magic_slices, (unsigned)p.nslices) * p.nslices)
                                         : cur.slice;
         const float* unext = u_ptr(next_slice);
-        // F1: the first block on the NEXT item's patch (its stores are older than every DMA of this item's loop, so the first
-        // unit barrier's vmcnt(2) has seen them land long before the last units fetch from there)
-        if (F1 && has_next) {
-            MPQ_T(t_c0);
-            conv1_item(decode(item_next), cur_par ^ 1);
-            MPQ_T(t_c1);
-            MPQ_ADD(5, t_c0, t_c1);                                        // first block on the next item's patch
-            MPQ_ADD(6, t_c0, c1_t1);                                       // ... of which: staging the image patch and the parameters
-        }
-
         // schedule of the input transform inside a unit (group g, slot e behind the e-th MFMA of the group)
         auto tf_at = [&](const int g, const int e, const int vb) __attribute__((always_inline)) {
             if (g == 0 && e == 2) tf_pass1();
-            else if (g == 2 && e == 2) { tf_pass1b(3u * RB4 * 4u - rd_byte - rt_byte); tf_pass1w(0); }   // unit n+1 transforms raw((n+2) % 3)
+            else if (g == 2 && e == 2) { tf_pass1b(F1 ? (unsigned)vb * (RB4 * 4u) : 3u * RB4 * 4u - rd_byte - rt_byte); tf_pass1w(0); }   // unit n+1 transforms raw(n+2): ring of 3 (F1: of 2, buffer n & 1)
             else if (g == 2 && e == 3) tf_pass1w(1);
             else if (g == 3 && e == 1) tf_pass1w(2);
             else if (g == 3 && e == 2) tf_pass2();
             else if (g == 5 && e == 2) { tf_pass2b(); tf_pass2w(vb ^ 1, 0); }
             else if (g == 5 && e == 3) tf_pass2w(vb ^ 1, 1);
             else if (g == 6 && e == 1) tf_pass2w(vb ^ 1, 2);
+        };
+        // F1: the production of raw(n+2) (prod_step) in the slots the transform leaves free, one small MFMA per slot; the second
+        // block of waves 0, 1 (granules 512..611) as one piece in front of them
+        auto prod_at = [&](const int g, const int e, const int vb) __attribute__((always_inline)) {
+            const unsigned wbuf = (unsigned)vb * (RB4 * 4u);
+            constexpr int slot_g[11] = {0, 0, 1, 1, 1, 2, 3, 4, 4, 4, 5};
+            constexpr int slot_e[11] = {1, 3, 1, 2, 3, 1, 3, 1, 2, 3, 1};
+            if (MPQX & 4194304) return;                            // (timing only: no production at all)
+            if (g == 0 && e == 0 && !(MPQX & 2097152)) { if (wave + 8 < NRB) produce(wbuf, 1); }      // (2097152, timing only: not the second block)
+#pragma unroll
+            for (int k = 0; k <= 10; ++k)
+                if (g == slot_g[k] && e == slot_e[k]) prod_step(k, wbuf, 0, px_);
         };
         // the 36 MFMAs of a unit and everything that rides in their shadow: one basic block
         auto unit_body = [&](const int c, auto first_tag, auto vb_tag) __attribute__((always_inline)) {
@@ -572,6 +617,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                     acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g % 3][e], bf[g % 3][e], FIRST ? zero4 : acc[s], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                     if (e != 2) tf_at(g, e, vb);
+                    if constexpr (F1) prod_at(g, e, vb);
                     if (e == 0 && !(MPQX & 4)) {
                         // fragments two groups ahead; groups 7, 8 fetch groups 0, 1 of the NEXT unit (behind the unit barrier)
                         af[(g + 2) % 3] = *reinterpret_cast<const f32x4*>(g + 2 < 9 ? &ur[4 * (g + 2)] : &urn[4 * (g - 7)]);
@@ -585,8 +631,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                         // but the two patch DMAs, which have until the NEXT barrier.
                         if (g == 7) { u_dma(un2, vb, 0); u_dma(un2, vb, 1); u_dma(un2, vb, 2); }
                         else if (g == 8) { u_dma(un2, vb, 3); u_dma(un2, vb, 4); }
-                        else if (g == 0) raw_dma(rsrc, rd_byte, 0);
-                        else if (g == 1) raw_dma(rsrc, rd_byte, 1);
+                        else if (g == 0) { if constexpr (!F1) raw_dma(rsrc, rd_byte, 0); }
+                        else if (g == 1) { if constexpr (!F1) raw_dma(rsrc, rd_byte, 1); }
                     } else if (e == 2) {
                         // input transform of unit n+1: raw[vb^1] -> V[vb^1]
                         // input transform of unit n+1, raw -> V[vb^1]: reads, arithmetic and stores of the two passes spread
@@ -601,7 +647,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
 #endif
                             // U(n+1), raw(n+2) (and an item's output stores) have landed; raw(n+3) stays in flight
                             // (lgkmcnt: the V stores are asm statements hipcc does not count)
-                            asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+                            if constexpr (F1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (no raw DMA in flight: raw(n+2) was produced above)
+                            else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
                             if (MPQX & 65536) {
 #pragma unroll
                                 for (int q = 0; q < 6; ++q) asm volatile("" :: "v"(tq[q]), "v"(tq2[q]));
@@ -624,9 +671,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
         };
         auto unit = [&](const int c, auto first_tag, auto vb_tag) __attribute__((always_inline)) {
             unit_body(c, first_tag, vb_tag);
-            ld_advance();
-            const unsigned ro = 3u * RB4 * 4u - rd_byte - rt_byte;     // rotate the raw ring: (rd, rt) <- (rt, third)
-            rd_byte = rt_byte; rt_byte = ro;
+            if constexpr (F1) {
+                prod_advance();
+            } else {
+                ld_advance();
+                const unsigned ro = 3u * RB4 * 4u - rd_byte - rt_byte;     // rotate the raw ring: (rd, rt) <- (rt, third)
+                rd_byte = rt_byte; rt_byte = ro;
+            }
         };
         using VB0 = std::integral_constant<int, 0>;
         using VB1 = std::integral_constant<int, 1>;
@@ -639,8 +690,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
 
         MPQ_T(t_e0);
         MPQ_ADD(3, t_item, t_e0);                                      // whole unit loop of the item
-        // F1: the image patch of item k+2 (the phase at the top of the next item stages it) -- in flight across the epilogue
-        if (F1 && item_next + stride < item_end) conv1_load(decode(item_next + stride));
+        // F1: the image patch of item k+2 -> this item's patch buffer (last read while unit 13 was multiplied); in flight across the epilogue
+        if constexpr (F1) { if (item_next + stride < item_end) patch_dma(decode(item_next + stride), cur_par); }
         // ---- output transform Y = A^T M A in registers, bias / ReLU / BN, [2x2 max-pool], store ----
         // lane = tile (lane & 15) of the wave's tile block, registers r = output channels 4 * (lane >> 4) + r of its channel block
         if (MPQX & 8) {
@@ -792,9 +843,8 @@ bool conv_wino43_supports(const ConvParams& p)
 }
 
 // p.wpack must point at the F(4x4,3x3) weights packed by pack_wino43_weights() (api.hip).  fuse_first: the input is the
-// first encoder block of p.img (p.w1 / b1 / s1 / t1, 64 channels), evaluated inside the kernel; p.scratch holds
-// conv_wino43_scratch_floats(p.ncu) floats; the layer must be the pooled 64 -> 64 one (enc.conv2)
-size_t conv_wino43_scratch_floats(int ncu) { return (size_t)ncu * 2 * 16 * NPIXP * 4; }
+// first encoder block of p.img (p.w1 / b1 / s1 / t1, 64 channels), evaluated inside the kernel; the layer must be the pooled
+// 64 -> 64 one (enc.conv2)
 int launch_conv_wino43(const ConvParams& p, bool pool, hipStream_t s, bool fuse_first)
 {
     if (fuse_first) return pool && p.cin == 64 ? launch_q<true, 8, true>(p, s) : 2;          // 2: shape not covered

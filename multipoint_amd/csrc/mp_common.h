@@ -42,10 +42,6 @@ struct ConvParams {
     // conv_wino43.hip only: channel-quad-planar tensors [B][C/4][H][W][4] instead of NHWC (a unit of 4 input channels is then
     // contiguous row by row: its patch DMA touches ~10 cache lines per instruction instead of 64)
     int in_planar, out_planar;
-    // conv_wino43.hip with the first encoder block fused in (img / w1 / b1 / s1 / t1 above): per persistent workgroup two
-    // buffers of 16 channel quads x 612 patch pixels x 4 floats that the block's output of an item is parked in (L2 / Infinity
-    // Cache resident: 2 x 157 KB x 256 workgroups)
-    float* scratch;
     // machine shape (api.hip: mp_create derives it from the device, run_conv copies it into every launch): compute units of
     // the device = workgroups of a one-per-CU persistent grid, and log2 of its XCD count (workgroup b runs on XCD b mod nxcd;
     // each XCD has its own L2, so a persistent workgroup walks a contiguous share of ITS XCD's items)
@@ -111,7 +107,6 @@ int launch_conv_wino(const ConvParams& p, bool pool, bool fuse1, hipStream_t s);
 #endif
 bool conv_wino43_supports(const ConvParams& p);
 int launch_conv_wino43(const ConvParams& p, bool pool, hipStream_t s, bool fuse_first = false);
-size_t conv_wino43_scratch_floats(int ncu);       // ConvParams::scratch of a fuse_first launch (one slot per persistent workgroup)
 
 // fp16 path (mixed_precision: activations and packed weights fp16, fp32 accumulate; conv_f16.hip).
 // Same tiling as ConvParams; a chunk is 64 input channels, so cin must be a multiple of 64.

@@ -100,10 +100,12 @@ def test_fused_first_block_equals_unfused(oracle, monkeypatch, upd, B, H, W):
 @pytest.mark.parametrize('upd', [{}, {'multispectral': True}, {'bn_first': True}])
 @pytest.mark.parametrize('B,H,W', [(3, 72, 104), (2, 16, 16), (1, 240, 320), (5, 40, 264), (2, 480, 640)])
 def test_first_block_inside_f43_equals_standalone(oracle, monkeypatch, upd, B, H, W):
-    """The first encoder block evaluated inside the F(4x4,3x3) conv2 kernel (default: per item on the matrix pipe into a
-    per-workgroup scratch the unit loop DMAs from) against the standalone first-block launch (MP_NO_FUSE43=1): the same nine
-    products per output summed in the MFMA's order instead of a multiply-add chain, so the network outputs agree to the last
-    bits of fp32 -- borders (two nested reflections), partial items, two encoders."""
+    """The first encoder block evaluated inside the F(4x4,3x3) conv2 kernel (default; round 3: per unit, straight into the raw LDS
+    ring, nine rank-1 v_mfma_f32_4x4x1 updates per pixel with the bias as the accumulator's initial value) against the standalone
+    first-block launch (MP_NO_FUSE43=1: a k-ordered multiply-add chain, bias added last): the same nine products and the bias summed
+    in another order, so the block's outputs differ by an ulp here and there and the network outputs by what that becomes
+    downstream (measured: prob <= 1.0e-5, desc <= 6e-7 between the two; each of them 6.5e-6 .. 9.9e-6 from an fp64 evaluation,
+    the fp32 CPU oracle 7e-6 .. 1.2e-5) -- borders (two nested reflections), partial items, two encoders, bn_first."""
     cfg = dict(oracle.SHIPPED_MODEL_CONFIG); cfg.update(upd)
     img = oracle.make_images(31 + W, B, H, W)
     flags = torch.tensor([[i % 2 == 0] for i in range(B)])
@@ -114,7 +116,8 @@ def test_first_block_inside_f43_equals_standalone(oracle, monkeypatch, upd, B, H
     b = net2({'image': img.cuda(), 'is_optical': flags})
     ref = oracle.forward(sd, img, cfg, is_optical=flags)
     assert (a['prob'].cpu() - ref['prob']).abs().max().item() <= PROB_TOL and (a['desc'].cpu() - ref['desc']).abs().max().item() <= DESC_TOL
-    assert (a['prob'] - b['prob']).abs().max().item() <= 2e-6 and (a['desc'] - b['desc']).abs().max().item() <= 2e-6
+    assert (b['prob'].cpu() - ref['prob']).abs().max().item() <= PROB_TOL and (b['desc'].cpu() - ref['desc']).abs().max().item() <= DESC_TOL
+    assert (a['prob'] - b['prob']).abs().max().item() <= 3e-5 and (a['desc'] - b['desc']).abs().max().item() <= 3e-6
 
 
 @pytest.mark.parametrize('upd', [{}, {'multispectral': True}, {'bn_first': True}])
