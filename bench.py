@@ -368,13 +368,14 @@ def main():
                      'conv_mfma_persist_kernel<9,32,true,false> (enc.conv2, direct convolution)'
         elif f43:
             # Winograd F(4x4,3x3): 36 multiplies per 4x4 output tile and channel pair instead of 144 -> 4x fewer MFMA FLOPs.
-            # Fused first block: 468 v_mfma_f32_16x16x4_f32 (2048 FLOP each, K = 9 padded to 12) per item of 16 x 32 pixels
+            # Fused first block: per item of 16 x 32 pixels and unit of 4 channels 10 blocks of 64 patch pixels x 9 taps, one
+            # v_mfma_f32_4x4x1_16b_f32 (512 FLOP) each -> 16 x 10 x 9 = 1440 per item
             items = 2 * P * ((H + 15) // 16) * ((W + 31) // 32)
-            issued = (conv2_flop / 4.0 + items * 468 * 2048.0) if fused else flop / 4.0
+            issued = (conv2_flop / 4.0 + items * 1440 * 512.0) if fused else flop / 4.0
             inst = 'conv_wino43_kernel<true,false,8,true>' if fused else 'conv_wino43_kernel<true,false,8,false>'
-            kernel = ('conv_wino43_kernel<true,false,8,true> (encoder conv1 -- Cin = 1, evaluated per item on the matrix pipe and parked '
-                      'in an L2-resident scratch -- fused into enc.conv2 64->64 @480x640 by Winograd F(4x4,3x3) on '
-                      'v_mfma_f32_16x16x4_f32, weights and input patches staged by LDS-DMA, + bias/ReLU/BN + 2x2 max-pool)') if fused else \
+            kernel = ('conv_wino43_kernel<true,false,8,true> (encoder conv1 -- Cin = 1, produced per unit of 4 channels on the matrix pipe '
+                      '(v_mfma_f32_4x4x1_16b_f32) straight into the LDS patch ring -- fused into enc.conv2 64->64 @480x640 by Winograd '
+                      'F(4x4,3x3) on v_mfma_f32_16x16x4_f32, weights staged by LDS-DMA, + bias/ReLU/BN + 2x2 max-pool)') if fused else \
                      ('conv_wino43_kernel<true,false,8,false> (enc.conv2 64->64 @480x640 by Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32, '
                       'weights and channel-quad-planar input patches staged by LDS-DMA, + bias/ReLU/BN + 2x2 max-pool)')
         else:
@@ -403,8 +404,8 @@ def main():
                 # the MFMA utilisation the F(2x2,3x3) kernel (2.25x fewer FLOPs than direct) would need for this launch time
                 # the fused launch parks the first block's 64-channel output in a per-workgroup scratch and DMAs it back (6 GB each
                 # way at the L2 boundary): the same bytes the two separate launches moved (5.3 + 7.6 GB), now inside one launch
-                'traffic_note': ('L2-boundary bytes incl. the round trip of the fused first block\'s output through the per-workgroup '
-                                 'scratch (the un-fused pair of launches moved 5.3 + 7.6 GB)') if (f43 and fused) else None,
+                'traffic_note': ('L2-boundary bytes: images in, pooled output out, weights from L2 (round 2 moved 14.2 GB: the first block\'s '
+                                 'output made a round trip through a global scratch; the un-fused pair of launches 5.3 + 7.6 GB)') if (f43 and fused) else None,
                 'f22_equivalent_frac': round((conv2_flop if fused else flop) / (ms * 1e-3) / 1e12 / 2.25 / peak, 4) if f43 else None,
                 'note': 'achieved/frac = MFMA FLOPs issued by the launch / hipEvent time on the launch stream inside the timed '
                         'region / dense MFMA peak (matrix-pipe utilisation; agrees with SQ_VALU_MFMA_BUSY_CYCLES in profiles/).  '
