@@ -1,11 +1,15 @@
 #!/bin/bash
 # Developer tool (GPU box, repo root): everything profiles/ is regenerated from -- the rocprofv3 passes of
 # tools/collect_profiles.sh plus the bench lines (default, --workload c5, RCCL world size 1, F(2x2,3x3)-only A/B).
-#   bash tools/collect_all.sh gpurun_out/prof_rNN ; python tools/summarize_profiles.py gpurun_out/prof_rNN rNN
+#   bash tools/collect_all.sh gpurun_out/prof_rNN rNN ; python tools/summarize_profiles.py gpurun_out/prof_rNN rNN   (the second call, here in the
+#   build container, copies the bench lines; on the GPU box profiles/ is part of the scratch copy of the repository)
 set -u
 R=${1:-gpurun_out/prof}
+TAG=${2:-r03}
 mkdir -p "$R"
 bash tools/collect_profiles.sh "$R" > "$R.log" 2>&1
+# the PMC summary first: the bench lines below read roofline.traffic from profiles/${TAG}_pmc_hbm_traffic*.json
+python3 tools/summarize_profiles.py "$R" "$TAG" > "$R/summary.log" 2>&1
 python3 bench.py > "$R/bench_n1.json" 2> "$R/bench_n1.err"
 python3 bench.py --workload c5 > "$R/bench_c5.json" 2> "$R/bench_c5.err"
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --no-cpu-baseline > "$R/bench_rccl.json" 2> "$R/bench_rccl.err"

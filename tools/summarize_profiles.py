@@ -111,3 +111,15 @@ summarize('', '', 'conv_wino43_kernel<true, false, 8, true>', 1,
 # fp16 workload: enc.conv1 evaluated inside enc.conv2 on the LDS-resident-weights kernel, one launch of this instantiation per forward
 summarize('c5_', '_c5', 'conv_f16_res_kernel<32, true, false, 2, true>', 1,
           'python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --workload c5', 'python3 tools/bench_layers.py 16 1024 1280 f16')
+
+# the bench lines of tools/collect_all.sh (run AFTER the PMC passes were summarised: bench.py reads the traffic figure from the
+# committed profiles/<tag>_pmc_hbm_traffic*.json) -> profiles/<tag>_bench_*.json, and the SQ counter summary of the fp16 convolutions
+for name, out in (('bench_n1', 'bench_n1'), ('bench_c5', 'bench_c5_f16_n1'), ('bench_rccl', 'bench_rccl_world1'), ('bench_f22', 'bench_f22_only_n1'),
+                  ('bench_c5_stream', 'bench_c5_streaming_kernel_n1')):
+    path = os.path.join(src, name + '.json')
+    if os.path.exists(path):
+        lines = [l for l in open(path) if l.startswith('{')]
+        if lines:
+            json.dump(json.loads(lines[-1]), open(os.path.join(dst, '%s_%s.json' % (tag, out)), 'w'), indent=1)
+if os.path.exists(os.path.join(src, 'sq_c5.txt')):
+    shutil.copy(os.path.join(src, 'sq_c5.txt'), os.path.join(dst, tag + '_pmc_sq_counters_c5.txt'))
