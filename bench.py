@@ -328,8 +328,7 @@ def main():
     roof = None
     wino = os.environ.get('MP_NO_WINOGRAD') != '1' and not c5
     # the library's choice for conv2 (api.hip uses_wino43): F(4x4,3x3) unless switched off, fused, or the frame is no multiple of 4
-    f43 = (wino and os.environ.get('MP_WINO43', '2') != '0' and os.environ.get('MP_WINO_FUSE') != '1'
-           and H % 4 == 0 and W % 4 == 0)
+    f43 = wino and os.environ.get('MP_WINO43', '2') != '0' and H % 4 == 0 and W % 4 == 0
     dom = by_name.get('enc.conv1+2') or by_name.get('enc.conv2')
     n_launch = 1
     if dom:
@@ -380,11 +379,8 @@ def main():
                       'weights and channel-quad-planar input patches staged by LDS-DMA, + bias/ReLU/BN + 2x2 max-pool)')
         else:
             issued = (conv2_flop if fused else flop) / 2.25
-            inst = 'conv_wino_kernel<true,false,true,false,8>' if fused else 'conv_wino_kernel<true,false,false,false,8>'
-            kernel = ('conv_wino_kernel<true,false,true,false,8> (encoder conv1 -- Cin = 1, computed on the vector pipe inside the loader '
-                      '-- fused into enc.conv2 64->64 @480x640 by Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32 + bias/ReLU/BN '
-                      '+ 2x2 max-pool)') if fused else \
-                     ('conv_wino_kernel<true,false,false,false,8> (enc.conv2 64->64 @480x640 by Winograd F(2x2,3x3) on '
+            inst = 'conv_wino_kernel<true,false,false,8>'
+            kernel = ('conv_wino_kernel<true,false,false,8> (enc.conv2 64->64 @480x640 by Winograd F(2x2,3x3) on '
                       'v_mfma_f32_32x32x2_f32, operands staged by LDS-DMA, + bias/ReLU/BN + 2x2 max-pool)')
         ach = issued / (ms * 1e-3) / 1e12
         alg = flop / (ms * 1e-3) / 1e12

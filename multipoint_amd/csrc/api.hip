@@ -77,8 +77,6 @@ struct mp_handle {
     int wino43 = 2;                 // MP_WINO43: 0 off, 1 F(4x4,3x3) for the 3x3 layers with 64 input channels only, 2 (default) every 3x3 layer it supports
     bool head_fuse = true;          // MP_NO_HEAD_FUSE=1: separate 1x1 convolution / softmax / normalisation launches
     bool fuse43 = true;             // first block evaluated inside the F(4x4,3x3) conv2 kernel (MP_NO_FUSE43=1: its own launch)
-    bool wino_fuse = false;         // MP_WINO_FUSE=1: first block computed inside the Winograd conv2 loader (default since round 2:
-                                    // standalone first block + Winograd conv2 with LDS-DMA staging -- 6.50 vs 6.84 ms per 64 images)
     int* pinned = nullptr;          // small pinned host scratch (img lists, counters)
     bool f16_res = true;            // MP_F16_NO_RES=1: the streaming kernel (conv_f16.hip) also for the 64 -> 64 layers
     bool f16_fuse1 = true;          // MP_F16_NO_FUSE1=1: the first block of the fp16 path as its own launch
@@ -524,7 +522,7 @@ bool uses_wino43(const mp_handle* h, const ConvLayer& L, int H, int W, bool fuse
                  int out_cstride = 0, int out_coff = 0)
 {
     // fuse: the first block is evaluated by the layer's kernel -- with F(4x4,3x3) only by the pooled 64 -> 64 layer, 64 real channels
-    if (fuse && !(h->fuse43 && !h->wino_fuse && L.pool && L.cin == 64 && L.cout == 64 && h->cfg.channel_version == 0)) return false;
+    if (fuse && !(h->fuse43 && L.pool && L.cin == 64 && L.cout == 64 && h->cfg.channel_version == 0)) return false;
     if (!(L.taps == 9 && L.u43pack && h->wino && (h->wino43 == 2 || L.cin == 64))) return false;
     ConvParams q{};
     q.pad_zero = h->cfg.reflection_pad ? 0 : 1; q.cin = L.cin; q.cout = L.cout; q.H = H; q.W = W;
@@ -564,9 +562,9 @@ int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, 
     if (f43) {
         p.wpack = L.u43pack; p.in_planar = in_planar; p.out_planar = out_planar;
         big = launch_conv_wino43(p, L.pool, s, fuse != nullptr);
-    } else if (L.taps == 9 && L.upack && h->wino && (!fuse || (L.pool && L.cin == 64))) {
+    } else if (L.taps == 9 && L.upack && h->wino && !fuse) {
         p.wpack = L.upack;
-        big = launch_conv_wino(p, L.pool, fuse != nullptr, s);
+        big = launch_conv_wino(p, L.pool, s);
     } else {
         big = launch_conv_mfma(p, L.taps, mbw, L.pool, fuse != nullptr, s);
     }
@@ -839,7 +837,6 @@ int mp_create(mp_handle** out, int device)
     while ((1 << hh->xcd_shift) < nxcd) ++hh->xcd_shift;
     { const char* e = getenv("MP_NO_FUSE"); hh->fuse_first = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_NO_WINOGRAD"); hh->wino = !(e && e[0] == '1'); }
-    { const char* e = getenv("MP_WINO_FUSE"); hh->wino_fuse = (e && e[0] == '1'); }
     { const char* e = getenv("MP_NO_FUSE43"); hh->fuse43 = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_NO_HEAD_FUSE"); hh->head_fuse = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_F16_NO_RES"); hh->f16_res = !(e && e[0] == '1'); }
@@ -1007,7 +1004,7 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
         // the fused loader is a 64-channel direct-convolution kernel; with Winograd on, the standalone first block +
         // Winograd second convolution is faster than the fused direct kernel
         const bool fuse1 = h->fuse_first && h->cfg.channel_version == 0 &&
-                           (!h->wino || h->wino_fuse || uses_wino43(h, E.conv[0], H, W, true));
+                           (!h->wino || uses_wino43(h, E.conv[0], H, W, true));
         // a tensor written by conv1 or an F(4x4,3x3) layer AND read by an F(4x4,3x3) layer is channel-quad planar
         // -- when the producer's stores are few: conv1, or a POOLED F(4x4,3x3) layer.  (An un-pooled layer stores 16 pixels per
         // lane and tile; planar, a store instruction then writes 16-byte pieces 64 bytes apart instead of 64-byte runs, which

@@ -22,12 +22,6 @@
 // any VALU instruction 12 cycles alone in an MFMA gap, 8 + 4n in a cluster of n (8 + 5n packed); s_nop, ds_read_b32/64/128
 // and an LDS-DMA per 4 MFMAs free; ds_write_b64 free up to 2 per MFMA; global_load_dwordx4 into registers 10 cycles.
 //
-// FUSE (encoder conv2 only): the input of this convolution is the first encoder block (ReflectionPad -> Conv2d(1,64,3)
-// -> ReLU -> BN, Cin = 1).  Instead of reading its 64-channel output from HBM, the raw patch of a unit (18x18 pixels x
-// 8 channels) is computed from a 20x20 image patch in LDS: per thread and unit three 4-channel vectors = 27 LDS reads
-// (issued in the MFMA slots of the unit) + 54 packed multiply-adds and the activation (one block behind the unit's
-// MFMAs, see f_row), written to raw[] with ds_write_b128.  This removes the first block's launch and its 78.6 MB per
-// image round trip through HBM (the same k-ordered fmaf chain as conv_first_kernel).
 #include "mp_common.h"
 
 #include <algorithm>
@@ -68,8 +62,6 @@ constexpr int RS = UC;                       // raw patch pixel stride in floats
 constexpr int NRAW = (NPX * 2 + 255) / 256;  // raw 16-byte granules per thread (3): granule f = tid + 256*j = pixel f>>1, quad f&1
 constexpr int RAWBUF = 12 * 64 * 4;          // floats per raw buffer: 12 wave-DMAs of 64 granules (12 KiB): 648 granules used,
                                              // block 11 is a dummy target (fourth wave's third DMA, zero-fill of unpadded slots)
-constexpr int IT = WT + 4;                   // image patch edge of the fused first block (20)
-constexpr int NPL = (IT * IT + 255) / 256;   // image patch pixels per thread (2)
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
@@ -139,28 +131,22 @@ __device__ __forceinline__ void st4(float* q, f32x4 v) { *reinterpret_cast<f32x4
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)p; }   // low 32 bits of a flat LDS address
 
-// ZPAD: zero-padding model (ZeroPad2d(1): reflection_pad false, SuperPointMagicLeap); the FUSE variant reads p.pad_zero
+// ZPAD: zero-padding model (ZeroPad2d(1): reflection_pad false, SuperPointMagicLeap)
 // TC: tile columns of an item (8: 8 x 8 Winograd tiles = 16 x 16 pixels; 16: 4 x 16 tiles = 8 x 32 pixels, for layers whose
 // height is a multiple of 8 but not of 16 -- 120 x 160 -- where the square item spends 6.7 % of its rows outside the image)
-template <bool POOL, bool BNF, bool FUSE, bool ZPAD, int TC = 8>
+template <bool POOL, bool BNF, bool ZPAD, int TC = 8>
 __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
 {
     static_assert(TC == 8 || TC == 16, "an item is 64 Winograd tiles: 8 x 8 or 4 x 16");
-    static_assert(!FUSE || TC == 8, "the fused first block is written for the square item");
     constexpr int TR = 64 / TC;                          // tile rows of an item
     constexpr int WTX = 2 * TC, WTY = 2 * TR;            // output pixels of an item
     constexpr int PWX = WTX + 2, PWY = WTY + 2;          // raw patch (18 x 18 or 34 x 10)
     constexpr int NPXG = PWX * PWY;                      // patch pixels: 324 or 340 (<= 352 = 11 DMA blocks of 32 pixels)
     static_assert(NPXG * 2 <= 11 * 64 && (NPXG * 2 + 255) / 256 == NRAW, "raw buffer geometry");
-    static_assert(!FUSE || POOL, "the fused first block feeds the pooled second encoder convolution");
-    static_assert(!(FUSE && ZPAD), "the fused variant handles both paddings at run time");
     __shared__ __attribute__((aligned(16))) float Vs[2 * VBUF];
     __shared__ __attribute__((aligned(16))) float Us[2 * UBUF];
     __shared__ __attribute__((aligned(16))) float raw[2 * RAWBUF];
     __shared__ __attribute__((aligned(16))) float prm[3 * 64];
-    __shared__ __attribute__((aligned(16))) float its[FUSE ? 2 * IT * IT : 4];     // image patches of two items
-    __shared__ __attribute__((aligned(16))) float w1s[FUSE ? 9 * 64 : 4];          // first-block weights [tap][channel]
-    __shared__ __attribute__((aligned(16))) float p1s[FUSE ? 3 * 64 : 4];          // its bias | BN scale | BN shift
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -192,7 +178,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
 
     // ---- raw patch staging: vector f = tid + 256*j covers patch pixel f>>1, channel quad f&1; its LDS slot is f*4 ----
     int roff[NRAW];
-    unsigned rvoff[NRAW];         // !FUSE: byte offset of the granule's source (clamped to 0 for padding / unused slots)
+    unsigned rvoff[NRAW];         // byte offset of the granule's source (clamped to 0 for padding / unused slots)
     bool roff_rel = false;        // roff holds the item-invariant offsets of interior items
     auto raw_offsets = [&](const Where& w) __attribute__((always_inline)) -> const float* {
         const bool interior = (w.y0 >= 1) && (w.y0 + WTY < p.H) && (w.x0 >= 1) && (w.x0 + WTX < p.W);
@@ -202,8 +188,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                 for (int j = 0; j < NRAW; ++j) {
                     const int f = tid + j * 256, q = f >> 1;
                     const int py = q / PWX, px = q - py * PWX;
-                    if constexpr (FUSE) roff[j] = (f < NPXG * 2) ? (py + 1) * IT + (px + 1) : IT + 1;   // window centre in the image patch
-                    else roff[j] = (f < NPXG * 2) ? (py * p.W + px) * p.in_cstride + (f & 1) * 4 : 0;
+                    roff[j] = (f < NPXG * 2) ? (py * p.W + px) * p.in_cstride + (f & 1) * 4 : 0;
                     rvoff[j] = (unsigned)roff[j] * 4u;
                 }
                 roff_rel = true;
@@ -225,21 +210,13 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                 } else {
                     gy = reflect_clamp_w(gy, p.H); gx = reflect_clamp_w(gx, p.W);
                 }
-                if constexpr (FUSE) {
-                    // centre of the first-block window inside the image patch (patch origin = tile - 2); pixels of partial
-                    // tiles far outside the image are clamped (their outputs are never stored)
-                    const int qy = min(max(gy, w.y0 - 1), w.y0 + WT), qx = min(max(gx, w.x0 - 1), w.x0 + WT);
-                    if (!zero) off = (qy - w.y0 + 2) * IT + (qx - w.x0 + 2);
-                } else {
-                    if (!zero) off = (gy * p.W + gx) * p.in_cstride + (f & 1) * 4;
-                }
+                if (!zero) off = (gy * p.W + gx) * p.in_cstride + (f & 1) * 4;
             }
             roff[j] = off;
             rvoff[j] = (unsigned)(off >= 0 ? off : 0) * 4u;
         }
         return w.in_base;
     };
-    f32x4 rreg[NRAW];                 // FUSE: the computed raw granules of a unit on their way to LDS
     const unsigned raw_lds = lds_addr(raw), us_lds = lds_addr(Us);
     // granule block j of this wave (64 granules = 1 KiB, block index wave + 4*j) of the staging cursor's unit -> raw[buf]
     // There is no control flow in here on purpose: a branch inside the unit body splits it into basic blocks, and hipcc
@@ -265,101 +242,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
         if (MPX & 128) return;
         dma16(ub + (i & 1) * half_stride + (b >> 1) * 256, (unsigned)lane * 16u, us_lds + (unsigned)(buf * UBUF + b * 256) * 4u);
     };
-    unsigned rzero = 0;           // bit j: vector j of rreg is a zero-padding slot (set when the loads are issued)
-    auto raw_mark = [&]() __attribute__((always_inline)) {
-        rzero = 0;
-#pragma unroll
-        for (int j = 0; j < NRAW; ++j) rzero |= (roff[j] < 0 ? 1u : 0u) << j;
-    };
-    auto raw_put = [&](int buf) __attribute__((always_inline)) {       // FUSE only
-        if constexpr (FUSE) {
-#pragma unroll
-            for (int j = 0; j < NRAW; ++j) {
-                const int f = tid + j * 256;
-                f32x4 v = rreg[j];
-                if ((rzero >> j) & 1u) v = f32x4{0.f, 0.f, 0.f, 0.f};
-                // unconditional store (no branch inside the unit body): granules beyond the patch go to the dummy block
-                *reinterpret_cast<f32x4*>(&raw[buf * RAWBUF + (f < NPXG * 2 ? f * 4 : 11 * 256 + lane * 4)]) = v;
-            }
-        }
-    };
-
-    // ---- fused first block (FUSE): raw vector j of the cursor's unit computed from the image patch ----
-    f32x4 wreg[FUSE ? 9 : 1], pb4, ps4, pt4;      // weights / bias / scale / shift of this thread's channel quad
-    f32x2 fa[FUSE ? NRAW : 1][2];
-    float pl[NPL];
-    int ld_pb = 0;                                 // image patch buffer of the item the load cursor is in
-    auto patch_load = [&](const Where& w) __attribute__((always_inline)) {
-        const float* image = p.img + (long long)w.img * p.H * p.W;
-#pragma unroll
-        for (int u = 0; u < NPL; ++u) {
-            const int f = tid + u * 256;
-            const int r = f / IT, c = f - r * IT;
-            int gy = w.y0 - 2 + r, gx = w.x0 - 2 + c;
-            float v = 0.f;
-            if (f < IT * IT) {
-                if (p.pad_zero) {
-                    const bool zero = (gy < 0) | (gy >= p.H) | (gx < 0) | (gx >= p.W);
-                    gy = min(max(gy, 0), p.H - 1); gx = min(max(gx, 0), p.W - 1);
-                    v = image[gy * p.W + gx];
-                    if (zero) v = 0.f;
-                } else {
-                    v = image[reflect_clamp_w(gy, p.H) * p.W + reflect_clamp_w(gx, p.W)];
-                }
-            }
-            pl[u] = v;
-        }
-    };
-    auto patch_put = [&](int buf) __attribute__((always_inline)) {
-#pragma unroll
-        for (int u = 0; u < NPL; ++u) {
-            const int f = tid + u * 256;
-            if (f < IT * IT) its[buf * IT * IT + f] = pl[u];
-        }
-    };
-    auto f_weights = [&](int chunk, int part) __attribute__((always_inline)) {
-        const int c4 = chunk * UC + (tid & 1) * 4;
-        if (part == 0) {
-#pragma unroll
-            for (int k = 0; k < 5; ++k) wreg[k] = *reinterpret_cast<const f32x4*>(&w1s[k * 64 + c4]);
-        } else {
-#pragma unroll
-            for (int k = 5; k < 9; ++k) wreg[k] = *reinterpret_cast<const f32x4*>(&w1s[k * 64 + c4]);
-            pb4 = *reinterpret_cast<const f32x4*>(&p1s[c4]);
-            ps4 = *reinterpret_cast<const f32x4*>(&p1s[64 + c4]);
-            pt4 = *reinterpret_cast<const f32x4*>(&p1s[128 + c4]);
-        }
-    };
-    // Row kh of vector j's 3x3 window: three LDS reads + 12 multiply-adds (k order 0..8 as in conv_first_kernel).
-    // The reads are placed in the MFMA slots of the unit; the arithmetic is written there too, but LLVM sinks it towards
-    // its use (the LDS write of the next unit) into one block behind the unit's MFMAs -- which is also the fastest
-    // arrangement measured: pinned into the slots the same instructions cost 0.5 ms more per launch (every vector
-    // instruction issued into an fp32 MFMA stream stalls it), and hand-packed v_pk_fma_f32 with op_sel broadcasts was
-    // slower than the scalar FMAs the compiler picks (7.2-7.6 against 7.06 ms).
-    auto f_row = [&](int j, int kh) __attribute__((always_inline)) {
-        const int o = ld_pb * IT * IT + (roff[j] >= 0 ? roff[j] : IT + 1) + (kh - 1) * IT;
-        const float x[3] = {its[o - 1], its[o], its[o + 1]};
-        if (kh == 0) { fa[j][0] = f32x2{0.f, 0.f}; fa[j][1] = f32x2{0.f, 0.f}; }
-#pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-            const f32x4 wv = wreg[kh * 3 + kw];
-            fa[j][0] = __builtin_elementwise_fma(f32x2{x[kw], x[kw]}, f32x2{wv[0], wv[1]}, fa[j][0]);
-            fa[j][1] = __builtin_elementwise_fma(f32x2{x[kw], x[kw]}, f32x2{wv[2], wv[3]}, fa[j][1]);
-        }
-    };
-    auto f_act = [&](int j) __attribute__((always_inline)) {
-        f32x2 v0 = fa[j][0] + f32x2{pb4[0], pb4[1]}, v1 = fa[j][1] + f32x2{pb4[2], pb4[3]};
-        const f32x2 s0 = {ps4[0], ps4[1]}, s1 = {ps4[2], ps4[3]}, t0 = {pt4[0], pt4[1]}, t1 = {pt4[2], pt4[3]};
-        if (BNF) {
-            v0 = v0 * s0 + t0; v1 = v1 * s1 + t1;
-            rreg[j] = f32x4{relu_w(v0[0]), relu_w(v0[1]), relu_w(v1[0]), relu_w(v1[1])};
-        } else {
-            v0 = f32x2{relu_w(v0[0]), relu_w(v0[1])} * s0 + t0;
-            v1 = f32x2{relu_w(v1[0]), relu_w(v1[1])} * s1 + t1;
-            rreg[j] = f32x4{v0[0], v0[1], v1[0], v1[1]};
-        }
-    };
-
     // ---- input transform V = B^T d B of one unit: thread = (tile t, channel pair cg) ----
     const int t_tile = tid >> 2, t_cg = tid & 3;
     const int tr_base = (((t_tile / TC) * 2) * PWX + (t_tile % TC) * 2) * RS + t_cg * 2;   // top-left of the 4x4 window
@@ -410,7 +292,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
         }
     };
 
-    // ---- prologue: V(0) transformed, raw(1) and U(0) in LDS (FUSE: raw(2) computed, in registers) ----
+    // ---- prologue: V(0) transformed, raw(1) and U(0) in LDS ----
     Where cur = decode(item);
     const float* rbase = raw_offsets(cur);               // base pointer the staging loads currently use
     Where ld_item = cur;                                  // item the staging loads currently target
@@ -425,39 +307,19 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                 ld_item = decode(ld_next_item);
                 rbase = raw_offsets(ld_item);
                 ld_next_item += stride;
-                ld_pb ^= 1;                               // FUSE: that item's image patch was staged during units 0-1
             } else {
                 ld_has_item = false;                      // past the end: dummy re-reads of the last item
             }
         }
     };
-    // the cursor's raw unit (not interleaved): FUSE -> rreg (raw_put() stores it), otherwise DMA -> raw[buf]
+    // the cursor's raw unit (not interleaved): DMA -> raw[buf]
     auto raw_make = [&](int buf) __attribute__((always_inline)) {
-        if constexpr (FUSE) {
-            raw_mark();
-            f_weights(ld_chunk, 0); f_weights(ld_chunk, 1);
 #pragma unroll
-            for (int j = 0; j < NRAW; ++j) {
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh) f_row(j, kh);
-                f_act(j);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < NRAW; ++j) raw_dma(rbase, ld_chunk, buf, j);
-        }
+        for (int j = 0; j < NRAW; ++j) raw_dma(rbase, ld_chunk, buf, j);
         ld_advance();
     };
-    if constexpr (FUSE) {
-        for (int f = tid; f < 9 * 64; f += 256) w1s[f] = p.w1[f];
-        if (tid < 64) { p1s[tid] = p.b1[tid]; p1s[64 + tid] = p.s1[tid]; p1s[128 + tid] = p.t1[tid]; }
-        patch_load(cur);
-        patch_put(0);
-        __syncthreads();
-    }
     const float* up = u_ptr(cur.slice);                           // weights of the item being multiplied (half 0, unit 0)
     raw_make(0);                                                  // raw(0)
-    raw_put(0);
     raw_make(1);                                                  // raw(1)
 #pragma unroll
     for (int i = 0; i < 8; ++i) u_dma(up, u_half, 0, i);          // U(0)
@@ -469,8 +331,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
     tf_rows(); tf_cols();
 #pragma unroll
     for (int e = 0; e < 16; ++e) tf_write(0, e);
-    raw_put(1);
-    if constexpr (FUSE) raw_make(0);                              // raw(2): in registers, written to raw[0] during unit 0
     __syncthreads();
     afr[0] = *reinterpret_cast<const f32x4*>(&Vs[a_base]);
     afr[1] = *reinterpret_cast<const f32x4*>(&Vs[a_base + VPOS]);
@@ -478,7 +338,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
     bfr[1] = *reinterpret_cast<const f32x4*>(&Us[b_base + 512]);
 
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int cur_pb = 0;                                       // FUSE: image patch buffer of the item being multiplied
 #ifdef MP_TIMING
     unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const bool t_on = ((POOL ? p.H : -p.H) == g_timing_w_sel);      // select a pooled launch by +H, an un-pooled one by -H
@@ -491,8 +350,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
         const int next_slice = has_next ? (int)(item_next - (int)udiv((unsigned)item_next, p.magic_slices, (unsigned)p.nslices) * p.nslices)
                                         : cur.slice;
         const float* unext = u_ptr(next_slice);
-        Where nxt_w = cur;
-        if constexpr (FUSE) { if (has_next) nxt_w = decode(item_next); }
 
         // the 64 MFMAs of a unit and everything that rides in their shadow: ONE basic block (no control flow inside)
         // The buffer parity is a compile-time constant (units are unrolled in pairs; the number of units per item is even),
@@ -537,16 +394,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
                         else if (s < 14) { tf_write(vb ^ 1, 2 * (s - 6)); tf_write(vb ^ 1, 2 * (s - 6) + 1); }
                     } else {
                         // raw(n+2) -> raw[vb] (its previous content was transformed during unit n-1)
-                        if constexpr (FUSE) {
-                            // computed one unit ahead: raw(n+2) sits in rreg, raw(n+3) is COMPUTED from the image patch (f_row)
-                            if (s == 0) f_weights(ld_chunk, 0);
-                            else if (s == 1) raw_put(vb);
-                            else if (s == 2) f_weights(ld_chunk, 1);
-                            else if (s < 12) f_row((s - 3) / 3, (s - 3) % 3);
-                            else if (s < 15) { if (s == 12) raw_mark(); f_act(s - 12); }
-                        } else {
-                            if (s < NRAW) raw_dma(rbase, ld_chunk, vb, s);
-                        }
+                        if (s < NRAW) raw_dma(rbase, ld_chunk, vb, s);
                         if (s == 15 - PF) {
                             // unit barrier: every V(n) / U(n) read has been issued (fragments are fetched two positions
                             // ahead), V(n+1) is written, and the DMAs of the unit (issued before position 8) have had six
@@ -571,15 +419,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
         // a unit + the cursor bookkeeping behind it (all control flow lives here, between two units)
         auto unit = [&](const int c, auto first_tag, auto vb_tag) __attribute__((always_inline)) {
             unit_body(c, first_tag, vb_tag);
-            if constexpr (FUSE) {
-                ld_advance();
-                // the next item's image patch: fetched behind unit 0, staged behind unit 1 -- the load cursor enters that
-                // item in unit NC-4
-                if (c == 0 && has_next) patch_load(nxt_w);
-                else if (c == 1 && has_next) patch_put(cur_pb ^ 1);
-            } else {
-                ld_advance();
-            }
+            ld_advance();
         };
         using VB0 = std::integral_constant<int, 0>;
         using VB1 = std::integral_constant<int, 1>;
@@ -715,11 +555,10 @@ __global__ __launch_bounds__(256, 1) void conv_wino_kernel(const ConvParams p)
         item = item_next;
         cur = decode(item);
         up = unext;
-        cur_pb ^= 1;
     }
 }
 
-template <bool POOL, bool FUSE, int TC>
+template <bool POOL, int TC>
 int launch_w(const ConvParams& p, hipStream_t s)
 {
     ConvParams q = p;
@@ -735,26 +574,26 @@ int launch_w(const ConvParams& p, hipStream_t s)
     q.nitems = (int)nitems;
     const unsigned grid = persistent_grid(nitems, p.ncu, p.xcd_shift);
     const ConvParams& pp = q;
-    if (!FUSE && p.pad_zero) {
-        if (p.bn_first) hipLaunchKernelGGL((conv_wino_kernel<POOL, true, false, true, TC>), dim3(grid), dim3(256), 0, s, pp);
-        else hipLaunchKernelGGL((conv_wino_kernel<POOL, false, false, true, TC>), dim3(grid), dim3(256), 0, s, pp);
+    if (p.pad_zero) {
+        if (p.bn_first) hipLaunchKernelGGL((conv_wino_kernel<POOL, true, true, TC>), dim3(grid), dim3(256), 0, s, pp);
+        else hipLaunchKernelGGL((conv_wino_kernel<POOL, false, true, TC>), dim3(grid), dim3(256), 0, s, pp);
     } else {
-        if (p.bn_first) hipLaunchKernelGGL((conv_wino_kernel<POOL, true, FUSE, false, TC>), dim3(grid), dim3(256), 0, s, pp);
-        else hipLaunchKernelGGL((conv_wino_kernel<POOL, false, FUSE, false, TC>), dim3(grid), dim3(256), 0, s, pp);
+        if (p.bn_first) hipLaunchKernelGGL((conv_wino_kernel<POOL, true, false, TC>), dim3(grid), dim3(256), 0, s, pp);
+        else hipLaunchKernelGGL((conv_wino_kernel<POOL, false, false, TC>), dim3(grid), dim3(256), 0, s, pp);
     }
     return 0;
 }
 
 }  // namespace
 
-// p.wpack must point at the Winograd-domain weights packed by pack_wino_weights() (api.hip)
-// fuse1: p.img / p.w1 / p.b1 / p.s1 / p.t1 describe the first encoder block, p.in is not read (pooled, cin == 64 only)
-int launch_conv_wino(const ConvParams& p, bool pool, bool fuse1, hipStream_t s)
+// p.wpack must point at the Winograd-domain weights packed by pack_wino_weights() (api.hip).  (Round 1's variant with the first
+// encoder block computed inside the loader, MP_WINO_FUSE, was retired in round 3: never the default since round 2 and slower than
+// both alternatives -- its own launch in front of this kernel, or inside the F(4x4,3x3) kernel.)
+int launch_conv_wino(const ConvParams& p, bool pool, hipStream_t s)
 {
-    if (fuse1) return launch_w<true, true, 8>(p, s);
     // 4 x 16-tile items (8 x 32 pixels) where they tile the layer with fewer phantom rows than 8 x 8 tiles (16 x 16 pixels)
     const long long sq = (long long)((p.H + 15) / 16) * ((p.W + 15) / 16);
     const long long wide = (long long)((p.H + 7) / 8) * ((p.W + 31) / 32);
-    if (wide < sq) return pool ? launch_w<true, false, 16>(p, s) : launch_w<false, false, 16>(p, s);
-    return pool ? launch_w<true, false, 8>(p, s) : launch_w<false, false, 8>(p, s);
+    if (wide < sq) return pool ? launch_w<true, 16>(p, s) : launch_w<false, 16>(p, s);
+    return pool ? launch_w<true, 8>(p, s) : launch_w<false, 8>(p, s);
 }

@@ -90,7 +90,7 @@ struct Conv1Params {
 int launch_conv_mfma(const ConvParams& p, int taps, int mbw, bool pool, bool fuse1, hipStream_t s);
 void launch_conv_first(const Conv1Params& p, hipStream_t s);
 // Winograd F(2x2,3x3) flavour of the 3x3 layers (conv_wino.hip); p.wpack = weights packed by pack_wino_weights()
-int launch_conv_wino(const ConvParams& p, bool pool, bool fuse1, hipStream_t s);
+int launch_conv_wino(const ConvParams& p, bool pool, hipStream_t s);
 // Winograd F(4x4,3x3) (conv_wino43.hip): p.wpack = pack_wino43_weights() output; supports() says whether the shape is covered
 // Interpolation points of the F(4x4,3x3) transforms: {0, +-a, +-b, inf}.  The textbook choice a = 1, b = 2 (Lavin & Gray) has
 // integer transform matrices but the worst conditioning of the family: its fp32 error is ~20x that of a direct fp32

@@ -51,15 +51,14 @@ def test_forward_matches_oracle(oracle, shipped, B, H, W):
 
 
 @pytest.mark.parametrize('env', [{'MP_PERSIST_MIN_ITEMS': '1'}, {'MP_NO_PERSIST': '1'}, {'MP_NO_FUSE': '1'},
-                                 {'MP_WINO_FUSE': '1'}, {'MP_NO_WINOGRAD': '1'}, {'MP_NO_WINOGRAD': '1', 'MP_NO_FUSE': '1'},
+                                 {'MP_NO_WINOGRAD': '1'}, {'MP_NO_WINOGRAD': '1', 'MP_NO_FUSE': '1'},
                                  {'MP_NO_HEAD_FUSE': '1'}, {'MP_WINO43': '0'}, {'MP_WINO43': '1'}, {'MP_NO_PLANAR': '1'},
                                  {'MP_PLANAR': '2'}, {'MP_WINO43': '1', 'MP_PLANAR': '2'}, {'MP_NO_FUSE43': '1'}])
 @pytest.mark.parametrize('B,H,W', [(6, 120, 160), (3, 200, 328)])
 def test_forward_kernel_variants(oracle, monkeypatch, env, B, H, W):
     """Every convolution kernel variant against the oracle on the same inputs: the persistent one-workgroup-per-CU
     kernel forced onto small launches (all tile shapes, partial tiles at the right/bottom edge), the per-tile kernel
-    only, the first block fused into the Winograd conv2 loader, the unfused first block in front of the direct second
-    convolution, the first block fused into the direct kernel, the four separate head-tail launches instead of the fused
+    only, the unfused first block in front of the direct second convolution, the first block fused into the direct kernel, the four separate head-tail launches instead of the fused
     head_tail kernel, Winograd F(2x2,3x3) everywhere (MP_WINO43=0), F(4x4,3x3) on the 64-input-channel layers only
     (MP_WINO43=1), NHWC everywhere (MP_NO_PLANAR=1) or channel-quad-planar tensors between EVERY two F(4x4,3x3) layers
     (MP_PLANAR=2) instead of behind conv1 and the pooled layers only.  The default -- standalone first block writing
@@ -73,28 +72,6 @@ def test_forward_kernel_variants(oracle, monkeypatch, env, B, H, W):
     out = net({'image': img.cuda()})
     assert (out['prob'].cpu() - ref['prob']).abs().max().item() <= PROB_TOL
     assert (out['desc'].cpu() - ref['desc']).abs().max().item() <= DESC_TOL
-
-
-@pytest.mark.parametrize('upd', [{}, {'reflection_pad': False}, {'bn_first': True}, {'multispectral': True}])
-@pytest.mark.parametrize('B,H,W', [(4, 72, 104), (2, 16, 16), (3, 40, 264)])
-def test_fused_first_block_equals_unfused(oracle, monkeypatch, upd, B, H, W):
-    """The standalone first-block kernel in front of the Winograd F(2x2,3x3) conv2 against the first block computed inside
-    that kernel's loader (MP_WINO_FUSE=1) on the same inputs (MP_WINO43=0 for both: the default conv2 is the F(4x4,3x3)
-    kernel, a different summation): border and partial tiles, zero padding, bn_first, two encoders -- the same k-ordered
-    multiply-add chain, so the outputs agree to the last bits of fp32 (and both match the oracle)."""
-    monkeypatch.setenv('MP_WINO43', '0')
-    cfg = dict(oracle.SHIPPED_MODEL_CONFIG); cfg.update(upd)
-    img = oracle.make_images(17 + W, B, H, W)
-    flags = torch.tensor([[i % 2 == 0] for i in range(B)])
-    net, sd = _net(oracle, cfg, seed=2)
-    first = net({'image': img.cuda(), 'is_optical': flags})
-    fp, fd = first['prob'].cpu(), first['desc'].cpu()
-    monkeypatch.setenv('MP_WINO_FUSE', '1')
-    net2, _ = _net(oracle, cfg, seed=2)
-    plain = net2({'image': img.cuda(), 'is_optical': flags})
-    ref = oracle.forward(sd, img, cfg, is_optical=flags)
-    assert (fp - ref['prob']).abs().max().item() <= PROB_TOL and (fd - ref['desc']).abs().max().item() <= DESC_TOL
-    assert (fp - plain['prob'].cpu()).abs().max().item() <= 2e-6 and (fd - plain['desc'].cpu()).abs().max().item() <= 2e-6
 
 
 @pytest.mark.parametrize('upd', [{}, {'multispectral': True}, {'bn_first': True}])
