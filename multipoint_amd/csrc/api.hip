@@ -598,8 +598,22 @@ int run_conv_h(mp_handle* h, const ConvLayer& L, const _Float16* in, int in_cstr
     if (fuse) { p.img = images; p.w1 = fuse->w_h; p.b1 = fuse->bias_h; p.s1 = fuse->scale; p.t1 = fuse->shift; }
     prof_begin(h, fuse ? "enc.conv1+2" : L.name,
                2.0 * L.taps * L.cin * L.cout * (double)B * H * W + (fuse ? 2.0 * 9 * 64 * (double)B * H * W : 0.0), s);
-    const int big = (h->f16_res && conv_f16_res_supports(p, L.taps)) ? launch_conv_f16_res(p, mbw, L.pool, s)
-                                                                     : launch_conv_f16(p, L.taps, mbw, L.pool, s);
+    int big = 0;
+    if (h->f16_res && conv_f16_res_supports(p, L.taps)) {
+        big = launch_conv_f16_res(p, mbw, L.pool, s);
+    } else if (h->f16_res && !fuse && L.taps == 9 && L.cin == 64 && L.nslices > 1 && L.cout == 64 * L.nslices) {
+        // 64 input channels, several 64-channel output slices (enc.conv5): a slice's packed weights are 72 KiB, so the
+        // LDS-resident-weights kernel runs once per slice (the input is read once per slice: cheaper than streaming the weights)
+        for (int sl = 0; sl < L.nslices && !big; ++sl) {
+            ConvParamsH q = p;
+            q.wpack = p.wpack + (size_t)sl * 36 * 2 * 64 * 8;
+            q.bias = p.bias + 64 * sl; q.scale = p.scale + 64 * sl; q.shift = p.shift + 64 * sl;
+            q.out_coff = out_coff + 64 * sl; q.cout = 64; q.nslices = 1;
+            big = conv_f16_res_supports(q, L.taps) ? launch_conv_f16_res(q, mbw, L.pool, s) : 2;
+        }
+    } else {
+        big = launch_conv_f16(p, L.taps, mbw, L.pool, s);
+    }
     prof_end(h, s);
     return big ? launch_failed(h, big, L.name, B, H, W) : MP_OK;
 }
