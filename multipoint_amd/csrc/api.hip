@@ -80,6 +80,7 @@ struct mp_handle {
     int* pinned = nullptr;          // small pinned host scratch (img lists, counters)
     bool f16_res = true;            // MP_F16_NO_RES=1: the streaming kernel (conv_f16.hip) also for the 64 -> 64 layers
     bool f16_fuse1 = true;          // MP_F16_NO_FUSE1=1: the first block of the fp16 path as its own launch
+    int f16_res_groups = 3;         // MP_F16_RES_GROUPS=2: two instead of three wave groups per CU in conv_f16_res.hip
     bool prof = false;
     bool head_fallback_noted = false;
     std::vector<ProfEntry> prof_entries;
@@ -586,7 +587,7 @@ int run_conv_h(mp_handle* h, const ConvLayer& L, const _Float16* in, int in_cstr
     p.pad_zero = h->cfg.reflection_pad ? 0 : 1;
     p.bn_first = h->cfg.bn_first;
     p.dummy = static_cast<_Float16*>(h->dummy);
-    p.ncu = h->ncu; p.xcd_shift = h->xcd_shift;
+    p.ncu = h->ncu; p.xcd_shift = h->xcd_shift; p.res_groups = h->f16_res_groups;
     int mbw = 32;
     if (L.taps == 9) {
         mbw = pick_mbw(H, W);
@@ -855,6 +856,7 @@ int mp_create(mp_handle** out, int device)
     { const char* e = getenv("MP_NO_HEAD_FUSE"); hh->head_fuse = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_F16_NO_RES"); hh->f16_res = !(e && e[0] == '1'); }
     { const char* e = getenv("MP_F16_NO_FUSE1"); hh->f16_fuse1 = !(e && e[0] == '1'); }
+    { const char* e = getenv("MP_F16_RES_GROUPS"); if (e && e[0] == '2') hh->f16_res_groups = 2; }
     { const char* e = getenv("MP_NO_PLANAR"); if (e && e[0] == '1') hh->planar = 0; }
     { const char* e = getenv("MP_PLANAR"); if (e && e[0] >= '0' && e[0] <= '2') hh->planar = e[0] - '0'; }
     { const char* e = getenv("MP_WINO43"); if (e && e[0] >= '0' && e[0] <= '2') hh->wino43 = e[0] - '0'; }

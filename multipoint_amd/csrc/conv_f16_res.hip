@@ -16,7 +16,6 @@
 #include "mp_common.h"
 
 #include <algorithm>
-#include <cstdlib>
 #include <type_traits>
 
 namespace {
@@ -577,7 +576,7 @@ bool conv_f16_res_supports(const ConvParamsH& p, int taps)
 
 int launch_conv_f16_res(const ConvParamsH& p, int mbw, bool pool, hipStream_t s)
 {
-    static const int ng = [] { const char* e = getenv("MP_F16_RES_GROUPS"); return (e && e[0] == '2') ? 2 : 3; }();
+    const int ng = p.res_groups == 2 ? 2 : 3;           // (MP_F16_RES_GROUPS, read per handle in mp_create)
     if (p.img) {           // first encoder block fused in: the pooled 64 -> 64 layer (enc.conv2), reflection padding
         if (!pool || p.pad_zero) return 2;
         if (mbw == 32) return launch_res<32, true, 2, true>(p, s);

@@ -128,6 +128,7 @@ struct ConvParamsH {
     int nitems;           // work items (tile, slice) of the launch (filled in by the launcher)
     _Float16* dummy;      // >= 1 KiB scratch line that masked-off store lanes write to
     int ncu, xcd_shift;   // machine shape, as in ConvParams
+    int res_groups;       // conv_f16_res.hip: independent four-wave groups per CU (3; 2 = MP_F16_RES_GROUPS=2; the fused-first-block launch always runs 2)
     // conv_f16_res.hip with the first encoder block fused in: the fp32 image [B][H][W] and the Cin = 1 layer's parameters
     // ([9][64] tap-major fp16-representable weights, bias, BN scale / shift); img == nullptr: p.in is read
     const float* img;
