@@ -40,6 +40,8 @@ struct FirstLayer {
 struct Encoder {
     FirstLayer first;
     ConvLayer conv[7];
+    int nconv = 7;                  // 3x3 layers after the first one: 7, or 3 with double_convolution: false (MultiPoint.py:147-148)
+    bool first_pool = false;        // ... where MaxPool2d(2,2) follows the first block directly
 };
 
 struct ProfEntry {
@@ -421,14 +423,24 @@ int build_encoder(mp_handle* h, TensorMap& tm, Encoder& E, const std::string& pr
     // MultiPoint: generate_encoder (MultiPoint.py:168-185): Sequential indices, 4 modules per conv block
     // (pad, conv, X, Y) and one MaxPool2d after blocks 2, 4, 6.
     // SuperPointMagicLeap (SuperPointMagicLeap.py:16-23): named convolutions, no BatchNorm.
-    static const int conv_idx[8] = {1, 5, 10, 14, 19, 23, 28, 32};
+    // double_convolution: false -- one (pad, conv, X, Y) group per stage, a pool after stages 1-3: indices 1, 6, 11, 16
+    static const int conv_idx2[8] = {1, 5, 10, 14, 19, 23, 28, 32};
+    static const int conv_idx1[4] = {1, 6, 11, 16};
+    const bool dbl = h->cfg.double_convolution != 0;
+    const int* conv_idx = dbl ? conv_idx2 : conv_idx1;
     static const char* ml_names[8] = {"conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b"};
     // MultiPoint.py:38-53: channel_version 0 [1,64,64,128,128], 1 [1,32,64,96,128], 2 [1,8,16,32,64]
     static const int stage_ch[3][5] = {{1, 64, 64, 128, 128}, {1, 32, 64, 96, 128}, {1, 8, 16, 32, 64}};
     const int* sc = stage_ch[h->cfg.channel_version];
-    const int chan[9] = {1, sc[1], sc[1], sc[2], sc[2], sc[3], sc[3], sc[4], sc[4]};
+    const int chan2[9] = {1, sc[1], sc[1], sc[2], sc[2], sc[3], sc[3], sc[4], sc[4]};
+    const int chan1[9] = {1, sc[1], sc[2], sc[3], sc[4], 0, 0, 0, 0};
+    const int* chan = dbl ? chan2 : chan1;
     auto pad32 = [](int c) { return ((c + 31) / 32) * 32; };
-    static const bool pool[8] = {false, true, false, true, false, true, false, false};
+    static const bool pool2[8] = {false, true, false, true, false, true, false, false};
+    static const bool pool1[8] = {true, true, true, false, false, false, false, false};
+    const bool* pool = dbl ? pool2 : pool1;
+    E.nconv = dbl ? 7 : 3;
+    E.first_pool = pool[0];
     const int bn_off = h->cfg.bn_first ? 1 : 2;
     auto conv_key = [&](int i) {
         return h->cfg.key_layout == 1 ? std::string(ml_names[i]) : prefix + "." + std::to_string(conv_idx[i]);
@@ -461,7 +473,7 @@ int build_encoder(mp_handle* h, TensorMap& tm, Encoder& E, const std::string& pr
             if ((rc = upload(h, bias, &E.first.bias_h))) return rc;
         }
     }
-    for (int i = 1; i < 8; ++i) {
+    for (int i = 1; i <= E.nconv; ++i) {
         int rc = build_conv(h, tm, E.conv[i - 1], kEncNames[i - 1], {conv_key(i)}, {bn_key(i)}, {chan[i + 1]}, pad32(chan[i]), 9,
                             pool[i], true, chan[i], true);
         if (rc) return rc;
@@ -899,8 +911,10 @@ int mp_load_weights(mp_handle* h, const mp_model_config* cfg, const mp_tensor* t
                                   "(its K chunks are 64 channels wide)");
     if (cfg->channel_version != 0 && cfg->key_layout == 1)
         return fail(h, MP_EINVAL, "unsupported model config: SuperPointMagicLeap has channel_version 0 shapes");
-    if (!cfg->double_convolution)
-        return fail(h, MP_EINVAL, "unsupported model config: double_convolution must be true");
+    if (!cfg->double_convolution && cfg->mixed_precision)
+        return fail(h, MP_EINVAL, "unsupported model config: the fp16 path (mixed_precision) needs double_convolution: true");
+    if (!cfg->double_convolution && cfg->key_layout == 1)
+        return fail(h, MP_EINVAL, "unsupported model config: SuperPointMagicLeap has two convolutions per stage");
     if (cfg->descriptor_head && cfg->descriptor_size != 64 && cfg->descriptor_size != 128 &&
         cfg->descriptor_size != 256)
         return fail(h, MP_EINVAL, "unsupported model config: descriptor_size must be 64, 128 or 256");
@@ -936,7 +950,7 @@ int mp_load_weights(mp_handle* h, const mp_model_config* cfg, const mp_tensor* t
     // both 3x3 head convs read the same encoder output: one launch with N = hc (+hc); hc = 256 for channel_version 0,
     // descriptor_size otherwise (MultiPoint.py:38-53)
     const int hc = cfg->channel_version == 0 ? 256 : cfg->descriptor_size;
-    const int enc_out = h->enc[0].conv[6].cout;                 // 128 (64 for channel_version 2)
+    const int enc_out = h->enc[0].conv[h->enc[0].nconv - 1].cout;                 // 128 (64 for channel_version 2)
     const int enc_real = cfg->channel_version == 2 ? 64 : 128;
     h->head_channels = hc;
     if (cfg->descriptor_head)
@@ -1019,31 +1033,33 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
         c1.channels = E.first.channels;
         // the fused loader is a 64-channel direct-convolution kernel; with Winograd on, the standalone first block +
         // Winograd second convolution is faster than the fused direct kernel
-        const bool fuse1 = h->fuse_first && h->cfg.channel_version == 0 &&
+        const bool fuse1 = h->fuse_first && h->cfg.channel_version == 0 && !E.first_pool &&
                            (!h->wino || uses_wino43(h, E.conv[0], H, W, true));
         // a tensor written by conv1 or an F(4x4,3x3) layer AND read by an F(4x4,3x3) layer is channel-quad planar
         // -- when the producer's stores are few: conv1, or a POOLED F(4x4,3x3) layer.  (An un-pooled layer stores 16 pixels per
         // lane and tile; planar, a store instruction then writes 16-byte pieces 64 bytes apart instead of 64-byte runs, which
         // costs the producer more than the consumer's patch DMAs gain: conv3 1.29 vs 1.17 ms.)
         bool f43[8] = {}, pl[9] = {};               // pl[i]: the input tensor of E.conv[i] is planar
-        for (int i = 0, hh = H, ww = W; i < 7; ++i) {
+        const int H1 = E.first_pool ? H / 2 : H, W1 = E.first_pool ? W / 2 : W;      // frame of the first block's output
+        for (int i = 0, hh = H1, ww = W1; i < E.nconv; ++i) {
             f43[i] = uses_wino43(h, E.conv[i], hh, ww, i == 0 && fuse1);
             if (E.conv[i].pool) { hh /= 2; ww /= 2; }
         }
-        pl[0] = h->planar && f43[0];
-        for (int i = 1; i < 7; ++i) pl[i] = h->planar && f43[i - 1] && f43[i] && (E.conv[i - 1].pool || h->planar == 2);
+        pl[0] = h->planar && f43[0] && !E.first_pool;
+        for (int i = 1; i < E.nconv; ++i) pl[i] = h->planar && f43[i - 1] && f43[i] && (E.conv[i - 1].pool || h->planar == 2);
         c1.out_planar = pl[0] ? 1 : 0;
+        c1.pool = E.first_pool ? 1 : 0;
         if (!fuse1) {
             prof_begin(h, "enc.conv1", 2.0 * 9 * 64 * (double)nb * H * W, s);
             launch_conv_first(c1, s);
             prof_end(h, s);
         }
-        int hh = H, ww = W;
+        int hh = H1, ww = W1;
         float* src = P;
         float* dst = Q;
-        for (int i = 0; i < 7; ++i) {
+        for (int i = 0; i < E.nconv; ++i) {
             const ConvLayer& L = E.conv[i];
-            if ((rc = run_conv(h, L, src, L.cin, 0, i == 6 ? X : dst, L.cout, 0, nb, hh, ww, lptr[e], s,
+            if ((rc = run_conv(h, L, src, L.cin, 0, i == E.nconv - 1 ? X : dst, L.cout, 0, nb, hh, ww, lptr[e], s,
                      (i == 0 && fuse1) ? &E.first : nullptr, images, pl[i], pl[i + 1]))) return rc;
             if (L.pool) { hh /= 2; ww /= 2; }
             float* t = src; src = dst; dst = t;

@@ -83,6 +83,7 @@ struct Conv1Params {
     int pad_zero, bn_first;
     int channels;         // output channels incl. zero padding: 64 (channel_version 0) or 32
     int out_planar;       // write [B][channels/4][H][W][4] (the consumer is conv_wino43.hip) instead of NHWC
+    int pool;             // double_convolution: false (MultiPoint.py:147-148): MaxPool2d(2,2) follows the block -> out [B][H/2][W/2][channels]
 };
 
 // the conv launchers return 0, or 1 when the launch has more work items than the kernels' 32-bit magic-number tile decode

@@ -39,8 +39,8 @@ class MultiPoint:
             raise ValueError('channel_version must be 0, 1 or 2 (MultiPoint.py:38-53)')
         if self.config['channel_version'] != 0 and self.config['mixed_precision']:
             raise ValueError('mixed_precision (fp16 MFMA path) needs channel_version 0')
-        if not self.config['double_convolution']:
-            raise ValueError('multipoint_amd supports double_convolution=True only')
+        if not self.config['double_convolution'] and self.config['mixed_precision']:
+            raise ValueError('mixed_precision (fp16 MFMA path) needs double_convolution=True')
         self.training = False
         self.device = None
         self._handle = None
@@ -71,8 +71,12 @@ class MultiPoint:
         # MultiPoint.py:38-53
         stage = {0: [1, 64, 64, 128, 128], 1: [1, 32, 64, 96, 128], 2: [1, 8, 16, 32, 64]}[c['channel_version']]
         head_channels = 256 if c['channel_version'] == 0 else c['descriptor_size']
-        chan = [1, stage[1], stage[1], stage[2], stage[2], stage[3], stage[3], stage[4], stage[4]]
-        conv_idx = [1, 5, 10, 14, 19, 23, 28, 32]
+        if c['double_convolution']:
+            chan = [1, stage[1], stage[1], stage[2], stage[2], stage[3], stage[3], stage[4], stage[4]]
+            conv_idx = [1, 5, 10, 14, 19, 23, 28, 32]
+        else:       # getConvolutionBlock (MultiPoint.py:147-148): one (pad, conv, X, Y) group per stage, a pool after stages 1-3
+            chan = list(stage)
+            conv_idx = [1, 6, 11, 16]
         bn_off = 1 if c['bn_first'] else 2
         names = ['encoder_thermal', 'encoder_optical'] if c['multispectral'] else ['encoder']
         for name in names:

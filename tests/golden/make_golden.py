@@ -62,7 +62,10 @@ def main():
     variants = {}
     for name, upd in [('multispectral', {'multispectral': True}), ('zero_pad', {'reflection_pad': False}),
                       ('bn_first', {'bn_first': True}), ('desc256', {'descriptor_size': 256}),
-                      ('no_final_bn', {'final_batchnorm': False}), ('no_normalize', {'normalize_descriptors': False})]:
+                      ('no_final_bn', {'final_batchnorm': False}), ('no_normalize', {'normalize_descriptors': False}),
+                      ('single_conv', {'double_convolution': False}),
+                      ('single_conv_ms_zero_pad', {'double_convolution': False, 'multispectral': True, 'reflection_pad': False,
+                                                   'bn_first': True})]:
         c = dict(cfg); c.update(upd)
         s = O.make_weights(3, c)
         im = O.make_images(13, 3, 32, 48)

@@ -74,6 +74,28 @@ def test_forward_kernel_variants(oracle, monkeypatch, env, B, H, W):
     assert (out['desc'].cpu() - ref['desc']).abs().max().item() <= DESC_TOL
 
 
+@pytest.mark.parametrize('env', [{}, {'MP_WINO43': '0'}, {'MP_NO_WINOGRAD': '1'}])
+@pytest.mark.parametrize('upd', [{}, {'multispectral': True, 'bn_first': True}, {'reflection_pad': False},
+                                 {'channel_version': 1, 'descriptor_size': 128}])
+@pytest.mark.parametrize('B,H,W', [(3, 72, 104), (2, 240, 320), (1, 16, 16)])
+def test_single_convolution_per_stage(oracle, monkeypatch, env, upd, B, H, W):
+    """`double_convolution: false` (MultiPoint.py:144-148): one 3x3 convolution per stage, MaxPool2d(2,2) directly behind the first
+    block (conv_first_pool_kernel) and behind stages 2 and 3; state_dict keys encoder.{1,6,11,16} / BN {3,8,13,18} -- the three
+    convolution families against the oracle (itself pinned on this layout by tests/golden/forward_variants.npz)."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    cfg = dict(oracle.SHIPPED_MODEL_CONFIG); cfg['double_convolution'] = False; cfg.update(upd)
+    net, sd = _net(oracle, cfg, seed=8)
+    assert 'encoder.16.weight' in sd or 'encoder_thermal.16.weight' in sd
+    img = oracle.make_images(61 + W, B, H, W)
+    flags = torch.tensor([[i % 2 == 0] for i in range(B)])
+    ref = oracle.forward(sd, img, cfg, is_optical=flags)
+    out = net({'image': img.cuda(), 'is_optical': flags})
+    assert out['desc'].shape == (B, cfg['descriptor_size'], H // 8, W // 8)
+    assert (out['prob'].cpu() - ref['prob']).abs().max().item() <= PROB_TOL
+    assert (out['desc'].cpu() - ref['desc']).abs().max().item() <= DESC_TOL
+
+
 @pytest.mark.parametrize('upd', [{}, {'multispectral': True}, {'bn_first': True}])
 @pytest.mark.parametrize('B,H,W', [(3, 72, 104), (2, 16, 16), (1, 240, 320), (5, 40, 264), (2, 480, 640)])
 def test_first_block_inside_f43_equals_standalone(oracle, monkeypatch, upd, B, H, W):
@@ -159,6 +181,9 @@ def test_forward_matches_reference_golden(oracle, shipped, golden_dir):
 @pytest.mark.parametrize('name,upd', [('multispectral', {'multispectral': True}), ('zero_pad', {'reflection_pad': False}),
                                       ('bn_first', {'bn_first': True}), ('desc256', {'descriptor_size': 256}),
                                       ('no_final_bn', {'final_batchnorm': False}),
+                                      ('single_conv', {'double_convolution': False}),
+                                      ('single_conv_ms_zero_pad', {'double_convolution': False, 'multispectral': True,
+                                                                   'reflection_pad': False, 'bn_first': True}),
                                       ('no_normalize', {'normalize_descriptors': False})])
 def test_forward_variants_match_reference_golden(oracle, golden_dir, name, upd):
     g = np.load(os.path.join(golden_dir, 'forward_variants.npz'))

@@ -76,7 +76,7 @@ def test_product_does_not_import_oracle():
 def test_state_dict_layout_matches_oracle_spec(oracle):
     import multipoint_amd.models as M
     for cfg in (oracle.SHIPPED_MODEL_CONFIG, {'multispectral': True}, {'bn_first': True, 'multispectral': False},
-                {'final_batchnorm': False, 'descriptor_head': False}):
+                {'final_batchnorm': False, 'descriptor_head': False}, {'double_convolution': False, 'bn_first': True}):
         ours = [(k, tuple(s), d) for k, s, d in M.MultiPoint(dict(cfg)).state_dict_spec()]
         theirs = [(k, tuple(s), d) for k, s, d in oracle.state_dict_spec(cfg)]
         assert ours == theirs
@@ -106,6 +106,12 @@ def test_load_state_dict_is_strict(oracle):
     M.MultiPoint(cfg).load_state_dict(U.fix_model_weigth_keys(pre))
     with pytest.raises(ValueError):
         M.MultiPoint({'channel_version': 3})
+    # double_convolution: false (MultiPoint.py:144-148): the reference module's own key list -- fp32 path only
+    single = dict(cfg); single['double_convolution'] = False
+    assert [k for k, _, _ in M.MultiPoint(single).state_dict_spec()] == list(oracle.make_weights(0, single).keys())
+    assert 'encoder.16.weight' in oracle.make_weights(0, single) and 'encoder.19.weight' not in oracle.make_weights(0, single)
+    with pytest.raises(ValueError, match='double_convolution'):
+        M.MultiPoint({'double_convolution': False, 'mixed_precision': True})
     with pytest.raises(ValueError):
         net.set_force_return_logits(1)
     with pytest.raises(NotImplementedError):

@@ -39,6 +39,9 @@ def test_forward_240x320_samples(oracle, golden_dir):
 @pytest.mark.parametrize('name,upd', [('multispectral', {'multispectral': True}), ('zero_pad', {'reflection_pad': False}),
                                       ('bn_first', {'bn_first': True}), ('desc256', {'descriptor_size': 256}),
                                       ('no_final_bn', {'final_batchnorm': False}),
+                                      ('single_conv', {'double_convolution': False}),
+                                      ('single_conv_ms_zero_pad', {'double_convolution': False, 'multispectral': True,
+                                                                   'reflection_pad': False, 'bn_first': True}),
                                       ('no_normalize', {'normalize_descriptors': False})])
 def test_forward_variants(oracle, golden_dir, name, upd):
     g = _load(golden_dir, 'forward_variants.npz')
