@@ -65,6 +65,9 @@ struct mp_handle {
     DevBuf ws2;                     // NMS work map + kept lists
     DevBuf ws3;                     // matching arg-min arrays
     DevBuf ws4;                     // pair metrics: warped keypoints + inverse match map
+    DevBuf split_ws;                // F(4x4,3x3) split launches: the ranges' pre-bias output tiles
+    int* split_ctr = nullptr;       // ... and their arrival counters (1024, zero between launches)
+    int splitk_max = 8;             // most ranges the input channels of a small launch are cut into (MP_SPLITK_MAX; 1: never)
     DevBuf nms_state;               // 64 round counters + tile flags
     DevBuf kp_scratch;              // segment counts + list totals of the keypoint compaction
     int* nms_total = nullptr;       // device: undecided candidates summed over all calls since the last read
@@ -574,6 +577,23 @@ int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, 
     int big;
     if (f43) {
         p.wpack = L.u43pack; p.in_planar = in_planar; p.out_planar = out_planar;
+        if (!fuse && B <= 2 && h->splitk_max > 1 && h->split_ctr) {
+            // single-pair latency (the reference's shipped batchsize: 1): a launch with fewer items than half the CUs (conv7 /
+            // conv8 of one 480x640 pair: 40 items of 32 units on 256 CUs) cuts the input channels into 2, 4 or 8 ranges --
+            // (cin / 4) / ranges units each, even and >= 4 -- as long as the items still fit the machine once.  Only for
+            // forwards of one or two images: the ranges are summed in another order than one accumulator chain would, and a
+            // batched forward must not change its bits with the batch size (tests: HA grouping, sharded == single-rank)
+            const long long items = conv_wino43_items(p);
+            const int units = L.cin / 4;
+            int ks = 0;
+            while ((items << (ks + 1)) <= h->ncu && (2 << ks) <= h->splitk_max && (units >> (ks + 1)) >= 4 &&
+                   ((units >> (ks + 1)) & 1) == 0 && ((units >> (ks + 1)) << (ks + 1)) == units) ++ks;
+            if (ks > 0 && items <= 1024) {
+                int rc = ensure(h, h->split_ws, (size_t)(items << ks) * (2 * 16 * 512 * 8));
+                if (rc) return rc;
+                p.ks_shift = ks; p.split_scratch = static_cast<float*>(h->split_ws.p); p.split_ctr = h->split_ctr;
+            }
+        }
         big = launch_conv_wino43(p, L.pool, s, fuse != nullptr);
     } else if (L.taps == 9 && L.upack && h->wino && !fuse) {
         p.wpack = L.upack;
@@ -874,9 +894,16 @@ int mp_create(mp_handle** out, int device)
     { const char* e = getenv("MP_WINO43"); if (e && e[0] >= '0' && e[0] <= '2') hh->wino43 = e[0] - '0'; }
     { const char* e = getenv("MP_PERSIST_MIN_ITEMS"); if (e && atoi(e) > 0) hh->persist = atoi(e); }
     { const char* e = getenv("MP_NO_PERSIST"); if (e && e[0] == '1') hh->persist = 0; }
+    { const char* e = getenv("MP_SPLITK_MAX"); if (e && atoi(e) >= 1 && atoi(e) <= 8) hh->splitk_max = atoi(e); }
     if (hipHostMalloc(reinterpret_cast<void**>(&hh->pinned), 4096) != hipSuccess) {
         delete hh;
         return fail(h, MP_ENOMEM, "mp_create: hipHostMalloc failed");
+    }
+    if (hipMalloc(reinterpret_cast<void**>(&hh->split_ctr), 1024 * 4) != hipSuccess ||
+        hipMemset(hh->split_ctr, 0, 1024 * 4) != hipSuccess) {
+        (void)hipHostFree(hh->pinned);
+        delete hh;
+        return fail(h, MP_ENOMEM, "mp_create: hipMalloc failed");
     }
     *out = hh;
     return MP_OK;
@@ -891,6 +918,8 @@ void mp_destroy(mp_handle* h)
     if (h->ws2.p) (void)hipFree(h->ws2.p);
     if (h->ws3.p) (void)hipFree(h->ws3.p);
     if (h->ws4.p) (void)hipFree(h->ws4.p);
+    if (h->split_ws.p) (void)hipFree(h->split_ws.p);
+    if (h->split_ctr) (void)hipFree(h->split_ctr);
     if (h->nms_state.p) (void)hipFree(h->nms_state.p);
     if (h->kp_scratch.p) (void)hipFree(h->kp_scratch.p);
     if (h->nms_total) (void)hipFree(h->nms_total);

@@ -173,9 +173,10 @@ __device__ __forceinline__ void at6(const f32x2 m[6], f32x2 y[4])
 // already reflected) and the weight of channel lane & 3, and receives the 4 channels of its own pixel -- exactly one raw
 // granule, written after ReLU / BatchNorm with one ds_write_b128.  Nothing of the block ever leaves the CU; the image patch of
 // item k + 2 arrives by 4-byte LDS-DMA during the epilogue of item k.
-template <bool POOL, bool BNF, int TC4, bool F1>
+template <bool POOL, bool BNF, int TC4, bool F1, bool SPLIT = false>
 __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
 {
+    static_assert(!(F1 && SPLIT), "the fused first block is never split");
     constexpr int TR4 = 32 / TC4;                      // tile rows x tile columns of an item
     constexpr int OY = 4 * TR4, OX = 4 * TC4;          // output pixels of an item
     constexpr int PY = OY + 2, PX = OX + 2;            // raw patch
@@ -185,12 +186,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     __shared__ __attribute__((aligned(16))) float raw[3 * RB4 + 256];
     __shared__ __attribute__((aligned(16))) float scr[8 * SW4];
     __shared__ __attribute__((aligned(16))) float prm[3 * 64];
+    __shared__ int split_flag;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tb = wave & 1, cb = wave >> 1;             // tile block (16 tiles), channel block (16 couts) of this wave's GEMMs
-    const int NC = p.cin / UC4;                          // units per item (even: cin is a multiple of 8)
+    // units per item (even: cin is a multiple of 8).  SPLIT: the launcher cut the input channels into 2^ks_shift ranges -- an
+    // item is (tile block, virtual slice = slice * ranges + range) and runs the units of its range only
+    const int NC = SPLIT ? (p.cin / UC4) >> p.ks_shift : p.cin / UC4;
 
     // ---- work items: (tile block, slice) of this XCD's contiguous eighth ----
     const XcdRange xr = xcd_range(p.nitems, p.xcd_shift);
@@ -213,6 +217,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
         // planar input [B][cin/4][H][W][4]: base of the image's first plane; a unit's plane is chunk * H * W * 4 floats on
         w.in_base = p.in_planar ? p.in + (long long)w.img * (p.cin / 4) * p.H * p.W * 4
                                 : p.in + (long long)w.img * p.H * p.W * p.in_cstride + p.in_coff;
+        if constexpr (SPLIT)      // first unit of the item's range of input channels
+            w.in_base += (long long)((w.slice & ((1 << p.ks_shift) - 1)) * NC) * (p.in_planar ? (long long)p.H * p.W * 4 : UC4);
         return w;
     };
 
@@ -274,7 +280,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     auto u_ptr = [&](int slice) __attribute__((always_inline)) -> const float* {      // unit 0 of a slice
         return p.wpack + (long long)slice * NC * UB4;
     };
-    auto load_prm = [&](int slice) __attribute__((always_inline)) {
+    auto load_prm = [&](int vslice) __attribute__((always_inline)) {
+        const int slice = SPLIT ? vslice >> p.ks_shift : vslice;
         if (tid < 64) {
             prm[tid] = p.bias[slice * 64 + tid]; prm[64 + tid] = p.scale[slice * 64 + tid]; prm[128 + tid] = p.shift[slice * 64 + tid];
         }
@@ -706,16 +713,61 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
             const f32x4 s4 = *reinterpret_cast<const f32x4*>(&prm[64 + cl]);
             const f32x4 t4 = *reinterpret_cast<const f32x4*>(&prm[128 + cl]);
             const int oy = cur.y0 + 4 * (tl / TC4), ox = cur.x0 + 4 * (tl % TC4);
-            const int ch0 = cur.slice * 64 + cl;
+            const int ch0 = (SPLIT ? cur.slice >> p.ks_shift : cur.slice) * 64 + cl;
             const int cs = p.out_cstride;
             // per channel pair h (registers 2h, 2h+1): transform, activation, [pool] -- the 72 accumulator registers of a
             // finished pair are dead before the next one starts (register budget: 256 per lane); the first pair's results
             // wait in registers so that every pixel is ONE 16-byte store of the lane's 4 channels
             constexpr int NO = POOL ? 2 : 4;                            // output rows / columns per tile
             f32x2 keep[NO][NO];
+            // SPLIT: this item's share of the sum over input channels leaves as pre-bias output tiles; the last range of the
+            // group to arrive adds the shares up in range order (deterministic) and continues with the ordinary epilogue
+            bool finish = true;
+            const unsigned long long* part0 = nullptr;
+            if constexpr (SPLIT) {
+                // (agent-scope relaxed atomics = sc1 stores / loads: coherent across the XCDs' L2s by themselves -- a device-wide
+                // fence would write back and invalidate the whole L2 instead: 40 us)
+                unsigned long long* const part = reinterpret_cast<unsigned long long*>(p.split_scratch) + (long long)item * (2 * 16 * 512) + tid;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    f32x2 tcol[4][6];
+#pragma unroll
+                    for (int j = 0; j < 6; ++j) {
+                        f32x2 m[6], y[4];
+#pragma unroll
+                        for (int i = 0; i < 6; ++i) m[i] = f32x2{acc[6 * i + j][2 * h], acc[6 * i + j][2 * h + 1]};
+                        at6(m, y);
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) tcol[a][j] = y[a];
+                    }
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        f32x2 y[4];
+                        at6(tcol[a], y);
+#pragma unroll
+                        for (int b = 0; b < 4; ++b)
+                            __hip_atomic_store(&part[(h * 16 + a * 4 + b) * 512], __builtin_bit_cast(unsigned long long, y[b]),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's shares have been written ...
+                __syncthreads();                                        // ... and every wave's, before the group's count moves
+                if (tid == 0)
+                    split_flag = __hip_atomic_fetch_add(&p.split_ctr[item >> p.ks_shift], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __syncthreads();
+                finish = split_flag == (1 << p.ks_shift) - 1;
+                if (finish) {
+                    if (tid == 0)                                       // ready for the next launch
+                        __hip_atomic_store(&p.split_ctr[item >> p.ks_shift], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    part0 = reinterpret_cast<const unsigned long long*>(p.split_scratch) +
+                            (long long)((item >> p.ks_shift) << p.ks_shift) * (2 * 16 * 512) + tid;
+                }
+            }
+            if (finish) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 f32x2 tcol[4][6];                                       // T[a][j] = sum_i A^T[a][i] M[i][j]
+                if constexpr (!SPLIT) {
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
                     f32x2 m[6], y[4];
@@ -725,12 +777,53 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
 #pragma unroll
                     for (int a = 0; a < 4; ++a) tcol[a][j] = y[a];
                 }
+                }
                 const f32x2 bb = {b4[2 * h], b4[2 * h + 1]}, ss = {s4[2 * h], s4[2 * h + 1]}, tt = {t4[2 * h], t4[2 * h + 1]};
                 f32x2 yv[4][4];                                         // [row a][col b] -> this pair's 2 channels
+                f32x2 ysum[SPLIT ? 4 : 1][4];
+                if constexpr (SPLIT) {
+                    // the shares come from memory (sc1 loads, ~1.5 us a trip): every load of a batch is issued before the first
+                    // value is used -- two rows of up to 4 ranges per batch, of 8 ranges row by row (64 registers)
+                    const int KS = 1 << p.ks_shift;
+                    auto gather = [&](auto ab_tag, auto a0_tag) __attribute__((always_inline)) {
+                        constexpr int AB = decltype(ab_tag)::value, KMAX = AB == 2 ? 4 : 8, a0 = decltype(a0_tag)::value;
+                        unsigned long long rawv[KMAX][AB * 4];
+#pragma unroll
+                        for (int k = 0; k < KMAX; ++k)
+                            if (k < KS) {
+#pragma unroll
+                                for (int i = 0; i < AB * 4; ++i)
+                                    rawv[k][i] = __hip_atomic_load(&part0[(long long)k * (2 * 16 * 512) + (h * 16 + a0 * 4 + i) * 512],
+                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            }
+#pragma unroll
+                        for (int i = 0; i < AB * 4; ++i) {
+                            f32x2 y = __builtin_bit_cast(f32x2, rawv[0][i]);
+#pragma unroll
+                            for (int k = 1; k < KMAX; ++k)
+                                if (k < KS) y += __builtin_bit_cast(f32x2, rawv[k][i]);        // range order: deterministic
+                            ysum[a0 + i / 4][i % 4] = y;
+                        }
+                    };
+                    if (KS <= 4) {
+                        gather(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
+                        gather(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+                    } else {
+                        gather(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
+                        gather(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+                        gather(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
+                        gather(std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{});
+                    }
+                }
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     f32x2 y[4];
-                    at6(tcol[a], y);
+                    if constexpr (SPLIT) {
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) y[b] = ysum[a][b];
+                    } else {
+                        at6(tcol[a], y);
+                    }
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
                         f32x2 v = y[b] + bb;
@@ -783,6 +876,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                     }
                 }
             }
+            }
         }
         MPQ_T(t_e1);
         MPQ_ADD(2, t_e0, t_e1);                                        // epilogue
@@ -803,32 +897,33 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     }
 }
 
-template <bool POOL, int TC4, bool F1 = false>
+template <bool POOL, int TC4, bool F1 = false, bool SPLIT = false>
 int launch_q(const ConvParams& p, hipStream_t s)
 {
     constexpr int OY = 4 * (32 / TC4), OX = 4 * TC4;
     ConvParams q = p;
+    if (SPLIT) q.nslices = p.nslices << p.ks_shift;         // virtual slices: (slice, range of input channels)
     q.tiles_x = (p.W + OX - 1) / OX; q.tiles_y = (p.H + OY - 1) / OY;
-    const long long nitems = (long long)p.B * q.tiles_x * q.tiles_y * p.nslices;
+    const long long nitems = (long long)p.B * q.tiles_x * q.tiles_y * q.nslices;
     if (nitems <= 0) return 0;
     auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ull / (unsigned)d) + 1ull); };
-    q.magic_slices = magic(p.nslices); q.magic_tx = magic(q.tiles_x); q.magic_ty = magic(q.tiles_y);
-    const long long dmax = std::max(std::max(p.nslices, q.tiles_x), q.tiles_y);
+    q.magic_slices = magic(q.nslices); q.magic_tx = magic(q.tiles_x); q.magic_ty = magic(q.tiles_y);
+    const long long dmax = std::max(std::max(q.nslices, q.tiles_x), q.tiles_y);
     if (nitems * dmax >= 0x100000000ll) return 1;
     q.nitems = (int)nitems;
     const unsigned grid = persistent_grid(nitems, p.ncu, p.xcd_shift);
     const ConvParams& pp = q;
-    if (p.bn_first) hipLaunchKernelGGL((conv_wino43_kernel<POOL, true, TC4, F1>), dim3(grid), dim3(512), 0, s, pp);
-    else hipLaunchKernelGGL((conv_wino43_kernel<POOL, false, TC4, F1>), dim3(grid), dim3(512), 0, s, pp);
+    if (p.bn_first) hipLaunchKernelGGL((conv_wino43_kernel<POOL, true, TC4, F1, SPLIT>), dim3(grid), dim3(512), 0, s, pp);
+    else hipLaunchKernelGGL((conv_wino43_kernel<POOL, false, TC4, F1, SPLIT>), dim3(grid), dim3(512), 0, s, pp);
     return 0;
 }
 
 // the item shape that covers the frame with fewer items (16 x 32 pixels on a tie: longer contiguous patch rows)
-template <bool POOL>
+template <bool POOL, bool SPLIT = false>
 int launch_shape(const ConvParams& p, hipStream_t s)
 {
     const long long wide = (long long)((p.W + 31) / 32) * ((p.H + 15) / 16), tall = (long long)((p.W + 15) / 16) * ((p.H + 31) / 32);
-    return tall < wide ? launch_q<POOL, 4>(p, s) : launch_q<POOL, 8>(p, s);
+    return tall < wide ? launch_q<POOL, 4, false, SPLIT>(p, s) : launch_q<POOL, 8, false, SPLIT>(p, s);
 }
 
 }  // namespace
@@ -842,11 +937,24 @@ bool conv_wino43_supports(const ConvParams& p)
            p.in_cstride % 4 == 0 && p.in_coff % 4 == 0 && p.out_cstride % 4 == 0 && p.out_coff % 4 == 0;
 }
 
+// work items of a launch (the larger of the two item shapes' counts is never chosen): what api.hip sizes the split by
+long long conv_wino43_items(const ConvParams& p)
+{
+    const long long wide = (long long)((p.W + 31) / 32) * ((p.H + 15) / 16), tall = (long long)((p.W + 15) / 16) * ((p.H + 31) / 32);
+    return (long long)p.B * std::min(wide, tall) * p.nslices;
+}
+
 // p.wpack must point at the F(4x4,3x3) weights packed by pack_wino43_weights() (api.hip).  fuse_first: the input is the
 // first encoder block of p.img (p.w1 / b1 / s1 / t1, 64 channels), evaluated inside the kernel; the layer must be the pooled
-// 64 -> 64 one (enc.conv2)
+// 64 -> 64 one (enc.conv2).  p.ks_shift > 0 (small launches; (cin / 4) >> ks_shift even and >= 4): the input
+// channels run as 2^ks_shift items per (tile block, slice) that meet in p.split_scratch
 int launch_conv_wino43(const ConvParams& p, bool pool, hipStream_t s, bool fuse_first)
 {
     if (fuse_first) return pool && p.cin == 64 ? launch_q<true, 8, true>(p, s) : 2;          // 2: shape not covered
+    if (p.ks_shift > 0) {
+        const int ncs = (p.cin / 4) >> p.ks_shift;
+        if (ncs < 4 || (ncs & 1) || (ncs << p.ks_shift) * 4 != p.cin || !p.split_scratch || !p.split_ctr) return 2;
+        return pool ? launch_shape<true, true>(p, s) : launch_shape<false, true>(p, s);
+    }
     return pool ? launch_shape<true>(p, s) : launch_shape<false>(p, s);
 }

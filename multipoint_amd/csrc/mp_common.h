@@ -46,6 +46,12 @@ struct ConvParams {
     // the device = workgroups of a one-per-CU persistent grid, and log2 of its XCD count (workgroup b runs on XCD b mod nxcd;
     // each XCD has its own L2, so a persistent workgroup walks a contiguous share of ITS XCD's items)
     int ncu, xcd_shift;
+    // conv_wino43.hip, small launches (single-pair latency): the input channels of an item are cut into 2^ks_shift ranges that
+    // run as separate items; their pre-bias output tiles meet in split_scratch and the LAST range to arrive (split_ctr, one
+    // counter per group, left at zero) sums them in range order and runs the epilogue.  ks_shift = 0: off.
+    int ks_shift;
+    float* split_scratch;     // [virtual item][2][16][512] f32x2
+    int* split_ctr;           // [group]
 };
 
 // persistent schedule shared by the persistent kernels: the items are cut into one contiguous range per XCD, and the
@@ -107,6 +113,7 @@ int launch_conv_wino(const ConvParams& p, bool pool, hipStream_t s);
 #define MP_W43_B 1.5
 #endif
 bool conv_wino43_supports(const ConvParams& p);
+long long conv_wino43_items(const ConvParams& p);      // work items the launch would have (B x tile blocks x slices)
 int launch_conv_wino43(const ConvParams& p, bool pool, hipStream_t s, bool fuse_first = false);
 
 // fp16 path (mixed_precision: activations and packed weights fp16, fp32 accumulate; conv_f16.hip).

@@ -125,8 +125,12 @@ def test_driver_against_reference_golden(oracle, golden_dir, name):
     assert (diff > 1e-4).float().mean().item() <= 5e-3, (name, (diff > 1e-4).float().mean().item())
     assert diff.median().item() <= 1e-6 and diff.mean().item() <= 2e-5, (name, diff.mean().item())
     assert ((got == 0) != (want == 0)).float().mean().item() <= 5e-3        # min_count zeroing
-    # grouping of the views into forwards does not change a bit
-    assert torch.equal(_run_case(oracle, golden, name, max_images=2).cpu(), got)
+    # grouping of the views into (batched) forwards does not change a bit
+    assert torch.equal(_run_case(oracle, golden, name, max_images=8).cpu(), got)
+    # ... forwards of one or two images take the single-pair latency path (input channels of the small launches summed in
+    # ranges, conv_wino43.hip SPLIT): another summation order, the same tolerance class
+    two = _run_case(oracle, golden, name, max_images=2).cpu()
+    assert (two - got).abs().max().item() <= 2e-5 and ((two == 0) != (got == 0)).float().mean().item() <= 1e-3
 
 
 def test_driver_draws_the_reference_sequence(oracle, golden_dir):

@@ -74,6 +74,37 @@ def test_forward_kernel_variants(oracle, monkeypatch, env, B, H, W):
     assert (out['desc'].cpu() - ref['desc']).abs().max().item() <= DESC_TOL
 
 
+@pytest.mark.parametrize('B,H,W', [(2, 480, 640), (2, 240, 320), (1, 128, 96), (3, 64, 64)])
+def test_split_input_channels_on_small_launches(oracle, monkeypatch, B, H, W):
+    """Single-pair latency path (forwards of one or two images): an F(4x4,3x3) launch with fewer items than half the CUs runs the input channels of an item as
+    2 / 4 / 8 separate items whose pre-bias output tiles the last one to arrive sums in range order (conv_wino43.hip, SPLIT).
+    Against the oracle, against the unsplit launch (MP_SPLITK_MAX=1: another summation order, same tolerance class as any two
+    kernel variants), and bit-identical from run to run -- the arrival order must not show."""
+    img = oracle.make_images(77 + W, B, H, W)
+    net, sd = _net(oracle, oracle.SHIPPED_MODEL_CONFIG, seed=9)
+    a = net({'image': img.cuda()})
+    a2 = net({'image': img.cuda()})
+    for _ in range(3):
+        a3 = net({'image': img.cuda()})
+        assert torch.equal(a['prob'], a3['prob']) and torch.equal(a['desc'], a3['desc'])
+    assert torch.equal(a['prob'], a2['prob']) and torch.equal(a['desc'], a2['desc'])
+    monkeypatch.setenv('MP_SPLITK_MAX', '1')
+    net1, _ = _net(oracle, oracle.SHIPPED_MODEL_CONFIG, seed=9)
+    b = net1({'image': img.cuda()})
+    monkeypatch.setenv('MP_SPLITK_MAX', '2')
+    net2, _ = _net(oracle, oracle.SHIPPED_MODEL_CONFIG, seed=9)
+    c = net2({'image': img.cuda()})
+    ref = oracle.forward(sd, img, oracle.SHIPPED_MODEL_CONFIG)
+    for o in (a, b, c):
+        assert (o['prob'].cpu() - ref['prob']).abs().max().item() <= PROB_TOL
+        assert (o['desc'].cpu() - ref['desc']).abs().max().item() <= DESC_TOL
+    if B <= 2:
+        assert not torch.equal(a['desc'], b['desc'])        # the split really ran
+    else:       # forwards of more than two images never split: their bits must not depend on the batch size
+        assert torch.equal(a['desc'], b['desc']) and torch.equal(a['prob'], b['prob'])
+    assert (a['prob'] - b['prob']).abs().max().item() <= 3e-5 and (a['desc'] - b['desc']).abs().max().item() <= 3e-6
+
+
 @pytest.mark.parametrize('env', [{}, {'MP_WINO43': '0'}, {'MP_NO_WINOGRAD': '1'}])
 @pytest.mark.parametrize('upd', [{}, {'multispectral': True, 'bn_first': True}, {'reflection_pad': False},
                                  {'channel_version': 1, 'descriptor_size': 128}])
