@@ -15,5 +15,6 @@ python3 bench.py --workload c5 > "$R/bench_c5.json" 2> "$R/bench_c5.err"
 python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --no-cpu-baseline > "$R/bench_rccl.json" 2> "$R/bench_rccl.err"
 MP_WINO43=0 python3 bench.py --no-cpu-baseline > "$R/bench_f22.json" 2> "$R/bench_f22.err"
 MP_F16_NO_RES=1 python3 bench.py --workload c5 --no-cpu-baseline > "$R/bench_c5_stream.json" 2> "$R/bench_c5_stream.err"
+{ python3 tools/latency.py; MP_SPLITK_MAX=1 python3 tools/latency.py | sed -e 's/^/MP_SPLITK_MAX=1  /'; python3 tools/bench_layers.py 2 480 640; } 2>&1 | grep -v amdgpu.ids > "$R/latency.txt"
 bash tools/pmc_f16.sh "$R/sq_c5" > "$R/sq_c5.txt" 2>&1
 ls -l "$R" | head -40

@@ -121,5 +121,7 @@ for name, out in (('bench_n1', 'bench_n1'), ('bench_c5', 'bench_c5_f16_n1'), ('b
         lines = [l for l in open(path) if l.startswith('{')]
         if lines:
             json.dump(json.loads(lines[-1]), open(os.path.join(dst, '%s_%s.json' % (tag, out)), 'w'), indent=1)
+if os.path.exists(os.path.join(src, 'latency.txt')):
+    shutil.copy(os.path.join(src, 'latency.txt'), os.path.join(dst, tag + '_latency.txt'))
 if os.path.exists(os.path.join(src, 'sq_c5.txt')):
     shutil.copy(os.path.join(src, 'sq_c5.txt'), os.path.join(dst, tag + '_pmc_sq_counters_c5.txt'))
