@@ -763,7 +763,6 @@ int nms_common(mp_handle* h, const float* prob, const unsigned char* mask, int B
     int* list_idx = reinterpret_cast<int*>(work + n);
     float* list_score = work + 2 * n;
     int* remaining = static_cast<int*>(h->nms_state.p);
-    MP_HIP(hipMemsetAsync(remaining, 0, 64 * 4, s));
     // the candidate listing (prob * mask > min_prob) is fused into round 0, which reads the probability map itself
     // Rounds: a fixed number without any host read (max_rounds > 0, at most 64), or groups of 8 with one 4-byte read
     // of the undecided count after each group until it is zero (max_rounds == 0).  A round settles every chain of
@@ -773,12 +772,12 @@ int nms_common(mp_handle* h, const float* prob, const unsigned char* mask, int B
     const int per = max_rounds > 0 ? (max_rounds < 64 ? max_rounds : 64) : 8;
     const int cap = max_rounds > 0 ? per : 4096;
     for (;;) {
-        if (round >= 64) MP_HIP(hipMemsetAsync(remaining + (round & 63), 0, 8 * 4, s));      // recycle 8 counter slots
         for (int r = 0; r < per && round < cap; ++r, ++round) {
             if (round == 0) launch_nms_round0(prob, mask, min_prob, work, B, H, W, fp, remaining, s);
             else launch_nms_round(work, B, H, W, fp, remaining, round, s);
         }
         if (max_rounds > 0 || round >= cap) break;
+        launch_nms_accumulate(remaining, B, H, W, round - 1, nullptr, s);          // the tiles' undecided counts -> the round's slot
         MP_HIP(hipMemcpyAsync(h->pinned, remaining + ((round - 1) & 63), 4, hipMemcpyDeviceToHost, s));
         MP_HIP(hipStreamSynchronize(s));
         if (h->pinned[0] == 0) break;
@@ -788,7 +787,7 @@ int nms_common(mp_handle* h, const float* prob, const unsigned char* mask, int B
         MP_HIP(hipMalloc(reinterpret_cast<void**>(&h->nms_total), 4));
         MP_HIP(hipMemsetAsync(h->nms_total, 0, 4, s));
     }
-    launch_nms_accumulate(remaining + ((round - 1) & 63), h->nms_total, s);
+    launch_nms_accumulate(remaining, B, H, W, round - 1, h->nms_total, s);
     launch_select_keypoints(work, B, H, W, topk, K, list_idx, list_score, H * W, kp_yx, kp_score, kp_count,
                             prob_nms, static_cast<int*>(h->kp_scratch.p), s);
     MP_HIP(hipGetLastError());

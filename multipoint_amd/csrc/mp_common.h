@@ -208,7 +208,7 @@ void launch_nms_round(float* work, int B, int H, int W, const NmsFootprint& fp, 
                       int round, hipStream_t s);
 void launch_nms_round0(const float* prob, const uint8_t* mask, float min_prob, float* work, int B, int H, int W,
                        const NmsFootprint& fp, int* remaining, hipStream_t s);
-void launch_nms_accumulate(const int* remaining_last, int* total, hipStream_t s);
+void launch_nms_accumulate(int* remaining, int B, int H, int W, int round, int* total, hipStream_t s);
 // per image: ordered (row-major) list of kept pixels, top-k selection by (score desc, index asc),
 // outputs kp_yx [B][K][2] int32, kp_score [B][K], kp_count [B]; optional dense map prob_nms
 void launch_select_keypoints(const float* work, int B, int H, int W, int topk, int K,

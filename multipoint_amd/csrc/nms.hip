@@ -39,7 +39,9 @@ __global__ __launch_bounds__(256) void nms_init_kernel(const float* __restrict__
     reinterpret_cast<f32x4*>(work)[i] = v;
 }
 
-// flags: [2][B*tiles] ping-pong "tile still has undecided pixels"; remaining[round & 63] = #undecided.
+// flags: [2][B*tiles] ping-pong: the tile's count of undecided pixels after the round (0: the next round skips the tile).  Their
+// sum is what the host asks for (nms_accumulate_kernel) -- NOT a counter every workgroup adds to: 19 200 atomics on one address
+// from eight XCDs take 180 us, which was most of round 0's 216 us.
 // Work inside a tile is list driven: the undecided pixels are kept as a compact LDS list, one thread
 // per list entry, so an iteration costs O(#undecided) instead of O(tile) -- candidates are sparse
 // (a few % of the pixels) and most of them are decided after two or three iterations.
@@ -99,14 +101,48 @@ __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work
         return v;
     };
     if constexpr (RT > 0) {
-        // the tile + halo is (NT + 2 RT)^2 values, a fixed number per thread: ALL loads are issued before the first value is
-        // used (the kernel is latency-bound: one trip to memory per workgroup instead of one per loop iteration)
-        constexpr int LWC = NT + 2 * RT, NL = (LWC * LWC + 255) / 256;
-        float v[NL];
+        // the tile + halo as 16-byte groups: rows of 40 floats from the aligned column x0 - 4 (W is a multiple of 4: a group is
+        // inside the image or outside as a whole), (NT + 2 RT) x 10 groups = 1.5 per thread, ALL loads issued before the first
+        // value is used (the kernel is latency-bound: one trip to memory per workgroup, a quarter of the 4-byte form's requests)
+        constexpr int LWC = NT + 2 * RT, NG = LWC * 10, NL = (NG + 255) / 256;
+        f32x4 v[NL];
 #pragma unroll
-        for (int k = 0; k < NL; ++k) { const int f = tid + k * 256; v[k] = f < LWC * LWC ? fetch(f) : 0.f; }
+        for (int k = 0; k < NL; ++k) {
+            const int idx = tid + k * 256;
+            const int row = idx / 10, g = idx - row * 10;
+            const int gy = y0 + row - RT, gx = x0 - 4 + 4 * g;
+            v[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (idx < NG && gy >= 0 && gy < H && gx >= 0 && gx < W) {
+                const long long gi = (long long)b * H * W + (long long)gy * W + gx;
+                if constexpr (INIT) {
+                    v[k] = *reinterpret_cast<const f32x4*>(prob + gi);
+                    if (mask) {
+                        const uchar4 m = *reinterpret_cast<const uchar4*>(mask + gi);
+                        // prob * valid_mask (predict_align_image_pair.py:128)
+                        v[k][0] *= m.x ? 1.f : 0.f; v[k][1] *= m.y ? 1.f : 0.f; v[k][2] *= m.z ? 1.f : 0.f; v[k][3] *= m.w ? 1.f : 0.f;
+                    }
 #pragma unroll
-        for (int k = 0; k < NL; ++k) { const int f = tid + k * 256; if (f < LWC * LWC) place(f, v[k]); }
+                    for (int e = 0; e < 4; ++e) v[k][e] = (v[k][e] > min_prob) ? v[k][e] : 0.f;      // utils.py:97
+                } else {
+                    v[k] = *reinterpret_cast<const f32x4*>(work + gi);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < NL; ++k) {
+            const int idx = tid + k * 256;
+            const int row = idx / 10, g = idx - row * 10;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int lx = 4 * g + e - 4 + RT;
+                if (idx < NG && lx >= 0 && lx < LWC) {
+                    const int f = row * LWC + lx;
+                    t[f] = v[k][e];
+                    if (v[k][e] > 0.f && row >= RT && row < RT + NT && lx >= RT && lx < RT + NT)
+                        list[0][atomicAdd(&cnt[0], 1)] = (unsigned short)f;
+                }
+            }
+        }
     } else {
         for (int f = tid; f < LW * LW; f += 256) place(f, fetch(f));
     }
@@ -136,12 +172,25 @@ __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work
                     blocked |= (nb > s) || (nb == s && earlier);
                 };
                 if constexpr (RT > 0) {
+                    // every neighbour of the (2 RT + 1)^2 window is read (the halo makes them all addressable) before the first
+                    // one is looked at -- one LDS latency per candidate instead of one per neighbour -- and the footprint mask
+                    // turns the ones outside it into 0: neither kept (< 0) nor of higher priority than a candidate (s > 0)
+                    float nb[2 * RT + 1][2 * RT + 1];
+#pragma unroll
+                    for (int dy = -RT; dy <= RT; ++dy)
+#pragma unroll
+                        for (int dx = -RT; dx <= RT; ++dx) nb[dy + RT][dx + RT] = t[c + dy * LW + dx];
 #pragma unroll
                     for (int dy = -RT; dy <= RT; ++dy) {
                         const unsigned rm = fp.rowmask[dy + RT];
 #pragma unroll
-                        for (int dx = -RT; dx <= RT; ++dx)
-                            if (((rm >> (dx + RT)) & 1u) && (dy != 0 || dx != 0)) visit(dy, dx);
+                        for (int dx = -RT; dx <= RT; ++dx) {
+                            if (dy == 0 && dx == 0) continue;
+                            const float v = ((rm >> (dx + RT)) & 1u) ? nb[dy + RT][dx + RT] : 0.f;
+                            kill |= v < 0.f;
+                            const bool earlier = (dy < 0) || (dy == 0 && dx < 0);       // lower flat index
+                            blocked |= (v > s) || (v == s && earlier);
+                        }
                     }
                 } else {
                     for (int dy = -R; dy <= R; ++dy) {
@@ -167,32 +216,49 @@ __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work
         cur ^= 1;
     }
 
-    // each thread owns 4 pixels of the 32x32 tile: rows (tid>>5) + 8k, column tid&31
-    const int px = tid & 31, py0 = tid >> 5;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int py = py0 + 8 * k;
+    // each thread owns 4 consecutive pixels of one tile row: one 16-byte store
+    {
+        const int py = tid >> 3, px = (tid & 7) * 4;
         const int gy = y0 + py, gx = x0 + px;
-        if (gy < H && gx < W) img[(long long)gy * W + gx] = t[(py + R) * LW + px + R];
+        if (gy < H && gx < W) {
+            const float* const r = &t[(py + R) * LW + px + R];
+            *reinterpret_cast<f32x4*>(&img[(long long)gy * W + gx]) = f32x4{r[0], r[1], r[2], r[3]};
+        }
     }
     if (tid == 0) {
         const int und = cnt[cur];
-        fout[tile_id] = und > 0;
-        if (und) atomicAdd(&remaining[round & 63], und);      // 64 counter slots, recycled by the host after a sync
+        fout[tile_id] = und;
     }
 }
 
-__global__ void nms_accumulate_kernel(const int* __restrict__ remaining_last, int* __restrict__ total)
+// undecided pixels after a round = sum of the tiles' counts -> *slot (what the host reads), and added to *total (optional)
+__global__ __launch_bounds__(1024) void nms_accumulate_kernel(const int* __restrict__ counts, int ntiles, int* __restrict__ slot,
+                                                              int* __restrict__ total)
 {
-    if (threadIdx.x == 0 && *remaining_last) atomicAdd(total, *remaining_last);
+    __shared__ int part[16];
+    int sum = 0;
+    for (int i = threadIdx.x; i < ntiles; i += 1024) sum += counts[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int all = 0;
+        for (int w = 0; w < 16; ++w) all += part[w];
+        *slot = all;
+        if (total && all) atomicAdd(total, all);
+    }
 }
 
 }  // namespace
 
-// adds the undecided count of the final round to a persistent counter (read + reset by mp_nms_unresolved)
-void launch_nms_accumulate(const int* remaining_last, int* total, hipStream_t s)
+// the undecided count after round `round` (flags / slots as laid out below) -> its slot, and onto the persistent counter
+// (read + reset by mp_nms_unresolved) when `total` is given
+void launch_nms_accumulate(int* remaining, int B, int H, int W, int round, int* total, hipStream_t s)
 {
-    hipLaunchKernelGGL(nms_accumulate_kernel, dim3(1), dim3(64), 0, s, remaining_last, total);
+    const int ntiles = B * ((W + NT - 1) / NT) * ((H + NT - 1) / NT);
+    const int* counts = remaining + 64 + ((round + 1) & 1) * ntiles;
+    hipLaunchKernelGGL(nms_accumulate_kernel, dim3(1), dim3(1024), 0, s, counts, ntiles, remaining + (round & 63), total);
 }
 
 void launch_nms_init(const float* prob, const uint8_t* mask, float min_prob, float* work,
