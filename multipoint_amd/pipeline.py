@@ -56,7 +56,7 @@ class PairPipeline:
 
     def __init__(self, net, config, capacity=None, nms_rounds=8, overlap_post=True):
         self.net = net
-        self.overlap_post = overlap_post
+        self.overlap_post = overlap_post and os.environ.get('MP_POST_OVERLAP', '1') != '0'     # (developer A/B switch)
         self._post_stream = None
         self._last = None           # results of the latest run_interleaved() (check_converged inspects their counts)
         self.nms = config.get('nms', 4)
