@@ -58,6 +58,7 @@ class PairPipeline:
         self.net = net
         self.overlap_post = overlap_post and os.environ.get('MP_POST_OVERLAP', '1') != '0'     # (developer A/B switch)
         self._post_stream = None
+        self._fwd_stream = None
         self._last = None           # results of the latest run_interleaved() (check_converged inspects their counts)
         self.nms = config.get('nms', 4)
         self.thr = config.get('detection_threshold', 0.015)
@@ -103,17 +104,30 @@ class PairPipeline:
             raise ValueError('interleaved batch must hold an even number of images')
         if is_optical is None:
             is_optical = (torch.arange(B) % 2 == 0).reshape(B, 1)
-        out = self.net({'image': images, 'is_optical': is_optical})
         main = torch.cuda.current_stream(dev)
         if self.overlap_post:
+            # Two streams of the pipeline's own: the forward on a HIGH-priority one, the post-processing on a normal one.  A
+            # convolution workgroup needs a whole CU; when batch n's post-processing and batch n+1's first convolution become
+            # ready together, the dispatcher must hand the CUs to the convolution first -- otherwise the chain of ~20 small
+            # dependent post-processing kernels keeps landing on freed CUs and the convolution's last workgroups start up to
+            # 0.4 ms late (measured: enc.conv1+2 4.35 instead of 4.05 ms).
             if self._post_stream is None or self._post_stream.device != dev:
                 self._post_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("MP_POST_PRIORITY", "0")))
-            post = self._post_stream
-            post.wait_stream(main)
+                self._fwd_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("MP_FWD_PRIORITY", "-1")))
+            post, fwd = self._post_stream, self._fwd_stream
+            fwd.wait_stream(main)                                   # the inputs were produced on the caller's stream
+            with torch.cuda.stream(fwd):
+                out = self.net({'image': images, 'is_optical': is_optical})
+            for t in (images, valid_mask, is_optical if is_optical.is_cuda else None):
+                if t is not None:
+                    t.record_stream(fwd)
+            post.wait_stream(fwd)
+            main.wait_stream(fwd)      # whatever the caller enqueues next (another forward: one workspace per handle) comes behind
             for t in (out['prob'], out['desc'], valid_mask):
                 if t is not None:
                     t.record_stream(post)
         else:
+            out = self.net({'image': images, 'is_optical': is_optical})
             post = main
         with torch.cuda.stream(post):
             res = self._post(out, valid_mask, dev, B, H, W)
