@@ -63,16 +63,22 @@ __global__ __launch_bounds__(256) void sample_desc_kernel(const float* __restric
 }
 
 // best[x] = min over y of (dist(x,y) bits << 32 | y), X rows against all Y rows.
-// grid: (row-block groups, pairs, 2 directions); each wave owns one 32-row block of X.
-// (D = 64: at most 96 registers per lane so that a wave fits beside a resident Winograd convolution wave, see keypoints.hip)
+// grid: (row-block groups, pairs, 2 directions); each wave owns one 32-row block of X; the four waves of a workgroup walk the
+// same 32-column tiles of Y, which reach them through LDS: a tile is 32 x D contiguous floats, staged with fully coalesced
+// 16-byte loads (one 1 KiB run per wave instruction) one tile ahead, and read back as MFMA fragments (padded rows: conflict
+// free).  Fetching the fragments straight from global memory -- 16 bytes out of every 128-byte line of 32 lines per load
+// instruction, each wave for itself -- kept the kernel at twice its MFMA time (131 us for 62 us of v_mfma_f32_32x32x2_f32).
 template <int D>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 64 ? 5 : 1, D == 64 ? 5 : 8))) void nn_rows_kernel(const float* __restrict__ dA, const int* __restrict__ nA,
+__global__ __launch_bounds__(256) void nn_rows_kernel(const float* __restrict__ dA, const int* __restrict__ nA,
                                                      const float* __restrict__ dB, const int* __restrict__ nB,
                                                      long long pair_stride, int count_stride, int K,
                                                      unsigned long long* __restrict__ bestA,
                                                      unsigned long long* __restrict__ bestB)
 {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int RS = D + 4;                            // LDS row stride in floats
+    __shared__ __attribute__((aligned(16))) float ytile[2][32 * RS];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, half = lane >> 5;
     const int p = blockIdx.y, dir = blockIdx.z;
     const float* X = (dir == 0 ? dA : dB) + (long long)p * pair_stride;
@@ -80,8 +86,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 64 ? 5
     const int nx = min((dir == 0 ? nA : nB)[p * count_stride], K);
     const int ny = min((dir == 0 ? nB : nA)[p * count_stride], K);
     unsigned long long* best = (dir == 0 ? bestA : bestB) + (long long)p * K;
+    if ((int)blockIdx.x * 128 >= nx) return;             // (the whole workgroup)
     const int r0 = (blockIdx.x * 4 + wave) * 32;
-    if (r0 >= nx) return;
+    const bool active = r0 < nx;                         // a wave without rows still stages tiles and meets the barriers
 
     constexpr int NG = D / 8;
     f32x4 a[NG];
@@ -91,45 +98,73 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(D == 64 ? 5
         for (int g = 0; g < NG; ++g)
             a[g] = *reinterpret_cast<const f32x4*>(X + (long long)row * D + g * 8 + half * 4);
     }
-    unsigned long long run[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) run[r] = ~0ull;
+    // The products are formed TRANSPOSED (Y fragment as the A operand): lane li owns X row r0 + li, its 16 accumulator registers
+    // are 16 columns of the tile -- ONE running arg-min per lane, over columns that arrive in ascending order, so a later column
+    // replaces the best one only with a strictly smaller distance.  d = sqrt(u), u = 2 - 2 clip(x.y), is monotone in u:
+    // "u < the smallest u seen" is a necessary condition that costs one compare, and the correctly rounded sqrt (~20
+    // instructions) + 64-bit key update run only for candidates that pass it -- a lane has seen 16 (t - 1) columns before tile
+    // t, so few do.  Keys, hence ties (lowest index wins), are exactly those of the per-element form.
+    unsigned long long run = ~0ull;
+    float ub = __builtin_inff();
 
-    for (int c0 = 0; c0 < ny; c0 += 32) {
-        const int col = c0 + li;
-        const int colc = min(col, ny - 1);
+    // staging: the tile's 32 * D / 4 granules of 16 bytes, D / 32 per thread (rows beyond ny repeat row ny - 1; never selected)
+    constexpr int GPT = D / 32, GPR = D / 4;
+    f32x4 stage[GPT];
+    auto gload = [&](int c0) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < GPT; ++k) {
+            const int gran = tid + k * 256;
+            const int row = gran / GPR, q = gran - row * GPR;
+            stage[k] = *reinterpret_cast<const f32x4*>(Y + (long long)min(c0 + row, ny - 1) * D + q * 4);
+        }
+    };
+    auto lstore = [&](int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int k = 0; k < GPT; ++k) {
+            const int gran = tid + k * 256;
+            const int row = gran / GPR, q = gran - row * GPR;
+            *reinterpret_cast<f32x4*>(&ytile[buf][row * RS + q * 4]) = stage[k];
+        }
+    };
+    if (ny > 0) { gload(0); lstore(0); }
+    __syncthreads();
+    for (int c0 = 0, buf = 0; c0 < ny; c0 += 32, buf ^= 1) {
+        const bool more = c0 + 32 < ny;
+        if (more) gload(c0 + 32);                        // in flight across this tile's MFMAs
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            const f32x4 bv = *reinterpret_cast<const f32x4*>(Y + (long long)colc * D + g * 8 + half * 4);
+            const f32x4 bv = *reinterpret_cast<const f32x4*>(&ytile[buf][li * RS + g * 8 + half * 4]);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][e], bv[e], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(bv[e], a[g][e], acc, 0, 0, 0);      // acc[r]: column i(r) of the tile, row li
         }
-        if (col < ny) {
+        if (active) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                const int col = c0 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 const float t = fminf(fmaxf(acc[r], -1.f), 1.f);               // np.clip, matching.py:51
-                const float d = sqrtf(2.f - 2.f * t);
-                const unsigned long long key =
-                    ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)col;
-                run[r] = key < run[r] ? key : run[r];
+                const float u = 2.f - 2.f * t;
+                if (col < ny && u < ub) {
+                    ub = u;
+                    const float d = sqrtf(u);
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned)col;
+                    run = key < run ? key : run;
+                }
             }
         }
+        if (more) lstore(buf ^ 1);                       // last read one barrier ago
+        __syncthreads();
     }
-    // reduce over the 32 columns held by the lanes of each half-wave
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        unsigned long long v = run[r];
-#pragma unroll
-        for (int off = 1; off < 32; off <<= 1) {
-            const unsigned long long o = __shfl_xor(v, off);
-            v = o < v ? o : v;
-        }
-        const int row = r0 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (li == 0 && row < nx) best[row] = v;
+    if (!active) return;
+    // the two half-waves hold the two halves of the row's columns
+    {
+        const unsigned long long o = __shfl_xor(run, 32);
+        run = o < run ? o : run;
+        const int row = r0 + li;
+        if (half == 0 && row < nx) best[row] = run;
     }
 }
 
