@@ -59,16 +59,17 @@ def pmc_traffic(workload, instantiation):
     reported next to the kernel it was measured on.  PMC counters cannot be collected from inside the timed run."""
     import glob
     suffix = '_c5' if workload == 'c5' else ''
-    for path in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_hbm_traffic%s.json' % suffix)), reverse=True):
-        try:
-            with open(path) as f:
-                rec = json.load(f)
-            if rec.get('dominant_kernel', '').replace(' ', '') != instantiation.replace(' ', ''):
-                return None
-            return float(rec['dominant_kernel_mean_traffic_bytes_per_launch'])
-        except (OSError, KeyError, ValueError):
-            continue
-    return None
+    paths = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_pmc_hbm_traffic%s.json' % suffix)), reverse=True)
+    if not paths:
+        return None
+    try:        # the NEWEST round's file only: an older round's counters describe an older kernel
+        with open(paths[0]) as f:
+            rec = json.load(f)
+        if rec.get('dominant_kernel', '').replace(' ', '') != instantiation.replace(' ', ''):
+            return None
+        return float(rec['dominant_kernel_mean_traffic_bytes_per_launch'])
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def make_batch(pair_ids, device, H=H, W=W):
@@ -371,11 +372,11 @@ def main():
             # v_mfma_f32_4x4x1_16b_f32 (512 FLOP) each -> 16 x 10 x 9 = 1440 per item
             items = 2 * P * ((H + 15) // 16) * ((W + 31) // 32)
             issued = (conv2_flop / 4.0 + items * 1440 * 512.0) if fused else flop / 4.0
-            inst = 'conv_wino43_kernel<true,false,8,true>' if fused else 'conv_wino43_kernel<true,false,8,false>'
-            kernel = ('conv_wino43_kernel<true,false,8,true> (encoder conv1 -- Cin = 1, produced per unit of 4 channels on the matrix pipe '
+            inst = 'conv_wino43_kernel<true,false,8,true,false>' if fused else 'conv_wino43_kernel<true,false,8,false,false>'
+            kernel = ('conv_wino43_kernel<true,false,8,true,false> (encoder conv1 -- Cin = 1, produced per unit of 4 channels on the matrix pipe '
                       '(v_mfma_f32_4x4x1_16b_f32) straight into the LDS patch ring -- fused into enc.conv2 64->64 @480x640 by Winograd '
                       'F(4x4,3x3) on v_mfma_f32_16x16x4_f32, weights staged by LDS-DMA, + bias/ReLU/BN + 2x2 max-pool)') if fused else \
-                     ('conv_wino43_kernel<true,false,8,false> (enc.conv2 64->64 @480x640 by Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32, '
+                     ('conv_wino43_kernel<true,false,8,false,false> (enc.conv2 64->64 @480x640 by Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32, '
                       'weights and channel-quad-planar input patches staged by LDS-DMA, + bias/ReLU/BN + 2x2 max-pool)')
         else:
             issued = (conv2_flop if fused else flop) / 2.25
