@@ -195,8 +195,8 @@ def parity_block(res, net, images, flags, cres, prob_cpu, desc_cpu, PRED, H, W):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--pairs-per-gpu', type=int, default=PAIRS_PER_GPU)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--forward-only', action='store_true', help='configs[1]: encoder+heads only')
