@@ -164,15 +164,17 @@ __global__ __launch_bounds__(BT) void select_keypoints_kernel(
                 if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255u], 1u);
             }
             __syncthreads();
-            if (tid == 0) {
-                unsigned cum = 0;
-                int d = 255;
-                for (; d > 0; --d) {
-                    if (cum + s_hist[d] >= (unsigned)kk) break;
-                    cum += s_hist[d];
-                }
-                s_sel[0] = (unsigned)d;
-                s_sel[1] = cum;
+            // the digit d with (#keys of a larger digit) < kk <= (#keys of digit >= d), found by all 256 threads at once (thread t
+            // holds bin t; suffix count = total - exclusive prefix): a single thread walking the bins down took a dependent LDS
+            // read per bin, 256 x 4 passes = half of the kernel's 66 us
+            {
+                const int hcnt = (int)s_hist[tid];
+                int tot;
+                const int before = block_excl_scan(hcnt, s_wave, &tot);      // bins 0 .. t-1
+                const int ge = tot - before;                                 // bins t .. 255
+                if (tid == 0) { s_sel[0] = 0u; s_sel[1] = (unsigned)(tot - hcnt); }      // (fewer than kk keys: digit 0, as the walk did)
+                __syncthreads();
+                if (tid > 0 && ge >= kk && ge - hcnt < kk) { s_sel[0] = (unsigned)tid; s_sel[1] = (unsigned)(ge - hcnt); }
             }
             __syncthreads();
             prefix |= s_sel[0] << shift;
