@@ -52,7 +52,7 @@ template <int RT, bool INIT>
 __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work, int H, int W,
                                                        int tiles_x, int tiles_y, NmsFootprint fp,
                                                        int* __restrict__ flags, int ntiles_total,
-                                                       int* __restrict__ remaining, int round,
+                                                       int round,
                                                        const float* __restrict__ prob, const uint8_t* __restrict__ mask,
                                                        float min_prob)
 {
@@ -270,7 +270,8 @@ void launch_nms_init(const float* prob, const uint8_t* mask, float min_prob, flo
                        mask, min_prob, work, n4);
 }
 
-// flags / remaining live behind `remaining`:  remaining[0..63] round counters, then 2*ntiles flags
+// layout behind `remaining`: remaining[0..63] per-round undecided totals (written by nms_accumulate_kernel when the host asks),
+// then the 2 * ntiles ping-pong tile counts
 void launch_nms_round(float* work, int B, int H, int W, const NmsFootprint& fp, int* remaining,
                       int round, hipStream_t s)
 {
@@ -282,13 +283,13 @@ void launch_nms_round(float* work, int B, int H, int W, const NmsFootprint& fp, 
     const uint8_t* nm = nullptr;
     if (fp.R == 3)
         hipLaunchKernelGGL((nms_round_kernel<3, false>), dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
-                           tiles_y, fp, flags, ntiles, remaining, round, np, nm, 0.f);
+                           tiles_y, fp, flags, ntiles, round, np, nm, 0.f);
     else if (fp.R == 1)
         hipLaunchKernelGGL((nms_round_kernel<1, false>), dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
-                           tiles_y, fp, flags, ntiles, remaining, round, np, nm, 0.f);
+                           tiles_y, fp, flags, ntiles, round, np, nm, 0.f);
     else
         hipLaunchKernelGGL((nms_round_kernel<0, false>), dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
-                           tiles_y, fp, flags, ntiles, remaining, round, np, nm, 0.f);
+                           tiles_y, fp, flags, ntiles, round, np, nm, 0.f);
 }
 
 // round 0 with the candidate listing fused in: replaces launch_nms_init + launch_nms_round(round 0)
@@ -301,11 +302,11 @@ void launch_nms_round0(const float* prob, const uint8_t* mask, float min_prob, f
     int* flags = remaining + 64;
     if (fp.R == 3)
         hipLaunchKernelGGL((nms_round_kernel<3, true>), dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
-                           tiles_y, fp, flags, ntiles, remaining, 0, prob, mask, min_prob);
+                           tiles_y, fp, flags, ntiles, 0, prob, mask, min_prob);
     else if (fp.R == 1)
         hipLaunchKernelGGL((nms_round_kernel<1, true>), dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
-                           tiles_y, fp, flags, ntiles, remaining, 0, prob, mask, min_prob);
+                           tiles_y, fp, flags, ntiles, 0, prob, mask, min_prob);
     else
         hipLaunchKernelGGL((nms_round_kernel<0, true>), dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
-                           tiles_y, fp, flags, ntiles, remaining, 0, prob, mask, min_prob);
+                           tiles_y, fp, flags, ntiles, 0, prob, mask, min_prob);
 }
