@@ -1,6 +1,7 @@
 """CPU: host-side logic of the product package and the C-ABI library surface (no compute calls:
 there is no GPU here).  Also checks that the product never falls back to a CPU path."""
 import ctypes
+import json
 import os
 import re
 import subprocess
@@ -364,3 +365,24 @@ def test_hardware_queue_default_is_set_by_the_package():
     r = subprocess.run([__import__('sys').executable, '-c', 'import os; os.environ.pop("GPU_MAX_HW_QUEUES", None); import multipoint_amd; '
                         'print(os.environ["GPU_MAX_HW_QUEUES"])'], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
     assert r.returncode == 0 and r.stdout.strip() == '8', r.stderr[-500:]
+
+
+def test_bench_traffic_figure_only_next_to_the_kernel_it_was_measured_on(tmp_path, monkeypatch):
+    """bench.py's roofline.traffic comes from the committed PMC summary of the NEWEST round, and only when that summary is for the
+    kernel instantiation the run timed: an older round's counters, or another instantiation's, must give null -- never a number."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('bench_mod', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    prof = tmp_path / 'profiles'
+    prof.mkdir()
+    (prof / 'r02_pmc_hbm_traffic.json').write_text(json.dumps(
+        {'dominant_kernel': 'k<true, 8>', 'dominant_kernel_mean_traffic_bytes_per_launch': 14.2e9}))
+    (prof / 'r03_pmc_hbm_traffic.json').write_text(json.dumps(
+        {'dominant_kernel': 'k<true, 8, false>', 'dominant_kernel_mean_traffic_bytes_per_launch': 1.3e9}))
+    monkeypatch.setattr(bench, 'ROOT', str(tmp_path))
+    assert bench.pmc_traffic('c3', 'k<true,8,false>') == 1.3e9          # spaces do not matter
+    assert bench.pmc_traffic('c3', 'k<true,8>') is None                 # the OLD round's kernel: no fall-through to r02
+    assert bench.pmc_traffic('c5', 'k<true,8,false>') is None           # no file for that workload
+    (prof / 'r03_pmc_hbm_traffic.json').write_text('{"dominant_kernel": "k<true, 8, false>"}')
+    assert bench.pmc_traffic('c3', 'k<true,8,false>') is None           # a broken newest file does not expose the older one
