@@ -9,16 +9,16 @@
 // Ballot/shuffle prefix scans give every kept pixel its row-major rank without atomics (so the output order is
 // deterministic and equals nonzero()).  The dense map is compacted by MANY workgroups per image in two passes over
 // 16 Ki-pixel segments -- count, then ordered write at the segment's prefix (a single workgroup per image streams a
-// 1024x1280 map at only ~260 GB/s) -- and one 1024-thread workgroup per image then works on the short list only:
+// 1024x1280 map at only ~260 GB/s) -- and one 256-thread workgroup per image then works on the short list only:
 // a 4-pass 8-bit radix select over the fp32 score bits finds the exact k-th score; ties at the threshold are
 // admitted in row-major order.
 #include "mp_common.h"
 
 namespace {
 
-// 256 threads and < 64 VGPRs: a workgroup of these kernels fits on a CU NEXT TO a resident Winograd convolution
-// workgroup (408 of 512 registers per lane, 127 of 160 KiB LDS), so the post-processing stream really overlaps the
-// next batch's convolutions instead of waiting for a CU to drain
+// 256 threads and < 64 VGPRs.  (Sized in round 1 to fit on a CU next to a resident F(2x2,3x3) convolution workgroup; the
+// F(4x4,3x3) workgroups of rounds 2 / 3 own their CU -- 512 threads x 231-256 registers, 158 KiB of LDS -- so these kernels now
+// run at launch boundaries and beside the head tail)
 constexpr int BT = 256;                       // threads per workgroup (4 waves)
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane)
