@@ -149,6 +149,57 @@ __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work
     __syncthreads();
 
     int cur = 0;
+    if constexpr (RT > 0) {
+        // EIGHT lanes per candidate, one window row each (a tile holds a few dozen candidates: one thread per candidate left
+        // seven waves in eight idle and the eighth walking 48 neighbours), 32 candidates per pass of the workgroup; the lanes'
+        // verdicts meet by three xor-shuffles and lane 0 of the eight applies the transition AT ONCE -- both rules are sound under
+        // any mixture of old and new neighbour states -- and re-lists the candidate if it is still undecided.
+        static_assert(2 * RT + 1 <= 8, "one lane per window row");
+        const int sub = tid & 7, grp = tid >> 3;
+        const int dy = sub - RT;
+        const bool row_on = sub <= 2 * RT, row_earlier = dy < 0, row_same = dy == 0;
+        unsigned rm = 0u;
+#pragma unroll
+        for (int q = 0; q <= 2 * RT; ++q) rm = (sub == q) ? fp.rowmask[q] : rm;
+        const int row_off = row_on ? dy * LW : 0;
+        for (int iter = 0; iter < 64; ++iter) {
+            const int n = cnt[cur];
+            if (n == 0) break;
+            if (tid == 0) cnt[cur ^ 1] = 0;
+            __syncthreads();
+            int changed = 0;
+            for (int base = 0; base < n; base += 32) {
+                const int i = base + grp;
+                const bool valid = i < n;
+                const int c = list[cur][valid ? i : 0];
+                const float s = t[c];
+                float nb[2 * RT + 1];
+#pragma unroll
+                for (int dx = -RT; dx <= RT; ++dx) nb[dx + RT] = t[c + row_off + dx];
+                bool kill = false, blocked = false;
+#pragma unroll
+                for (int dx = -RT; dx <= RT; ++dx) {
+                    const bool on = row_on && ((rm >> (dx + RT)) & 1u) && !(dx == 0 && row_same);
+                    const float v = on ? nb[dx + RT] : 0.f;             // 0: neither kept (< 0) nor of higher priority (s > 0)
+                    kill |= v < 0.f;
+                    const bool earlier = row_earlier || (row_same && dx < 0);   // lower flat index
+                    blocked |= (v > s) || (v == s && earlier);
+                }
+                unsigned f = (kill ? 1u : 0u) | (blocked ? 2u : 0u);
+                f |= (unsigned)__shfl_xor((int)f, 1);
+                f |= (unsigned)__shfl_xor((int)f, 2);
+                f |= (unsigned)__shfl_xor((int)f, 4);
+                if (valid && sub == 0) {
+                    const float nvv = (f & 1u) ? 0.f : ((f & 2u) ? s : -s);
+                    if (nvv != s) { changed = 1; t[c] = nvv; }
+                    if (nvv > 0.f) list[cur ^ 1][atomicAdd(&cnt[cur ^ 1], 1)] = (unsigned short)c;
+                }
+            }
+            const int any = __syncthreads_or(changed);
+            cur ^= 1;                                            // (both lists hold the same entries if nothing changed)
+            if (!any) break;                                     // nothing can change without new halo data
+        }
+    } else {
     for (int iter = 0; iter < 64; ++iter) {
         const int n = cnt[cur];
         if (n == 0) break;
@@ -165,39 +216,15 @@ __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work
                 const int c = list[cur][i];
                 const float s = t[c];
                 bool kill = false, blocked = false;
-                auto visit = [&](int dy, int dx) {
-                    const float nb = t[c + dy * LW + dx];
-                    kill |= nb < 0.f;
-                    const bool earlier = (dy < 0) || (dy == 0 && dx < 0);       // lower flat index
-                    blocked |= (nb > s) || (nb == s && earlier);
-                };
-                if constexpr (RT > 0) {
-                    // every neighbour of the (2 RT + 1)^2 window is read (the halo makes them all addressable) before the first
-                    // one is looked at -- one LDS latency per candidate instead of one per neighbour -- and the footprint mask
-                    // turns the ones outside it into 0: neither kept (< 0) nor of higher priority than a candidate (s > 0)
-                    float nb[2 * RT + 1][2 * RT + 1];
-#pragma unroll
-                    for (int dy = -RT; dy <= RT; ++dy)
-#pragma unroll
-                        for (int dx = -RT; dx <= RT; ++dx) nb[dy + RT][dx + RT] = t[c + dy * LW + dx];
-#pragma unroll
-                    for (int dy = -RT; dy <= RT; ++dy) {
-                        const unsigned rm = fp.rowmask[dy + RT];
-#pragma unroll
-                        for (int dx = -RT; dx <= RT; ++dx) {
-                            if (dy == 0 && dx == 0) continue;
-                            const float v = ((rm >> (dx + RT)) & 1u) ? nb[dy + RT][dx + RT] : 0.f;
-                            kill |= v < 0.f;
+                for (int dy = -R; dy <= R; ++dy) {
+                    const unsigned rmask = fp.rowmask[dy + R];
+                    for (int dx = -R; dx <= R; ++dx)
+                        if (((rmask >> (dx + R)) & 1u) && (dy != 0 || dx != 0)) {
+                            const float nb = t[c + dy * LW + dx];
+                            kill |= nb < 0.f;
                             const bool earlier = (dy < 0) || (dy == 0 && dx < 0);       // lower flat index
-                            blocked |= (v > s) || (v == s && earlier);
+                            blocked |= (nb > s) || (nb == s && earlier);
                         }
-                    }
-                } else {
-                    for (int dy = -R; dy <= R; ++dy) {
-                        const unsigned rm = fp.rowmask[dy + R];
-                        for (int dx = -R; dx <= R; ++dx)
-                            if (((rm >> (dx + R)) & 1u) && (dy != 0 || dx != 0)) visit(dy, dx);
-                    }
                 }
                 pos[k] = c;
                 nv[k] = kill ? 0.f : (blocked ? s : -s);
@@ -214,6 +241,7 @@ __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work
             }
         __syncthreads();
         cur ^= 1;
+    }
     }
 
     // each thread owns 4 consecutive pixels of one tile row: one 16-byte store
