@@ -191,7 +191,14 @@ __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work
                 f |= (unsigned)__shfl_xor((int)f, 4);
                 if (valid && sub == 0) {
                     const float nvv = (f & 1u) ? 0.f : ((f & 2u) ? s : -s);
-                    if (nvv != s) { changed = 1; t[c] = nvv; }
+                    if (nvv != s) {
+                        changed = 1;
+                        t[c] = nvv;
+                        if constexpr (!INIT) {      // later rounds change a handful of pixels: those go to the work map one by one
+                            const int ly = c / LW, lx = c - ly * LW;
+                            img[(long long)(y0 + ly - RT) * W + (x0 + lx - RT)] = nvv;
+                        }
+                    }
                     if (nvv > 0.f) list[cur ^ 1][atomicAdd(&cnt[cur ^ 1], 1)] = (unsigned short)c;
                 }
             }
@@ -244,8 +251,9 @@ __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work
     }
     }
 
-    // each thread owns 4 consecutive pixels of one tile row: one 16-byte store
-    {
+    // each thread owns 4 consecutive pixels of one tile row: one 16-byte store (round 0 writes the whole thresholded tile; the
+    // later rounds of the compile-time footprints have written their few changes already)
+    if (INIT || RT == 0) {
         const int py = tid >> 3, px = (tid & 7) * 4;
         const int gy = y0 + py, gx = x0 + px;
         if (gy < H && gx < W) {
