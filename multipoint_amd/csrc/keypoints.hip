@@ -9,7 +9,7 @@
 // Ballot/shuffle prefix scans give every kept pixel its row-major rank without atomics (so the output order is
 // deterministic and equals nonzero()).  The dense map is compacted by MANY workgroups per image in two passes over
 // 16 Ki-pixel segments -- count, then ordered write at the segment's prefix (a single workgroup per image streams a
-// 1024x1280 map at only ~260 GB/s) -- and one 256-thread workgroup per image then works on the short list only:
+// 1024x1280 map at only ~260 GB/s) -- and one 1024-thread workgroup per image then works on the short list only:
 // a 4-pass 8-bit radix select over the fp32 score bits finds the exact k-th score; ties at the threshold are
 // admitted in row-major order.
 #include "mp_common.h"
@@ -31,7 +31,8 @@ __device__ __forceinline__ int wave_incl_scan(int v, int lane)
     return v;
 }
 
-// exclusive prefix of `c` over the workgroup in thread order; returns block total via *total
+// exclusive prefix of `c` over a workgroup of NT threads in thread order; returns block total via *total
+template <int NT = BT>
 __device__ __forceinline__ int block_excl_scan(int c, int* s_wave, int* total)
 {
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -40,7 +41,7 @@ __device__ __forceinline__ int block_excl_scan(int c, int* s_wave, int* total)
     __syncthreads();
     int base = 0, tot = 0;
 #pragma unroll
-    for (int i = 0; i < BT / 64; ++i) {
+    for (int i = 0; i < NT / 64; ++i) {
         const int x = s_wave[i];
         if (i < w) base += x;
         tot += x;
@@ -49,6 +50,8 @@ __device__ __forceinline__ int block_excl_scan(int c, int* s_wave, int* total)
     *total = tot;
     return base + inc - c;
 }
+
+constexpr int BTS = 1024;                     // threads of the per-image selection workgroup
 
 constexpr int SEG = 16384;                    // pixels per segment (a multiple of BT * 4)
 
@@ -131,12 +134,12 @@ __global__ __launch_bounds__(BT) void compact_segments_kernel(const float* __res
     }
 }
 
-__global__ __launch_bounds__(BT) void select_keypoints_kernel(
+__global__ __launch_bounds__(BTS) void select_keypoints_kernel(
     const float* __restrict__ work, int H, int W, int topk, int K, int* __restrict__ list_idx,
     float* __restrict__ list_score, int list_cap, int* __restrict__ kp_yx, float* __restrict__ kp_score,
     int* __restrict__ kp_count, float* __restrict__ prob_nms, const int* __restrict__ list_count)
 {
-    __shared__ int s_wave[BT / 64];
+    __shared__ int s_wave[BTS / 64];
     __shared__ unsigned s_hist[256];
     __shared__ unsigned s_sel[2];
     const int b = blockIdx.x, tid = threadIdx.x;
@@ -159,7 +162,7 @@ __global__ __launch_bounds__(BT) void select_keypoints_kernel(
             const int shift = 24 - 8 * pass;
             if (tid < 256) s_hist[tid] = 0;
             __syncthreads();
-            for (int i = tid; i < nk; i += BT) {
+            for (int i = tid; i < nk; i += BTS) {
                 const unsigned key = __float_as_uint(lsc[i]);
                 if ((key & mask) == prefix) atomicAdd(&s_hist[(key >> shift) & 255u], 1u);
             }
@@ -168,13 +171,13 @@ __global__ __launch_bounds__(BT) void select_keypoints_kernel(
             // holds bin t; suffix count = total - exclusive prefix): a single thread walking the bins down took a dependent LDS
             // read per bin, 256 x 4 passes = half of the kernel's 66 us
             {
-                const int hcnt = (int)s_hist[tid];
+                const int hcnt = tid < 256 ? (int)s_hist[tid] : 0;
                 int tot;
-                const int before = block_excl_scan(hcnt, s_wave, &tot);      // bins 0 .. t-1
+                const int before = block_excl_scan<BTS>(hcnt, s_wave, &tot);      // bins 0 .. t-1
                 const int ge = tot - before;                                 // bins t .. 255
                 if (tid == 0) { s_sel[0] = 0u; s_sel[1] = (unsigned)(tot - hcnt); }      // (fewer than kk keys: digit 0, as the walk did)
                 __syncthreads();
-                if (tid > 0 && ge >= kk && ge - hcnt < kk) { s_sel[0] = (unsigned)tid; s_sel[1] = (unsigned)(ge - hcnt); }
+                if (tid > 0 && tid < 256 && ge >= kk && ge - hcnt < kk) { s_sel[0] = (unsigned)tid; s_sel[1] = (unsigned)(ge - hcnt); }
             }
             __syncthreads();
             prefix |= s_sel[0] << shift;
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(BT) void select_keypoints_kernel(
 
     // ordered output (row-major, == torch.nonzero order of the NMS'ed map)
     int out_base = 0, tie_base = 0;
-    for (int start = 0; start < nk; start += BT) {
+    for (int start = 0; start < nk; start += BTS) {
         const int i = start + tid;
         unsigned key = 0;
         int idx = 0;
@@ -197,13 +200,16 @@ __global__ __launch_bounds__(BT) void select_keypoints_kernel(
         bool sel = i < nk;
         if (select) {
             const int eq = (i < nk) && (key == T);
-            int tot_eq;
-            const int tie_rank = tie_base + block_excl_scan(eq, s_wave, &tot_eq);
-            tie_base += tot_eq;
+            int tie_rank = 0;
+            if (__syncthreads_or(eq)) {                 // (scores AT the k-th one are rare: most chunks skip their rank scan)
+                int tot_eq;
+                tie_rank = tie_base + block_excl_scan<BTS>(eq, s_wave, &tot_eq);
+                tie_base += tot_eq;
+            }
             sel = (i < nk) && ((key > T) || (eq && tie_rank < need));
         }
         int tot;
-        const int pos = out_base + block_excl_scan(sel ? 1 : 0, s_wave, &tot);
+        const int pos = out_base + block_excl_scan<BTS>(sel ? 1 : 0, s_wave, &tot);
         out_base += tot;
         if (sel && pos < K) {
             if (kp_yx) {
@@ -233,7 +239,7 @@ void launch_select_keypoints(const float* work, int B, int H, int W, int topk, i
                        (const unsigned char*)nullptr);
     hipLaunchKernelGGL(compact_segments_kernel<0>, g, dim3(BT), 0, s, work, n, 0.f, W, nseg, seg_count, list_cap,
                        (long long)list_cap, list_idx, list_score, (int*)nullptr, list_count, (const unsigned char*)nullptr);
-    hipLaunchKernelGGL(select_keypoints_kernel, dim3(B), dim3(BT), 0, s, work, H, W, topk, K, list_idx,
+    hipLaunchKernelGGL(select_keypoints_kernel, dim3(B), dim3(BTS), 0, s, work, H, W, topk, K, list_idx,
                        list_score, list_cap, kp_yx, kp_score, kp_count, prob_nms, list_count);
 }
 
