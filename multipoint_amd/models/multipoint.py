@@ -46,6 +46,8 @@ class MultiPoint:
         self._handle = None
         self._state = None           # OrderedDict name -> CPU tensor (reference state_dict layout)
         self._uploaded = False
+        self._fwd_event = None       # last forward's completion, for callers that alternate streams
+        self._fwd_stream = None
         if self.config['verbose']:
             n = sum(int(np.prod(s)) for k, s, d in self.state_dict_spec() if d == torch.float32
                     and not k.endswith(('running_mean', 'running_var')))
@@ -233,11 +235,20 @@ class MultiPoint:
             D = self.config['descriptor_size']
             desc_cl = torch.empty((B, Hc, Wc, D), dtype=torch.float32, device=self.device)
         h = self._handle
+        # one workspace per handle: a forward on ANOTHER stream than the previous one is ordered behind it (same stream: in order anyway)
+        cur = torch.cuda.current_stream(self.device)
+        if self._fwd_event is not None and self._fwd_stream != cur:
+            cur.wait_event(self._fwd_event)
         with torch.cuda.device(self.device):
             h.check(h.lib.mp_forward(h.ptr, _lib.ptr(image),
                                      ctypes.c_void_p(is_opt.data_ptr()) if is_opt is not None else None,
                                      B, H, W, _lib.ptr(prob), _lib.ptr(logits), _lib.ptr(desc_cl),
                                      _lib.stream_ptr(self.device)))
+        if self._fwd_stream != cur:                  # (the event is only needed across a change of stream: record on change)
+            self._fwd_event = torch.cuda.Event()
+        if self._fwd_event is not None:
+            self._fwd_event.record(cur)
+        self._fwd_stream = cur
         out = {'prob': prob, 'logits': logits}
         if desc_cl is not None:
             # logically (B,D,Hc,Wc) like the reference, stored channels-last (values identical)

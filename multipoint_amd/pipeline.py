@@ -121,8 +121,7 @@ class PairPipeline:
             for t in (images, valid_mask, is_optical if is_optical.is_cuda else None):
                 if t is not None:
                     t.record_stream(fwd)
-            post.wait_stream(fwd)
-            main.wait_stream(fwd)      # whatever the caller enqueues next (another forward: one workspace per handle) comes behind
+            post.wait_stream(fwd)      # (a forward the caller enqueues next on ITS stream is ordered behind this one by the model itself)
             for t in (out['prob'], out['desc'], valid_mask):
                 if t is not None:
                     t.record_stream(post)

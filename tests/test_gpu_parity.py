@@ -228,6 +228,28 @@ def test_forward_variants_match_reference_golden(oracle, golden_dir, name, upd):
     assert np.abs(out['desc'].cpu().numpy() - g[name + '_desc']).max() <= DESC_TOL * scale
 
 
+def test_forwards_on_alternating_streams_share_the_workspace_safely(oracle, shipped):
+    """One workspace per handle: a forward enqueued on another stream than the previous one is ordered behind it by the model
+    (PairPipeline runs its forwards on a stream of its own while callers keep using theirs) -- no host synchronisation needed."""
+    net, sd = shipped
+    a = oracle.make_images(71, 6, 240, 320).cuda()
+    b = oracle.make_images(72, 6, 240, 320).cuda()
+    ra = net({'image': a}); rb = net({'image': b})
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            oa = net({'image': a})
+        ob = net({'image': b})                        # the caller's stream, right behind it, same workspace
+        with torch.cuda.stream(side):
+            oa2 = net({'image': a})
+        torch.cuda.synchronize()
+        assert torch.equal(oa['prob'], ra['prob']) and torch.equal(oa['desc'], ra['desc'])
+        assert torch.equal(ob['prob'], rb['prob']) and torch.equal(ob['desc'], rb['desc'])
+        assert torch.equal(oa2['prob'], ra['prob']) and torch.equal(oa2['desc'], ra['desc'])
+
+
 def test_force_return_logits(oracle, shipped, golden_dir):
     net, _ = shipped
     g = np.load(os.path.join(golden_dir, 'forward_variants.npz'))
