@@ -115,7 +115,8 @@ class PairPipeline:
                 self._post_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("MP_POST_PRIORITY", "0")))
                 self._fwd_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("MP_FWD_PRIORITY", "-1")))
             post, fwd = self._post_stream, self._fwd_stream
-            fwd.wait_stream(main)                                   # the inputs were produced on the caller's stream
+            if not main.query():                                    # the inputs were produced on the caller's stream: wait for whatever
+                fwd.wait_stream(main)                               # is still pending there (nothing, in a steady pipeline: no packet)
             with torch.cuda.stream(fwd):
                 out = self.net({'image': images, 'is_optical': is_optical})
             for t in (images, valid_mask, is_optical if is_optical.is_cuda else None):
