@@ -1214,7 +1214,6 @@ int mp_match_mutual_nn(mp_handle* h, const float* descA, const int* countA, cons
     if ((rc = ensure(h, h->ws3, need))) return rc;
     unsigned long long* rowbest = static_cast<unsigned long long*>(h->ws3.p);
     unsigned long long* colbest = rowbest + (size_t)P * K;
-    MP_HIP(hipMemsetAsync(match_count, 0, (size_t)P * 4, s));
     launch_match_impl(descA, countA, descB, countB, pair_stride, count_stride, P, K, D, threshold, rowbest,
                       colbest, match_idx, match_dist, match_count, s);
     MP_HIP(hipGetLastError());

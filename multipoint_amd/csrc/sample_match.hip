@@ -73,8 +73,10 @@ __global__ __launch_bounds__(256) void nn_rows_kernel(const float* __restrict__ 
                                                      const float* __restrict__ dB, const int* __restrict__ nB,
                                                      long long pair_stride, int count_stride, int K,
                                                      unsigned long long* __restrict__ bestA,
-                                                     unsigned long long* __restrict__ bestB)
+                                                     unsigned long long* __restrict__ bestB, int* __restrict__ match_count)
 {
+    // (the pair's match counter, which mutual_kernel adds to behind this launch, is zeroed here: one fill launch fewer)
+    if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) match_count[blockIdx.y] = 0;
     constexpr int RS = D + 4;                            // LDS row stride in floats
     __shared__ __attribute__((aligned(16))) float ytile[2][32 * RS];
     const int tid = threadIdx.x;
@@ -210,7 +212,7 @@ void launch_sample_desc(const float* desc, int B, int Hc, int Wc, int D, int H, 
                        Hc, Wc, D, H, W, kp_yx, kp_count, K, out);
 }
 
-// rowbest/colbest: [P][K] packed; match_count must be zeroed by the caller
+// rowbest/colbest: [P][K] packed; match_count is zeroed by the first launch
 void launch_match_impl(const float* dA, const int* nA, const float* dB, const int* nB,
                        long long pair_stride, int count_stride, int P, int K, int D, float thr,
                        unsigned long long* rowbest, unsigned long long* colbest, int* match_idx,
@@ -220,13 +222,13 @@ void launch_match_impl(const float* dA, const int* nA, const float* dB, const in
     const dim3 grid((K + 127) / 128, P, 2);
     if (D == 64)
         hipLaunchKernelGGL(nn_rows_kernel<64>, grid, dim3(256), 0, s, dA, nA, dB, nB, pair_stride,
-                           count_stride, K, rowbest, colbest);
+                           count_stride, K, rowbest, colbest, match_count);
     else if (D == 128)
         hipLaunchKernelGGL(nn_rows_kernel<128>, grid, dim3(256), 0, s, dA, nA, dB, nB, pair_stride,
-                           count_stride, K, rowbest, colbest);
+                           count_stride, K, rowbest, colbest, match_count);
     else
         hipLaunchKernelGGL(nn_rows_kernel<256>, grid, dim3(256), 0, s, dA, nA, dB, nB, pair_stride,
-                           count_stride, K, rowbest, colbest);
+                           count_stride, K, rowbest, colbest, match_count);
     hipLaunchKernelGGL(mutual_kernel, dim3((K + 255) / 256, P), dim3(256), 0, s, rowbest, colbest, nA,
                        nB, count_stride, K, thr, match_idx, match_dist, match_count);
 }
