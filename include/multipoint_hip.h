@@ -120,7 +120,7 @@ int mp_extract_keypoints(mp_handle* h, const float* map, const unsigned char* va
                          int K, int* kp_yx, float* kp_score, int* kp_count, void* stream);
 
 /* replaces utils.interpolate_descriptors (multipoint/utils/utils.py:159-167).
- *   desc [B][Hc][Wc][D] channels-last, out [B][K][D]; rows k >= kp_count[b] are left untouched. */
+ *   desc [B][Hc][Wc][D] channels-last, out [B][K][D]; rows k >= kp_count[b] are written as zeros. */
 int mp_sample_descriptors(mp_handle* h, const float* desc, int B, int Hc, int Wc, int D, int H, int W,
                           const int* kp_yx, const int* kp_count, int K, float* out, void* stream);
 

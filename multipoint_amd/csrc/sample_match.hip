@@ -28,7 +28,10 @@ __global__ __launch_bounds__(256) void sample_desc_kernel(const float* __restric
     if (wid >= (long long)B * K) return;
     const int b = (int)(wid / K), k = (int)(wid % K);
     const int cnt = min(kp_count[b], K);
-    if (k >= cnt) return;
+    if (k >= cnt) {                                   // rows beyond the image's keypoint count: zeros (the output is fully written)
+        for (int r = 0; r < (D >> 6); ++r) out[wid * D + r * 64 + lane] = 0.f;
+        return;
+    }
     const int y = kp_yx[wid * 2], x = kp_yx[wid * 2 + 1];
     // utils.py:162-163 (fp32) then ATen grid_sampler unnormalize, align_corners=True
     const float gy = (float)y / ((float)H * 0.5f) - 1.0f;

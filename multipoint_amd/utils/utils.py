@@ -161,7 +161,7 @@ def interpolate_descriptors_batched(kp_yx, kp_count, desc, H, W):
     d = _channels_last_desc(desc.to(dev, torch.float32))
     B, Hc, Wc, D = d.shape
     K = kp_yx.shape[1]
-    out = torch.zeros((B, K, D), dtype=torch.float32, device=dev)
+    out = torch.empty((B, K, D), dtype=torch.float32, device=dev)        # (the kernel writes the zero rows too)
     h = _lib.get_handle(dev)
     with torch.cuda.device(dev):
         h.check(h.lib.mp_sample_descriptors(h.ptr, _lib.ptr(d), B, Hc, Wc, D, int(H), int(W),
