@@ -1209,11 +1209,11 @@ int mp_match_mutual_nn(mp_handle* h, const float* descA, const int* countA, cons
     if (P <= 0 || K <= 0) return fail(h, MP_EINVAL, "mp_match_mutual_nn: P and K must be positive");
     hipStream_t s = static_cast<hipStream_t>(stream);
     MP_HIP(hipSetDevice(h->device));
-    const size_t need = (size_t)P * K * 8 * 2;      // packed (distance bits, index) arg-min arrays
+    const size_t need = (size_t)P * K * 8 * 2 * MATCH_SHARES;      // packed (distance bits, index) arg-min arrays, one per column share
     int rc;
     if ((rc = ensure(h, h->ws3, need))) return rc;
     unsigned long long* rowbest = static_cast<unsigned long long*>(h->ws3.p);
-    unsigned long long* colbest = rowbest + (size_t)P * K;
+    unsigned long long* colbest = rowbest + (size_t)P * K * MATCH_SHARES;
     launch_match_impl(descA, countA, descB, countB, pair_stride, count_stride, P, K, D, threshold, rowbest,
                       colbest, match_idx, match_dist, match_count, s);
     MP_HIP(hipGetLastError());

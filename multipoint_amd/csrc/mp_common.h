@@ -226,6 +226,7 @@ void launch_sample_desc(const float* desc, int B, int Hc, int Wc, int D, int H, 
                         const int* kp_yx, const int* kp_count, int K, float* out, hipStream_t s);
 
 // mutual nearest neighbour matching of P pairs; rowbest/colbest: [P][K] packed scratch
+constexpr int MATCH_SHARES = 2;     // column shares of the matcher's arg-min passes (sample_match.hip); rowbest / colbest hold one array per share
 void launch_match_impl(const float* dA, const int* nA, const float* dB, const int* nB,
                        long long pair_stride, int count_stride, int P, int K, int D, float thr,
                        unsigned long long* rowbest, unsigned long long* colbest, int* match_idx,

@@ -76,7 +76,8 @@ __global__ __launch_bounds__(256) void nn_rows_kernel(const float* __restrict__ 
                                                      const float* __restrict__ dB, const int* __restrict__ nB,
                                                      long long pair_stride, int count_stride, int K,
                                                      unsigned long long* __restrict__ bestA,
-                                                     unsigned long long* __restrict__ bestB, int* __restrict__ match_count)
+                                                     unsigned long long* __restrict__ bestB, int* __restrict__ match_count,
+                                                     int nsplit)
 {
     // (the pair's match counter, which mutual_kernel adds to behind this launch, is zeroed here: one fill launch fewer)
     if (blockIdx.x == 0 && blockIdx.z == 0 && threadIdx.x == 0) match_count[blockIdx.y] = 0;
@@ -85,12 +86,17 @@ __global__ __launch_bounds__(256) void nn_rows_kernel(const float* __restrict__ 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, half = lane >> 5;
-    const int p = blockIdx.y, dir = blockIdx.z;
+    // blockIdx.z = direction + 2 * column share: the Y columns are cut into `nsplit` contiguous shares of whole tiles, each share
+    // leaves its own arg-min array (mutual_kernel takes the minimum of the shares' keys) -- twice the waves per SIMD for the same
+    // work: the epilogue of one wave has another wave's MFMAs to hide behind
+    const int p = blockIdx.y, dir = blockIdx.z & 1, share = blockIdx.z >> 1;
     const float* X = (dir == 0 ? dA : dB) + (long long)p * pair_stride;
     const float* Y = (dir == 0 ? dB : dA) + (long long)p * pair_stride;
     const int nx = min((dir == 0 ? nA : nB)[p * count_stride], K);
     const int ny = min((dir == 0 ? nB : nA)[p * count_stride], K);
-    unsigned long long* best = (dir == 0 ? bestA : bestB) + (long long)p * K;
+    unsigned long long* best = (dir == 0 ? bestA : bestB) + ((long long)share * gridDim.y + p) * K;
+    const int ntile = (ny + 31) >> 5, per = (ntile + nsplit - 1) / nsplit;
+    const int c_begin = min(share * per, ntile) * 32, c_end = min(min((share + 1) * per, ntile) * 32, ny);
     if ((int)blockIdx.x * 128 >= nx) return;             // (the whole workgroup)
     const int r0 = (blockIdx.x * 4 + wave) * 32;
     const bool active = r0 < nx;                         // a wave without rows still stages tiles and meets the barriers
@@ -131,10 +137,10 @@ __global__ __launch_bounds__(256) void nn_rows_kernel(const float* __restrict__ 
             *reinterpret_cast<f32x4*>(&ytile[buf][row * RS + q * 4]) = stage[k];
         }
     };
-    if (ny > 0) { gload(0); lstore(0); }
+    if (c_begin < c_end) { gload(c_begin); lstore(0); }
     __syncthreads();
-    for (int c0 = 0, buf = 0; c0 < ny; c0 += 32, buf ^= 1) {
-        const bool more = c0 + 32 < ny;
+    for (int c0 = c_begin, buf = 0; c0 < c_end; c0 += 32, buf ^= 1) {
+        const bool more = c0 + 32 < c_end;
         if (more) gload(c0 + 32);                        // in flight across this tile's MFMAs
         f32x16 acc;
 #pragma unroll
@@ -178,20 +184,26 @@ __global__ __launch_bounds__(256) void mutual_kernel(const unsigned long long* _
                                                     const int* __restrict__ nA, const int* __restrict__ nB,
                                                     int count_stride, int K, float thr,
                                                     int* __restrict__ match_idx, float* __restrict__ match_dist,
-                                                    int* __restrict__ match_count)
+                                                    int* __restrict__ match_count, int nsplit)
 {
     const int p = blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
+    const long long share_stride = (long long)gridDim.y * K;        // the column shares' arrays lie [share][pair][K]
+    auto best_of = [&](const unsigned long long* b, long long at) -> unsigned long long {
+        unsigned long long v = b[at];
+        for (int sh = 1; sh < nsplit; ++sh) { const unsigned long long o = b[at + sh * share_stride]; v = o < v ? o : v; }
+        return v;
+    };
     const int na = min(nA[p * count_stride], K), nb = min(nB[p * count_stride], K);
     int hit = 0;
     if (i < K) {
         int j = -1;
         float d = 0.f;
         if (i < na && nb > 0) {
-            const unsigned long long v = bestA[(long long)p * K + i];
+            const unsigned long long v = best_of(bestA, (long long)p * K + i);
             const int jj = (int)(v & 0xffffffffu);
             d = __uint_as_float((unsigned)(v >> 32));
-            const unsigned long long w = bestB[(long long)p * K + jj];
+            const unsigned long long w = best_of(bestB, (long long)p * K + jj);
             const bool mutual = (int)(w & 0xffffffffu) == i;                   // matching.py:58-59
             const bool close = (thr < 0.f) || (d < thr);                        // matching.py:56
             if (mutual && close) j = jj;
@@ -215,23 +227,23 @@ void launch_sample_desc(const float* desc, int B, int Hc, int Wc, int D, int H, 
                        Hc, Wc, D, H, W, kp_yx, kp_count, K, out);
 }
 
-// rowbest/colbest: [P][K] packed; match_count is zeroed by the first launch
+// rowbest/colbest: [MATCH_SHARES][P][K] packed each; match_count is zeroed by the first launch
 void launch_match_impl(const float* dA, const int* nA, const float* dB, const int* nB,
                        long long pair_stride, int count_stride, int P, int K, int D, float thr,
                        unsigned long long* rowbest, unsigned long long* colbest, int* match_idx,
                        float* match_dist, int* match_count, hipStream_t s)
 {
     if (P <= 0 || K <= 0) return;
-    const dim3 grid((K + 127) / 128, P, 2);
+    const dim3 grid((K + 127) / 128, P, 2 * MATCH_SHARES);
     if (D == 64)
         hipLaunchKernelGGL(nn_rows_kernel<64>, grid, dim3(256), 0, s, dA, nA, dB, nB, pair_stride,
-                           count_stride, K, rowbest, colbest, match_count);
+                           count_stride, K, rowbest, colbest, match_count, MATCH_SHARES);
     else if (D == 128)
         hipLaunchKernelGGL(nn_rows_kernel<128>, grid, dim3(256), 0, s, dA, nA, dB, nB, pair_stride,
-                           count_stride, K, rowbest, colbest, match_count);
+                           count_stride, K, rowbest, colbest, match_count, MATCH_SHARES);
     else
         hipLaunchKernelGGL(nn_rows_kernel<256>, grid, dim3(256), 0, s, dA, nA, dB, nB, pair_stride,
-                           count_stride, K, rowbest, colbest, match_count);
+                           count_stride, K, rowbest, colbest, match_count, MATCH_SHARES);
     hipLaunchKernelGGL(mutual_kernel, dim3((K + 255) / 256, P), dim3(256), 0, s, rowbest, colbest, nA,
-                       nB, count_stride, K, thr, match_idx, match_dist, match_count);
+                       nB, count_stride, K, thr, match_idx, match_dist, match_count, MATCH_SHARES);
 }
