@@ -54,7 +54,7 @@ def test_forward_matches_oracle(oracle, shipped, B, H, W):
                                  {'MP_NO_WINOGRAD': '1'}, {'MP_NO_WINOGRAD': '1', 'MP_NO_FUSE': '1'},
                                  {'MP_NO_HEAD_FUSE': '1'}, {'MP_WINO43': '0'}, {'MP_WINO43': '1'}, {'MP_NO_PLANAR': '1'},
                                  {'MP_PLANAR': '2'}, {'MP_WINO43': '1', 'MP_PLANAR': '2'}, {'MP_NO_FUSE43': '1'}])
-@pytest.mark.parametrize('B,H,W', [(6, 120, 160), (3, 200, 328)])
+@pytest.mark.parametrize('B,H,W', [(6, 120, 160), (3, 200, 328), (3, 240, 320), (4, 64, 96)])
 def test_forward_kernel_variants(oracle, monkeypatch, env, B, H, W):
     """Every convolution kernel variant against the oracle on the same inputs: the persistent one-workgroup-per-CU
     kernel forced onto small launches (all tile shapes, partial tiles at the right/bottom edge), the per-tile kernel
@@ -63,7 +63,9 @@ def test_forward_kernel_variants(oracle, monkeypatch, env, B, H, W):
     (MP_WINO43=1), NHWC everywhere (MP_NO_PLANAR=1) or channel-quad-planar tensors between EVERY two F(4x4,3x3) layers
     (MP_PLANAR=2) instead of behind conv1 and the pooled layers only.  The default -- standalone first block writing
     planar, F(4x4,3x3) on every 3x3 layer whose frame is a multiple of 4 (F(2x2,3x3) otherwise), LDS-DMA staging -- is
-    what every other test of this file runs."""
+    what every other test of this file runs.  (240x320: conv1-5 are multiples of 4 and run F(4x4,3x3), conv6-8 and the heads
+    at 60x80 too, ... 30x40 is not: the deep layers take F(2x2,3x3) inside the SAME forward -- the mixed case the frame-size rule
+    produces; 64x96: every layer F(4x4,3x3) down to 8x12.)"""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     net, sd = _net(oracle, oracle.SHIPPED_MODEL_CONFIG, seed=4)          # new handle: reads the environment
