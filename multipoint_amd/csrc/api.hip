@@ -82,6 +82,7 @@ struct mp_handle {
     int wino43 = 2;                 // MP_WINO43: 0 off, 1 F(4x4,3x3) for the 3x3 layers with 64 input channels only, 2 (default) every 3x3 layer it supports
     bool head_fuse = true;          // MP_NO_HEAD_FUSE=1: separate 1x1 convolution / softmax / normalisation launches
     bool fuse43 = true;             // first block evaluated inside the F(4x4,3x3) conv2 kernel (MP_NO_FUSE43=1: its own launch)
+    int wino43_gen = 1;             // MP_WINO43_GEN: 1 conv_wino43.hip (two waves per SIMD), 2 conv_wino43b.hip (one wave per SIMD, whole-window transform)
     int* pinned = nullptr;          // small pinned host scratch (img lists, counters)
     bool f16_res = true;            // MP_F16_NO_RES=1: the streaming kernel (conv_f16.hip) also for the 64 -> 64 layers
     bool f16_fuse1 = true;          // MP_F16_NO_FUSE1=1: the first block of the fp16 path as its own launch
@@ -538,12 +539,12 @@ bool uses_wino43(const mp_handle* h, const ConvLayer& L, int H, int W, bool fuse
                  int out_cstride = 0, int out_coff = 0)
 {
     // fuse: the first block is evaluated by the layer's kernel -- with F(4x4,3x3) only by the pooled 64 -> 64 layer, 64 real channels
-    if (fuse && !(h->fuse43 && L.pool && L.cin == 64 && L.cout == 64 && h->cfg.channel_version == 0)) return false;
+    if (fuse && !(h->fuse43 && h->wino43_gen == 1 && L.pool && L.cin == 64 && L.cout == 64 && h->cfg.channel_version == 0)) return false;
     if (!(L.taps == 9 && L.u43pack && h->wino && (h->wino43 == 2 || L.cin == 64))) return false;
     ConvParams q{};
     q.pad_zero = h->cfg.reflection_pad ? 0 : 1; q.cin = L.cin; q.cout = L.cout; q.H = H; q.W = W;
     q.in_cstride = in_cstride; q.in_coff = in_coff; q.out_cstride = out_cstride; q.out_coff = out_coff;
-    return conv_wino43_supports(q);
+    return h->wino43_gen == 2 ? conv_wino43b_supports(q) : conv_wino43_supports(q);
 }
 
 int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, int in_coff, float* out,
@@ -594,7 +595,7 @@ int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, 
                 p.ks_shift = ks; p.split_scratch = static_cast<float*>(h->split_ws.p); p.split_ctr = h->split_ctr;
             }
         }
-        big = launch_conv_wino43(p, L.pool, s, fuse != nullptr);
+        big = h->wino43_gen == 2 ? launch_conv_wino43b(p, L.pool, s, fuse != nullptr) : launch_conv_wino43(p, L.pool, s, fuse != nullptr);
     } else if (L.taps == 9 && L.upack && h->wino && !fuse) {
         p.wpack = L.upack;
         big = launch_conv_wino(p, L.pool, s);
@@ -891,6 +892,7 @@ int mp_create(mp_handle** out, int device)
     { const char* e = getenv("MP_NO_PLANAR"); if (e && e[0] == '1') hh->planar = 0; }
     { const char* e = getenv("MP_PLANAR"); if (e && e[0] >= '0' && e[0] <= '2') hh->planar = e[0] - '0'; }
     { const char* e = getenv("MP_WINO43"); if (e && e[0] >= '0' && e[0] <= '2') hh->wino43 = e[0] - '0'; }
+    { const char* e = getenv("MP_WINO43_GEN"); if (e && (e[0] == '1' || e[0] == '2')) hh->wino43_gen = e[0] - '0'; }
     { const char* e = getenv("MP_PERSIST_MIN_ITEMS"); if (e && atoi(e) > 0) hh->persist = atoi(e); }
     { const char* e = getenv("MP_NO_PERSIST"); if (e && e[0] == '1') hh->persist = 0; }
     { const char* e = getenv("MP_SPLITK_MAX"); if (e && atoi(e) >= 1 && atoi(e) <= 8) hh->splitk_max = atoi(e); }

@@ -115,6 +115,9 @@ int launch_conv_wino(const ConvParams& p, bool pool, hipStream_t s);
 bool conv_wino43_supports(const ConvParams& p);
 long long conv_wino43_items(const ConvParams& p);      // work items the launch would have (B x tile blocks x slices)
 int launch_conv_wino43(const ConvParams& p, bool pool, hipStream_t s, bool fuse_first = false);
+// second generation (conv_wino43b.hip): one wave per SIMD, whole-window input transform; any frame size
+bool conv_wino43b_supports(const ConvParams& p);
+int launch_conv_wino43b(const ConvParams& p, bool pool, hipStream_t s, bool fuse_first = false);
 
 // fp16 path (mixed_precision: activations and packed weights fp16, fp32 accumulate; conv_f16.hip).
 // Same tiling as ConvParams; a chunk is 64 input channels, so cin must be a multiple of 64.
