@@ -23,7 +23,6 @@ struct DevBuf {
 struct ConvLayer {            // one MFMA conv launch
     const char* name = "";
     float *wpack = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
-    float* upack = nullptr;       // 3x3 layers: Winograd-domain weights U = G g G^T (conv_wino.hip)
     float* u43pack = nullptr;     // 3x3 layers: F(4x4,3x3) weights (conv_wino43.hip)
     _Float16* wpack_h = nullptr;  // mixed_precision: fp16 fragments (conv_f16.hip) and the fp16-rounded bias
     float* bias_h = nullptr;
@@ -74,15 +73,15 @@ struct mp_handle {
     int last_nms_rounds = 0;
     int head_channels = 256;        // width of each 3x3 head convolution (MultiPoint.py:38-53)
     void* dummy = nullptr;          // scratch line for masked-off store lanes of the fp16 kernels
-    bool wino = true;               // Winograd F(2x2,3x3) for the non-fused 3x3 layers (MP_NO_WINOGRAD=1 disables)
+    bool wino = true;               // Winograd F(4x4,3x3) for the 3x3 layers (MP_NO_WINOGRAD=1 / conv_algorithm 'direct': the direct kernels)
     int persist = 8;                // persistent conv workgroups for launches with >= this many items per CU
                                     // (MP_NO_PERSIST=1: never; MP_PERSIST_MIN_ITEMS=n overrides the threshold)
     bool fuse_first = true;         // fuse the Cin=1 block into the second convolution (MP_NO_FUSE=1 disables)
     int planar = 1;                 // 0 (MP_NO_PLANAR=1): NHWC everywhere; 1: channel-quad-planar tensors where they pay; 2 (MP_PLANAR=2): between every two F(4x4,3x3) layers
-    int wino43 = 2;                 // MP_WINO43: 0 off, 1 F(4x4,3x3) for the 3x3 layers with 64 input channels only, 2 (default) every 3x3 layer it supports
+    int wino43 = 2;                 // MP_WINO43: 0 off (direct kernels), 1 F(4x4,3x3) for the 3x3 layers with 64 input channels only, 2 (default) every 3x3 layer
     bool head_fuse = true;          // MP_NO_HEAD_FUSE=1: separate 1x1 convolution / softmax / normalisation launches
     bool fuse43 = true;             // first block evaluated inside the F(4x4,3x3) conv2 kernel (MP_NO_FUSE43=1: its own launch)
-    int wino43_gen = 1;             // MP_WINO43_GEN: 1 conv_wino43.hip (two waves per SIMD), 2 conv_wino43b.hip (one wave per SIMD, whole-window transform)
+    int wino43_gen = 0;             // MP_WINO43_GEN: 0 conv_wino43.hip where it applies, conv_wino43b.hip for every other shape; 1 / 2: only that kernel
     int* pinned = nullptr;          // small pinned host scratch (img lists, counters)
     bool f16_res = true;            // MP_F16_NO_RES=1: the streaming kernel (conv_f16.hip) also for the 64 -> 64 layers
     bool f16_fuse1 = true;          // MP_F16_NO_FUSE1=1: the first block of the fp16 path as its own launch
@@ -256,38 +255,6 @@ void pack_conv_weights(const std::vector<const float*>& srcs, const std::vector<
                             }
 }
 
-// Winograd F(2x2,3x3) weights for conv_wino_kernel: U[pos = 4a+b] = sum_ij G[a][i] g[i][j] G[b][j], fp32 on the host in
-// this fixed order (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]: the 0.5 factors are exact).  Layout
-//   [slice64][half(2)][chunk8 = cin/8][pos(16)][lane(64)][4]
-//   element e of lane l = U[pos][cout = slice*64 + half*32 + (l&31)][cin = chunk*8 + (l>>5)*4 + e]
-void pack_wino_weights(const std::vector<const float*>& srcs, const std::vector<int>& couts, int cin, int cin_real,
-                       std::vector<float>& out)
-{
-    static const float G[4][3] = {{1.f, 0.f, 0.f}, {0.5f, 0.5f, 0.5f}, {0.5f, -0.5f, 0.5f}, {0.f, 0.f, 1.f}};
-    int cout = 0;
-    for (int c : couts) cout += c;
-    const int nslices = (cout + 63) / 64, nchunks = cin / 8;
-    out.assign((size_t)nslices * 2 * nchunks * 16 * 64 * 4, 0.f);
-    size_t o = 0;
-    for (int s = 0; s < nslices; ++s)
-        for (int hf = 0; hf < 2; ++hf)
-            for (int c = 0; c < nchunks; ++c)
-                for (int pos = 0; pos < 16; ++pos)
-                    for (int l = 0; l < 64; ++l)
-                        for (int e = 0; e < 4; ++e, ++o) {
-                            int co = s * 64 + hf * 32 + (l & 31);
-                            const int ci = c * 8 + (l >> 5) * 4 + e;
-                            if (co >= cout || ci >= cin_real) continue;
-                            size_t t = 0;
-                            while (co >= couts[t]) { co -= couts[t]; ++t; }
-                            const float* g = srcs[t] + ((size_t)co * cin_real + ci) * 9;
-                            const int a = pos >> 2, b = pos & 3;
-                            float tmp[3];                      // (G g)[a][j]
-                            for (int j = 0; j < 3; ++j) tmp[j] = (G[a][0] * g[j] + G[a][1] * g[3 + j]) + G[a][2] * g[6 + j];
-                            out[o] = (tmp[0] * G[b][0] + tmp[1] * G[b][1]) + tmp[2] * G[b][2];
-                        }
-}
-
 // Winograd F(4x4,3x3) weights for conv_wino43_kernel: U[pos = 6i+j] = (G g G^T)[i][j] for the interpolation points
 // {0, +a, -a, +b, -b, inf} (a = MP_W43_A, b = MP_W43_B, mp_common.h): row of point p = [1, p, p^2] / prod_{q != p} (p - q), last
 // row [0, 0, 1]; evaluated in double and rounded to fp32 ONCE.  Layout = the LDS image of a unit of 4 input channels:
@@ -394,15 +361,10 @@ int build_conv(mp_handle* h, TensorMap& tm, ConvLayer& L, const char* name,
     if ((rc = upload(h, bias, &L.bias))) return rc;
     if ((rc = upload(h, scale, &L.scale))) return rc;
     if ((rc = upload(h, shift, &L.shift))) return rc;
-    if (taps == 9 && h->wino) {
-        std::vector<float> up;
-        pack_wino_weights(srcs, couts, cin, cin_real, up);
-        if ((rc = upload(h, up, &L.upack))) return rc;
-        if (h->wino43 && cin % 8 == 0) {
-            std::vector<float> u4;
-            pack_wino43_weights(srcs, couts, cin, cin_real, u4);
-            if ((rc = upload(h, u4, &L.u43pack))) return rc;
-        }
+    if (taps == 9 && h->wino && h->wino43 && cin % 8 == 0) {
+        std::vector<float> u4;
+        pack_wino43_weights(srcs, couts, cin, cin_real, u4);
+        if ((rc = upload(h, u4, &L.u43pack))) return rc;
     }
     if (h->cfg.mixed_precision) {
         std::vector<uint16_t> ph;
@@ -534,17 +496,26 @@ int launch_failed(mp_handle* h, int code, const char* name, int B, int H, int W)
                                   "layer shape (" + std::to_string(H) + "x" + std::to_string(W) + ")");
 }
 
-// does run_conv() send this 3x3 layer at H x W to the F(4x4,3x3) kernel?
-bool uses_wino43(const mp_handle* h, const ConvLayer& L, int H, int W, bool fuse, int in_cstride = 0, int in_coff = 0,
-                 int out_cstride = 0, int out_coff = 0)
+// which F(4x4,3x3) kernel run_conv() sends this 3x3 layer at H x W to: 0 none, 1 conv_wino43.hip (two waves per SIMD; reflection
+// padding and frames that are multiples of the 4x4 tile; the only one that evaluates the first block inside the launch), 2
+// conv_wino43b.hip (one wave per SIMD; any frame size, reflection or zero padding).  MP_WINO43_GEN: 0 (default) the first where
+// it applies and the second otherwise, 1 / 2 only that one.
+int wino43_kind(const mp_handle* h, const ConvLayer& L, int H, int W, bool fuse, int in_cstride = 0, int in_coff = 0,
+                int out_cstride = 0, int out_coff = 0)
 {
-    // fuse: the first block is evaluated by the layer's kernel -- with F(4x4,3x3) only by the pooled 64 -> 64 layer, 64 real channels
-    if (fuse && !(h->fuse43 && h->wino43_gen == 1 && L.pool && L.cin == 64 && L.cout == 64 && h->cfg.channel_version == 0)) return false;
-    if (!(L.taps == 9 && L.u43pack && h->wino && (h->wino43 == 2 || L.cin == 64))) return false;
+    if (!(L.taps == 9 && L.u43pack && h->wino && (h->wino43 == 2 || L.cin == 64))) return 0;
     ConvParams q{};
     q.pad_zero = h->cfg.reflection_pad ? 0 : 1; q.cin = L.cin; q.cout = L.cout; q.H = H; q.W = W;
     q.in_cstride = in_cstride; q.in_coff = in_coff; q.out_cstride = out_cstride; q.out_coff = out_coff;
-    return h->wino43_gen == 2 ? conv_wino43b_supports(q) : conv_wino43_supports(q);
+    const bool g1 = h->wino43_gen != 2 && conv_wino43_supports(q), g2 = h->wino43_gen != 1 && conv_wino43b_supports(q);
+    // fuse: the first block is evaluated by the layer's kernel -- only by the pooled 64 -> 64 layer, 64 real channels
+    if (fuse) return h->fuse43 && g1 && L.pool && L.cin == 64 && L.cout == 64 && h->cfg.channel_version == 0 ? 1 : 0;
+    return g1 ? 1 : g2 ? 2 : 0;
+}
+bool uses_wino43(const mp_handle* h, const ConvLayer& L, int H, int W, bool fuse, int in_cstride = 0, int in_coff = 0,
+                 int out_cstride = 0, int out_coff = 0)
+{
+    return wino43_kind(h, L, H, W, fuse, in_cstride, in_coff, out_cstride, out_coff) != 0;
 }
 
 int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, int in_coff, float* out,
@@ -571,14 +542,14 @@ int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, 
     } else {
         p.total_px = (long long)B * H * W;
     }
-    const bool f43 = uses_wino43(h, L, H, W, fuse != nullptr, in_cstride, in_coff, out_cstride, out_coff);
+    const int f43 = wino43_kind(h, L, H, W, fuse != nullptr, in_cstride, in_coff, out_cstride, out_coff);
     prof_begin(h, fuse ? "enc.conv1+2" : L.name,
                2.0 * L.taps * L.cin * L.cout * (double)B * H * W + (fuse ? 2.0 * 9 * 64 * (double)B * H * W : 0.0), s);
     if (fuse) { p.img = images; p.w1 = fuse->w; p.b1 = fuse->bias; p.s1 = fuse->scale; p.t1 = fuse->shift; }
     int big;
     if (f43) {
         p.wpack = L.u43pack; p.in_planar = in_planar; p.out_planar = out_planar;
-        if (!fuse && B <= 2 && h->splitk_max > 1 && h->split_ctr) {
+        if (f43 == 1 && !fuse && B <= 2 && h->splitk_max > 1 && h->split_ctr) {
             // single-pair latency (the reference's shipped batchsize: 1): a launch with fewer items than half the CUs (conv7 /
             // conv8 of one 480x640 pair: 40 items of 32 units on 256 CUs) cuts the input channels into 2, 4 or 8 ranges --
             // (cin / 4) / ranges units each, even and >= 4 -- as long as the items still fit the machine once.  Only for
@@ -595,10 +566,7 @@ int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, 
                 p.ks_shift = ks; p.split_scratch = static_cast<float*>(h->split_ws.p); p.split_ctr = h->split_ctr;
             }
         }
-        big = h->wino43_gen == 2 ? launch_conv_wino43b(p, L.pool, s, fuse != nullptr) : launch_conv_wino43(p, L.pool, s, fuse != nullptr);
-    } else if (L.taps == 9 && L.upack && h->wino && !fuse) {
-        p.wpack = L.upack;
-        big = launch_conv_wino(p, L.pool, s);
+        big = f43 == 2 ? launch_conv_wino43b(p, L.pool, s) : launch_conv_wino43(p, L.pool, s, fuse != nullptr);
     } else {
         big = launch_conv_mfma(p, L.taps, mbw, L.pool, fuse != nullptr, s);
     }
@@ -892,7 +860,7 @@ int mp_create(mp_handle** out, int device)
     { const char* e = getenv("MP_NO_PLANAR"); if (e && e[0] == '1') hh->planar = 0; }
     { const char* e = getenv("MP_PLANAR"); if (e && e[0] >= '0' && e[0] <= '2') hh->planar = e[0] - '0'; }
     { const char* e = getenv("MP_WINO43"); if (e && e[0] >= '0' && e[0] <= '2') hh->wino43 = e[0] - '0'; }
-    { const char* e = getenv("MP_WINO43_GEN"); if (e && (e[0] == '1' || e[0] == '2')) hh->wino43_gen = e[0] - '0'; }
+    { const char* e = getenv("MP_WINO43_GEN"); if (e && e[0] >= '0' && e[0] <= '2') hh->wino43_gen = e[0] - '0'; }
     { const char* e = getenv("MP_PERSIST_MIN_ITEMS"); if (e && atoi(e) > 0) hh->persist = atoi(e); }
     { const char* e = getenv("MP_NO_PERSIST"); if (e && e[0] == '1') hh->persist = 0; }
     { const char* e = getenv("MP_SPLITK_MAX"); if (e && atoi(e) >= 1 && atoi(e) <= 8) hh->splitk_max = atoi(e); }
@@ -948,9 +916,16 @@ int mp_load_weights(mp_handle* h, const mp_model_config* cfg, const mp_tensor* t
     if (cfg->descriptor_head && cfg->descriptor_size != 64 && cfg->descriptor_size != 128 &&
         cfg->descriptor_size != 256)
         return fail(h, MP_EINVAL, "unsupported model config: descriptor_size must be 64, 128 or 256");
+    if (cfg->conv_algorithm < 0 || cfg->conv_algorithm > 3)
+        return fail(h, MP_EINVAL, "unsupported model config: conv_algorithm must be 0 (auto), 1 (winograd43), 2 (winograd43_general) or 3 (direct)");
     MP_HIP(hipSetDevice(h->device));
     free_weights(h);
     h->cfg = *cfg;
+    // the convolution algorithm of the 3x3 layers is a MODEL setting (yaml model.conv_algorithm); the MP_* environment switches of
+    // mp_create only apply to 'auto'
+    if (cfg->conv_algorithm == 1) { h->wino = true; h->wino43 = 2; h->wino43_gen = 0; }
+    else if (cfg->conv_algorithm == 2) { h->wino = true; h->wino43 = 2; h->wino43_gen = 2; }
+    else if (cfg->conv_algorithm == 3) { h->wino = false; }
     TensorMap tm;
     for (int i = 0; i < n_tensors; ++i) {
         if (!tensors[i].name || (!tensors[i].data && tensors[i].numel > 0))

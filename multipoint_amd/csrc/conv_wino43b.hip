@@ -160,10 +160,9 @@ __device__ __forceinline__ float acc_read(float a)
         else DST = (ACC)[R];                                                                                               \
     } while (0)
 
-template <bool POOL, bool BNF, int TC4, bool F1, bool SPLIT = false>
+template <bool POOL, bool BNF, int TC4, bool ZPAD>
 __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const ConvParams p)
 {
-    static_assert(!F1, "the fused first block is not ported to the second generation yet");
     constexpr int TR4 = 32 / TC4;                      // tile rows x tile columns of an item
     constexpr int OY = 4 * TR4, OX = 4 * TC4;          // output pixels of an item
     constexpr int PY = OY + 2, PX = OX + 2;            // raw patch
@@ -182,7 +181,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const ConvParams p
 
     // LDS: V' first (ds_write_addtid_b32 takes its base from M0[15:0]: the V' buffers must lie below 64 KiB)
     __shared__ __attribute__((aligned(16))) float smem[2 * VB4 + 2 * UB4 + 3 * RB4 + 256 + 3 * 64 + 4 * 3 * 64];
-    __shared__ int split_flag;
     float* const Vs = smem;
     float* const Us = smem + 2 * VB4;
     float* const raw = Us + 2 * UB4;                   // three buffers + one dummy block
@@ -196,7 +194,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const ConvParams p
     const int tb = wave & 1, cbb = wave >> 1;          // tile block (16 tiles), channel block (32 couts) of this wave's GEMMs
     unsigned* const rvl = reinterpret_cast<unsigned*>(prm + 3 * 64) + wave * 192 + lane;
     const int half = wave & 1;                         // transform: rows {0, 1, 2} (0) or {5, 3, 4} (1) of the window; pair = wave >> 1
-    const int NC = SPLIT ? (p.cin / UC4) >> p.ks_shift : p.cin / UC4;      // units per item (even)
+    const int NC = p.cin / UC4;                        // units per item (even)
 
     // ---- work items: (tile block, slice) of this XCD's contiguous eighth ----
     const XcdRange xr = xcd_range(p.nitems, p.xcd_shift);
@@ -218,8 +216,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const ConvParams p
         w.y0 = ty * OY; w.x0 = tx * OX;
         w.in_base = p.in_planar ? p.in + (long long)w.img * (p.cin / 4) * p.H * p.W * 4
                                 : p.in + (long long)w.img * p.H * p.W * p.in_cstride + p.in_coff;
-        if constexpr (SPLIT)      // first unit of the item's range of input channels
-            w.in_base += (long long)((w.slice & ((1 << p.ks_shift) - 1)) * NC) * (p.in_planar ? (long long)p.H * p.W * 4 : UC4);
         return w;
     };
 
@@ -255,8 +251,14 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const ConvParams p
             int py, px;
             unsigned off = 0;
             if (slot_pixel(j, py, px, ln)) {
-                const int gy = reflect_clamp_q(w.y0 + py - 1, p.H), gx = reflect_clamp_q(w.x0 + px - 1, p.W);
-                off = (unsigned)((gy * p.W + gx) * pix_stride) * 4u;
+                if constexpr (ZPAD) {
+                    // ZeroPad2d(1): pixels outside the frame are zeros -- their lanes sit out of the DMA and store a zero granule instead
+                    const int gy = w.y0 + py - 1, gx = w.x0 + px - 1;
+                    off = (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? (unsigned)((gy * p.W + gx) * pix_stride) * 4u : 0xFFFFFFFFu;
+                } else {
+                    const int gy = reflect_clamp_q(w.y0 + py - 1, p.H), gx = reflect_clamp_q(w.x0 + px - 1, p.W);
+                    off = (unsigned)((gy * p.W + gx) * pix_stride) * 4u;
+                }
             }
             rvl[j * 64] = off;
         }
@@ -265,11 +267,22 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const ConvParams p
     const unsigned raw_lds = lds_addr(raw), us_lds = lds_addr(Us), vs_lds = lds_addr(Vs);
     const unsigned raw_m0 = raw_lds + (unsigned)wave * 1024u;             // block `wave` of buffer 0
     const unsigned raw_dummy = raw_lds + 3u * RB4 * 4u;
+    const f32x4 zero4v = {0.f, 0.f, 0.f, 0.f};
     auto raw_dma = [&](const float* src, unsigned boff_bytes, int j, unsigned voff) __attribute__((always_inline)) {
         const unsigned dst = (wave + 4 * j < NRB) ? raw_m0 + (unsigned)j * 4096u + boff_bytes : raw_dummy;
         if (MPQX & 16) return;                                            // (timing only)
         if (MPQX & 64) { dma16(src, (unsigned)lane * 16u, dst); return; } // (timing only: a linear 1 KiB instead of the patch gather)
         if (MPQX & 128) { dma16(p.in, voff, dst); return; }               // (timing only: the gather pattern on cache-hot addresses)
+        if constexpr (ZPAD) {
+            // lanes whose pixel lies outside the frame (offset ~0) are masked out of the DMA and write a zero granule into their slot
+            // instead: every slot of the buffer is written each unit, by one or the other -- no branch in the unit body
+            unsigned keep; unsigned long long save;
+            const unsigned slot = dst + (unsigned)lane * 16u;
+            asm volatile("v_cmp_ne_u32 vcc, -1, %2\n\ts_mov_b64 %1, exec\n\ts_and_b64 exec, exec, vcc\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 1\n\t"
+                         "global_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0\n\ts_andn2_b64 exec, %1, vcc\n\tds_write_b128 %5, %6\n\ts_mov_b64 exec, %1"
+                         : "=&s"(keep), "=&s"(save) : "v"(voff), "s"(src), "s"(dst), "v"(slot), "v"(zero4v) : "memory", "vcc", "scc");
+            return;
+        }
         dma16(src, voff, dst);
     };
     // weight blocks 9 wave + i (i = 0..8) of the unit whose weights start at `ub` -> U[buf]: source and destination bases point 4 KiB
@@ -288,7 +301,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const ConvParams p
     };
     auto u_ptr = [&](int slice) __attribute__((always_inline)) -> const float* { return p.wpack + (long long)slice * NC * UB4; };
     auto load_prm = [&](int vslice) __attribute__((always_inline)) {
-        const int slice = SPLIT ? vslice >> p.ks_shift : vslice;
+        const int slice = vslice;
         if (tid < 64) {
             prm[tid] = p.bias[slice * 64 + tid]; prm[64 + tid] = p.scale[slice * 64 + tid]; prm[128 + tid] = p.shift[slice * 64 + tid];
         }
@@ -550,114 +563,35 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const ConvParams p
             constexpr int NO = POOL ? 2 : 4;                            // output rows / columns per tile
             const int Ho = POOL ? p.H >> 1 : p.H, Wo = POOL ? p.W >> 1 : p.W;
             const int py0 = POOL ? oy >> 1 : oy, px0 = POOL ? ox >> 1 : ox;
-            bool finish = true;
-            if constexpr (SPLIT) {
-                // this item's share of the sum over input channels leaves as pre-bias output tiles; the last range of the group to
-                // arrive adds the shares up in range order (deterministic) and continues with the ordinary epilogue
-                // (agent-scope relaxed atomics = sc1 stores / loads: coherent across the XCDs' L2s by themselves)
-                unsigned long long* const part = reinterpret_cast<unsigned long long*>(p.split_scratch) + (long long)item * (2 * 16 * 512) + tid;
-#pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        f32x2 tcol[4][6];
-#pragma unroll
-                        for (int j = 0; j < 6; ++j) {
-                            f32x2 mm[6], y[4];
-#pragma unroll
-                            for (int i = 0; i < 6; ++i) {
-                                float lo, hi;
-                                MPB_ACC_RD(lo, acc[6 * i + j][m], (6 * i + j) * 2 + m, 2 * h);
-                                MPB_ACC_RD(hi, acc[6 * i + j][m], (6 * i + j) * 2 + m, 2 * h + 1);
-                                mm[i] = f32x2{lo, hi};
-                            }
-                            at6(mm, y);
-#pragma unroll
-                            for (int a = 0; a < 4; ++a) tcol[a][j] = y[a];
-                        }
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) {
-                            f32x2 y[4];
-                            at6(tcol[a], y);
-#pragma unroll
-                            for (int b = 0; b < 4; ++b)
-                                __hip_atomic_store(&part[(((m * 2 + h) * 16) + a * 4 + b) * 256], __builtin_bit_cast(unsigned long long, y[b]),
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-                    }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's shares have been written ...
-                __syncthreads();                                        // ... and every wave's, before the group's count moves
-                if (tid == 0)
-                    split_flag = __hip_atomic_fetch_add(&p.split_ctr[item >> p.ks_shift], 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                __syncthreads();
-                finish = split_flag == (1 << p.ks_shift) - 1;
-                if (finish && tid == 0)                                 // ready for the next launch
-                    __hip_atomic_store(&p.split_ctr[item >> p.ks_shift], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (finish) {
-            const unsigned long long* const part0 = SPLIT ? reinterpret_cast<const unsigned long long*>(p.split_scratch) +
-                                                            (long long)((item >> p.ks_shift) << p.ks_shift) * (2 * 16 * 512) + tid : nullptr;
+            {
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
             const int cl = cbb * 32 + m * 16 + 4 * (eln >> 4);          // first of this lane's 4 output channels in the slice
             const f32x4 b4 = *reinterpret_cast<const f32x4*>(&prm[cl]);
             const f32x4 s4 = *reinterpret_cast<const f32x4*>(&prm[64 + cl]);
             const f32x4 t4 = *reinterpret_cast<const f32x4*>(&prm[128 + cl]);
-            const int ch0 = (SPLIT ? cur.slice >> p.ks_shift : cur.slice) * 64 + cl;
+            const int ch0 = cur.slice * 64 + cl;
             f32x2 keep[NO][NO];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
-                f32x2 yv[SPLIT ? 4 : 1][4];                             // SPLIT: [row a][col b] summed over the ranges
-                f32x2 tcol[4][6];                                       // !SPLIT: T[a][j] = sum_i A^T[a][i] M[i][j]
-                if constexpr (!SPLIT) {
+                f32x2 tcol[4][6];                                       // T[a][j] = sum_i A^T[a][i] M[i][j]
 #pragma unroll
-                    for (int j = 0; j < 6; ++j) {
-                        f32x2 mm[6], y[4];
+                for (int j = 0; j < 6; ++j) {
+                    f32x2 mm[6], y[4];
 #pragma unroll
-                        for (int i = 0; i < 6; ++i) {
-                            float lo, hi;
-                            MPB_ACC_RD(lo, acc[6 * i + j][m], (6 * i + j) * 2 + m, 2 * h);
-                            MPB_ACC_RD(hi, acc[6 * i + j][m], (6 * i + j) * 2 + m, 2 * h + 1);
-                            mm[i] = f32x2{lo, hi};
-                        }
-                        at6(mm, y);
-#pragma unroll
-                        for (int a = 0; a < 4; ++a) tcol[a][j] = y[a];
-                        __builtin_amdgcn_sched_barrier(0);      // (register peak: the scheduler otherwise hoists every accumulator read)
+                    for (int i = 0; i < 6; ++i) {
+                        float lo, hi;
+                        MPB_ACC_RD(lo, acc[6 * i + j][m], (6 * i + j) * 2 + m, 2 * h);
+                        MPB_ACC_RD(hi, acc[6 * i + j][m], (6 * i + j) * 2 + m, 2 * h + 1);
+                        mm[i] = f32x2{lo, hi};
                     }
-                } else {
-                    // the shares come from memory (sc1 loads): every load of a row pair is issued before the first value is used
-                    const int KS = 1 << p.ks_shift;
+                    at6(mm, y);
 #pragma unroll
-                    for (int a0 = 0; a0 < 4; a0 += 2) {
-                        unsigned long long rawv[8][8];
-#pragma unroll
-                        for (int k = 0; k < 8; ++k)
-                            if (k < KS) {
-#pragma unroll
-                                for (int i = 0; i < 8; ++i)
-                                    rawv[k][i] = __hip_atomic_load(&part0[(long long)k * (2 * 16 * 512) + (((m * 2 + h) * 16) + a0 * 4 + i) * 256],
-                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
-#pragma unroll
-                        for (int i = 0; i < 8; ++i) {
-                            f32x2 y = __builtin_bit_cast(f32x2, rawv[0][i]);
-#pragma unroll
-                            for (int k = 1; k < 8; ++k)
-                                if (k < KS) y += __builtin_bit_cast(f32x2, rawv[k][i]);        // range order: deterministic
-                            yv[a0 + i / 4][i % 4] = y;
-                        }
-                    }
+                    for (int a = 0; a < 4; ++a) tcol[a][j] = y[a];
+                    __builtin_amdgcn_sched_barrier(0);      // (register peak: the scheduler otherwise hoists every accumulator read)
                 }
                 const f32x2 bb = {b4[2 * h], b4[2 * h + 1]}, ss = {s4[2 * h], s4[2 * h + 1]}, tt = {t4[2 * h], t4[2 * h + 1]};
-                auto out_row = [&](const int a, f32x2 (&y)[4]) __attribute__((always_inline)) {       // row a of the 4x4 output tile, pre-bias
-                    if constexpr (SPLIT) {
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) y[b] = yv[a][b];
-                    } else {
-                        at6(tcol[a], y);
-                    }
-                };
+                auto out_row = [&](const int a, f32x2 (&y)[4]) __attribute__((always_inline)) { at6(tcol[a], y); };       // row a of the 4x4 output tile, pre-bias
                 auto act = [&](f32x2 v) __attribute__((always_inline)) -> f32x2 {
                     v = v + bb;
                     if (BNF) { v = v * ss + tt; return f32x2{relu_q(v[0]), relu_q(v[1])}; }
@@ -737,12 +671,11 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const ConvParams p
     if (cbb == 0) item_loop(std::integral_constant<int, 0>{}); else item_loop(std::integral_constant<int, 1>{});
 }
 
-template <bool POOL, int TC4, bool SPLIT = false>
+template <bool POOL, int TC4, bool ZPAD>
 int launch_q(const ConvParams& p, hipStream_t s)
 {
     constexpr int OY = 4 * (32 / TC4), OX = 4 * TC4;
     ConvParams q = p;
-    if (SPLIT) q.nslices = p.nslices << p.ks_shift;         // virtual slices: (slice, range of input channels)
     q.tiles_x = (p.W + OX - 1) / OX; q.tiles_y = (p.H + OY - 1) / OY;
     const long long nitems = (long long)p.B * q.tiles_x * q.tiles_y * q.nslices;
     if (nitems <= 0) return 0;
@@ -753,37 +686,32 @@ int launch_q(const ConvParams& p, hipStream_t s)
     q.nitems = (int)nitems;
     const unsigned grid = persistent_grid(nitems, p.ncu, p.xcd_shift);
     const ConvParams& pp = q;
-    if (p.bn_first) hipLaunchKernelGGL((conv_wino43b_kernel<POOL, true, TC4, false, SPLIT>), dim3(grid), dim3(256), 0, s, pp);
-    else hipLaunchKernelGGL((conv_wino43b_kernel<POOL, false, TC4, false, SPLIT>), dim3(grid), dim3(256), 0, s, pp);
+    if (p.bn_first) hipLaunchKernelGGL((conv_wino43b_kernel<POOL, true, TC4, ZPAD>), dim3(grid), dim3(256), 0, s, pp);
+    else hipLaunchKernelGGL((conv_wino43b_kernel<POOL, false, TC4, ZPAD>), dim3(grid), dim3(256), 0, s, pp);
     return 0;
 }
 
 // the item shape that covers the frame with fewer items (16 x 32 pixels on a tie: longer contiguous patch rows)
-template <bool POOL, bool SPLIT = false>
+template <bool POOL, bool ZPAD>
 int launch_shape(const ConvParams& p, hipStream_t s)
 {
     const long long wide = (long long)((p.W + 31) / 32) * ((p.H + 15) / 16), tall = (long long)((p.W + 15) / 16) * ((p.H + 31) / 32);
-    return tall < wide ? launch_q<POOL, 4, SPLIT>(p, s) : launch_q<POOL, 8, SPLIT>(p, s);
+    return tall < wide ? launch_q<POOL, 4, ZPAD>(p, s) : launch_q<POOL, 8, ZPAD>(p, s);
 }
 
 }  // namespace
 
-// true when launch_conv_wino43b handles this layer shape: reflection padding, input channels a multiple of 8 (units of 4, walked
-// in pairs), output channels a multiple of 4 (16-byte stores); ANY frame of at least 2 x 2 pixels (tiles that stick out of the
-// frame are masked in the epilogue)
+// true when launch_conv_wino43b handles this layer shape: input channels a multiple of 8 (units of 4, walked in pairs), output
+// channels a multiple of 4 (16-byte stores); reflection OR zero padding; ANY frame of at least 2 x 2 pixels (tiles that stick out
+// of the frame are masked in the epilogue)
 bool conv_wino43b_supports(const ConvParams& p)
 {
-    return !p.pad_zero && p.cin % 8 == 0 && p.cout % 4 == 0 && p.H >= 2 && p.W >= 2 &&
+    return p.cin % 8 == 0 && p.cout % 4 == 0 && p.H >= 2 && p.W >= 2 &&
            p.in_cstride % 4 == 0 && p.in_coff % 4 == 0 && p.out_cstride % 4 == 0 && p.out_coff % 4 == 0;
 }
 
-int launch_conv_wino43b(const ConvParams& p, bool pool, hipStream_t s, bool fuse_first)
+int launch_conv_wino43b(const ConvParams& p, bool pool, hipStream_t s)
 {
-    if (fuse_first) return 2;          // 2: shape not covered
-    if (p.ks_shift > 0) {
-        const int ncs = (p.cin / 4) >> p.ks_shift;
-        if (ncs < 4 || (ncs & 1) || (ncs << p.ks_shift) * 4 != p.cin || !p.split_scratch || !p.split_ctr) return 2;
-        return pool ? launch_shape<true, true>(p, s) : launch_shape<false, true>(p, s);
-    }
-    return pool ? launch_shape<true>(p, s) : launch_shape<false>(p, s);
+    if (p.pad_zero) return pool ? launch_shape<true, true>(p, s) : launch_shape<false, true>(p, s);
+    return pool ? launch_shape<true, false>(p, s) : launch_shape<false, false>(p, s);
 }

@@ -96,8 +96,6 @@ struct Conv1Params {
 // can address (items * max divisor >= 2^32): nothing is launched and the caller reports MP_EINVAL
 int launch_conv_mfma(const ConvParams& p, int taps, int mbw, bool pool, bool fuse1, hipStream_t s);
 void launch_conv_first(const Conv1Params& p, hipStream_t s);
-// Winograd F(2x2,3x3) flavour of the 3x3 layers (conv_wino.hip); p.wpack = weights packed by pack_wino_weights()
-int launch_conv_wino(const ConvParams& p, bool pool, hipStream_t s);
 // Winograd F(4x4,3x3) (conv_wino43.hip): p.wpack = pack_wino43_weights() output; supports() says whether the shape is covered
 // Interpolation points of the F(4x4,3x3) transforms: {0, +-a, +-b, inf}.  The textbook choice a = 1, b = 2 (Lavin & Gray) has
 // integer transform matrices but the worst conditioning of the family: its fp32 error is ~20x that of a direct fp32
@@ -117,7 +115,7 @@ long long conv_wino43_items(const ConvParams& p);      // work items the launch 
 int launch_conv_wino43(const ConvParams& p, bool pool, hipStream_t s, bool fuse_first = false);
 // second generation (conv_wino43b.hip): one wave per SIMD, whole-window input transform; any frame size
 bool conv_wino43b_supports(const ConvParams& p);
-int launch_conv_wino43b(const ConvParams& p, bool pool, hipStream_t s, bool fuse_first = false);
+int launch_conv_wino43b(const ConvParams& p, bool pool, hipStream_t s);
 
 // fp16 path (mixed_precision: activations and packed weights fp16, fp32 accumulate; conv_f16.hip).
 // Same tiling as ConvParams; a chunk is 64 input channels, so cin must be a multiple of 64.

@@ -29,6 +29,10 @@ class MultiPoint:
         'mixed_precision': False,
         'force_return_logits': False
     }
+    # multipoint_amd only (no reference counterpart, hence not in default_config): optional key model.conv_algorithm, the algorithm of
+    # the 3x3 convolutions -- 'auto' | 'winograd43' | 'winograd43_general' | 'direct' (include/multipoint_hip.h:
+    # mp_model_config.conv_algorithm)
+    CONV_ALGORITHMS = {'auto': 0, 'winograd43': 1, 'winograd43_general': 2, 'direct': 3}
 
     def __init__(self, config=None):
         if config:
@@ -37,6 +41,8 @@ class MultiPoint:
             self.config = copy.deepcopy(self.default_config)
         if self.config['channel_version'] not in (0, 1, 2):
             raise ValueError('channel_version must be 0, 1 or 2 (MultiPoint.py:38-53)')
+        if self.config.get('conv_algorithm', 'auto') not in self.CONV_ALGORITHMS:
+            raise ValueError('conv_algorithm must be one of %s' % ', '.join(self.CONV_ALGORITHMS))
         if self.config['channel_version'] != 0 and self.config['mixed_precision']:
             raise ValueError('mixed_precision (fp16 MFMA path) needs channel_version 0')
         if not self.config['double_convolution'] and self.config['mixed_precision']:
@@ -193,7 +199,8 @@ class MultiPoint:
                 for k in ('multispectral', 'descriptor_head', 'descriptor_size', 'normalize_descriptors',
                           'final_batchnorm', 'reflection_pad', 'bn_first', 'double_convolution', 'channel_version')]
         vals += [self._abi_extra['batchnorm'], self._abi_extra['key_layout'], self._abi_extra['softmax_mode'],
-                 int(bool(c['mixed_precision']))]      # MultiPoint.py:99-103: forward under autocast -> fp16 MFMA path
+                 int(bool(c['mixed_precision'])),      # MultiPoint.py:99-103: forward under autocast -> fp16 MFMA path
+                 self.CONV_ALGORITHMS[c.get('conv_algorithm', 'auto')]]
         cfg = _lib.ModelConfig(*vals)
         keep = []
         arr = []

@@ -20,7 +20,10 @@ class SuperPointMagicLeap(MultiPoint):
     _abi_extra = {'batchnorm': 0, 'key_layout': 1, 'softmax_mode': 1}
 
     def __init__(self, config=None):
-        super().__init__(dict(self._fixed))
+        fixed = dict(self._fixed)
+        if isinstance(config, dict) and 'conv_algorithm' in config:      # the one multipoint_amd-only setting passes through
+            fixed['conv_algorithm'] = config['conv_algorithm']
+        super().__init__(fixed)
         self.user_config = config
 
     def state_dict_spec(self):

@@ -147,7 +147,7 @@ def trained_like_weights(seed, cfg=None, calib=None, var_range=(1e-3, 1e2), gamm
 
 def forward64(sd, image, cfg=None):
     """The oracle's forward evaluated in fp64 on the fp32 weights / images: the ground truth every fp32 implementation (ATen
-    CPU, direct MFMA, Winograd F(2x2), F(4x4)) is measured against."""
+    CPU, direct MFMA, Winograd F(4x4)) is measured against."""
     sd64 = {k: (v.double() if v.dtype == torch.float32 else v) for k, v in sd.items()}
     return O.forward(sd64, image.double(), cfg)
 
@@ -160,7 +160,9 @@ SEVERITIES = {
     'wide+hot': dict(var_range=(1e-3, 1e2), gamma_range=(0.1, 10.0), n_hot=3),
 }
 
-VARIANT_ENV = {'F(4x4,3x3)': {}, 'F(2x2,3x3)': {'MP_WINO43': '0'}, 'direct': {'MP_NO_WINOGRAD': '1'}}
+# kernel families of the 3x3 layers: the default (conv_wino43.hip where it applies, first block fused), the any-frame-size
+# F(4x4,3x3) kernel on every layer (conv_wino43b.hip), the direct implicit-GEMM kernels
+VARIANT_ENV = {'F(4x4,3x3)': {}, 'F(4x4,3x3) general': {'MP_WINO43_GEN': '2'}, 'direct': {'MP_NO_WINOGRAD': '1'}}
 
 
 def case(severity, seed, B, H, W, cfg=None):
@@ -185,7 +187,7 @@ def gpu_outputs(cfg, sd, img, env):
     """prob / desc / logits of the HIP path with the given kernel-selection environment (a new handle reads it)."""
     import os
     import multipoint_amd.models as M
-    old = {k: os.environ.get(k) for k in ('MP_WINO43', 'MP_NO_WINOGRAD')}
+    old = {k: os.environ.get(k) for k in ('MP_WINO43', 'MP_NO_WINOGRAD', 'MP_WINO43_GEN')}
     try:
         for k in old:
             os.environ.pop(k, None)

@@ -4,8 +4,8 @@ threshold 0.015, top-k 1000) -- the reference's contract is the index list torch
 with the oracle's; every keypoint that differs must be explained by a measured fp32-noise flip (oracle/flip_accounting.py:
 threshold crossing, order flip with a footprint neighbour, cascade through a neighbour, or rank displacement at the top-k
 boundary), the HIP NMS / top-k on the GPU's own map must equal the oracle's bit for bit, and descriptors are compared on
-the intersection.  Run for the default path (Winograd F(2x2,3x3)), the direct-convolution path (MP_NO_WINOGRAD=1) and the
-fp16 MFMA path (mixed_precision)."""
+the intersection.  Run for the default path (Winograd F(4x4,3x3)), the any-frame-size F(4x4,3x3) kernel on every layer and the
+direct-convolution path (both selected through the product's model.conv_algorithm), and the fp16 MFMA path (mixed_precision)."""
 import json
 
 import numpy as np
@@ -34,7 +34,7 @@ def _cpu_side(oracle, sd, cfg, P, H, W, mixed):
     return _cpu_cache[key]
 
 
-@pytest.mark.parametrize('variant,P,root_tol', [('winograd', 32, 2e-4), ('winograd22', 16, 2e-4), ('direct', 16, 2e-4),
+@pytest.mark.parametrize('variant,P,root_tol', [('winograd', 32, 2e-4), ('winograd43_general', 16, 2e-4), ('direct', 16, 2e-4),
                                                 ('fp16', 4, None)])
 def test_e2e_keypoint_flip_accounting(oracle, monkeypatch, variant, P, root_tol):
     import multipoint_amd.models as M
@@ -42,10 +42,9 @@ def test_e2e_keypoint_flip_accounting(oracle, monkeypatch, variant, P, root_tol)
     from oracle import flip_accounting as FA
     H, W = 480, 640
     cfg = dict(oracle.SHIPPED_MODEL_CONFIG)
-    if variant == 'direct':
-        monkeypatch.setenv('MP_NO_WINOGRAD', '1')
-    if variant == 'winograd22':                      # F(2x2,3x3) on every 3x3 layer ('winograd' = the default: F(4x4,3x3))
-        monkeypatch.setenv('MP_WINO43', '0')
+    # the product's own switch (yaml model.conv_algorithm -> mp_model_config.conv_algorithm), not the developer environment
+    if variant in ('direct', 'winograd43_general'):
+        cfg['conv_algorithm'] = variant
     if variant == 'fp16':
         cfg['mixed_precision'] = True
     sd = oracle.make_weights(0, cfg)
@@ -117,7 +116,7 @@ def test_unlimited_topk_lists_grow_instead_of_truncating(oracle):
 def test_launch_beyond_tile_decode_is_an_error(oracle):
     """A layer with more work items than the kernels' 32-bit magic-number tile decode addresses (items x max divisor >= 2^32)
     must fail with MP_EINVAL -- not return MP_OK with stale outputs: a 16 x 2097152 image has 65536 columns of the
-    F(4x4,3x3) kernel's 32-pixel-wide items (and 131072 of the F(2x2,3x3) kernel's)."""
+    F(4x4,3x3) kernels' 32-pixel-wide items."""
     import multipoint_amd.models as M
     cfg = dict(oracle.SHIPPED_MODEL_CONFIG)
     net = M.MultiPoint(dict(cfg)); net.load_state_dict(oracle.make_weights(0, cfg)); net.to('cuda'); net.eval()

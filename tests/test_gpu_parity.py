@@ -53,18 +53,20 @@ def test_forward_matches_oracle(oracle, shipped, B, H, W):
 @pytest.mark.parametrize('env', [{'MP_PERSIST_MIN_ITEMS': '1'}, {'MP_NO_PERSIST': '1'}, {'MP_NO_FUSE': '1'},
                                  {'MP_NO_WINOGRAD': '1'}, {'MP_NO_WINOGRAD': '1', 'MP_NO_FUSE': '1'},
                                  {'MP_NO_HEAD_FUSE': '1'}, {'MP_WINO43': '0'}, {'MP_WINO43': '1'}, {'MP_NO_PLANAR': '1'},
-                                 {'MP_PLANAR': '2'}, {'MP_WINO43': '1', 'MP_PLANAR': '2'}, {'MP_NO_FUSE43': '1'}])
+                                 {'MP_PLANAR': '2'}, {'MP_WINO43': '1', 'MP_PLANAR': '2'}, {'MP_NO_FUSE43': '1'},
+                                 {'MP_WINO43_GEN': '2'}, {'MP_WINO43_GEN': '2', 'MP_PLANAR': '2'}, {'MP_WINO43_GEN': '1'}])
 @pytest.mark.parametrize('B,H,W', [(6, 120, 160), (3, 200, 328), (3, 240, 320), (4, 64, 96)])
 def test_forward_kernel_variants(oracle, monkeypatch, env, B, H, W):
     """Every convolution kernel variant against the oracle on the same inputs: the persistent one-workgroup-per-CU
     kernel forced onto small launches (all tile shapes, partial tiles at the right/bottom edge), the per-tile kernel
     only, the unfused first block in front of the direct second convolution, the first block fused into the direct kernel, the four separate head-tail launches instead of the fused
-    head_tail kernel, Winograd F(2x2,3x3) everywhere (MP_WINO43=0), F(4x4,3x3) on the 64-input-channel layers only
-    (MP_WINO43=1), NHWC everywhere (MP_NO_PLANAR=1) or channel-quad-planar tensors between EVERY two F(4x4,3x3) layers
+    head_tail kernel, no Winograd kernel at all (MP_WINO43=0), F(4x4,3x3) on the 64-input-channel layers only
+    (MP_WINO43=1), the any-frame-size F(4x4,3x3) kernel on EVERY 3x3 layer (MP_WINO43_GEN=2: conv_wino43b.hip) or on none (=1: the direct
+    kernels take the frames conv_wino43.hip does not), NHWC everywhere (MP_NO_PLANAR=1) or channel-quad-planar tensors between EVERY two F(4x4,3x3) layers
     (MP_PLANAR=2) instead of behind conv1 and the pooled layers only.  The default -- standalone first block writing
-    planar, F(4x4,3x3) on every 3x3 layer whose frame is a multiple of 4 (F(2x2,3x3) otherwise), LDS-DMA staging -- is
+    planar, conv_wino43.hip on every 3x3 layer whose frame is a multiple of 4 (conv_wino43b.hip otherwise), LDS-DMA staging -- is
     what every other test of this file runs.  (240x320: conv1-5 are multiples of 4 and run F(4x4,3x3), conv6-8 and the heads
-    at 60x80 too, ... 30x40 is not: the deep layers take F(2x2,3x3) inside the SAME forward -- the mixed case the frame-size rule
+    at 60x80 too, ... 30x40 is not: the deep layers take the any-frame-size kernel inside the SAME forward -- the mixed case the frame-size rule
     produces; 64x96: every layer F(4x4,3x3) down to 8x12.)"""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
@@ -667,7 +669,7 @@ def test_machine_shape_is_derived_from_the_device():
 def test_smaller_machine_shapes_give_the_same_results(oracle, monkeypatch, shape, upd):
     """A partitioned or CU-masked device (MP_NCU / MP_NXCD emulate one on the full chip): fewer persistent workgroups and
     another XCD split of the work items, bit-identical outputs -- every persistent kernel family (F(4x4,3x3) with the fused
-    first block, F(2x2,3x3) on the deep 240x320 layers, the fused head tail, the fp16 kernels)."""
+    first block, the any-frame-size kernel on the deep 240x320 layers, the fused head tail, the fp16 kernels)."""
     from multipoint_amd import _lib
     cfg = dict(oracle.SHIPPED_MODEL_CONFIG); cfg.update(upd)
     img = oracle.make_images(77, 6, 240, 320).cuda()

@@ -386,3 +386,15 @@ def test_bench_traffic_figure_only_next_to_the_kernel_it_was_measured_on(tmp_pat
     assert bench.pmc_traffic('c5', 'k<true,8,false>') is None           # no file for that workload
     (prof / 'r03_pmc_hbm_traffic.json').write_text('{"dominant_kernel": "k<true, 8, false>"}')
     assert bench.pmc_traffic('c3', 'k<true,8,false>') is None           # a broken newest file does not expose the older one
+
+
+def test_conv_algorithm_is_a_model_setting():
+    """model.conv_algorithm (multipoint_amd only: the algorithm of the 3x3 convolutions) is validated on the host and is NOT part of
+    default_config, which stays equal to the reference's (tests/test_oracle_vs_reference.py)."""
+    import multipoint_amd.models as M
+    assert 'conv_algorithm' not in M.MultiPoint.default_config
+    assert M.MultiPoint({'conv_algorithm': 'direct'}).config['conv_algorithm'] == 'direct'
+    assert set(M.MultiPoint.CONV_ALGORITHMS) == {'auto', 'winograd43', 'winograd43_general', 'direct'}
+    with pytest.raises(ValueError):
+        M.MultiPoint({'conv_algorithm': 'winograd22'})
+    assert M.SuperPointMagicLeap({'conv_algorithm': 'direct'}).config['conv_algorithm'] == 'direct'
