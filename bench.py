@@ -112,10 +112,10 @@ def cpu_baseline(sd, cfg, n_pairs=16, H=H, W=W, PRED_CFG=PRED_CFG):
     pairs = [SyntheticPairs.make_pair(0, p, H, W) for p in range(n_pairs)]
     imgs = torch.from_numpy(np.stack([x for pr in pairs for x in pr]))              # interleaved like the GPU batch
     flags = (torch.arange(2 * n_pairs) % 2 == 0).reshape(-1, 1)
-    # ATen's CPU convolution does not scale to every hardware thread of a big host: pick the faster of two pool sizes on
-    # a one-pair probe (the choice and both timings are reported)
+    # ATen's CPU convolution does not scale to every hardware thread of a big host: pick the fastest pool size on a one-pair
+    # probe (the choice and every timing are reported)
     probe = {}
-    for nt in sorted({min(ncpu, 64), min(ncpu, 16)}):
+    for nt in sorted({min(ncpu, k) for k in (16, 32, 64, 128, ncpu)}):
         torch.set_num_threads(nt)
         O.forward(sd, imgs[:2], cfg, is_optical=flags[:2])                           # warm-up
         t0 = time.perf_counter(); O.forward(sd, imgs[:2], cfg, is_optical=flags[:2]); probe[nt] = time.perf_counter() - t0
@@ -127,9 +127,11 @@ def cpu_baseline(sd, cfg, n_pairs=16, H=H, W=W, PRED_CFG=PRED_CFG):
     t1 = time.perf_counter()
     prob = out['prob'].numpy(); desc = out['desc'].numpy()
     pn = prob.copy()
-    if nms > 0:                                     # one batched call per spectrum, thermal first (evaluation.py:231-240)
-        pn[1::2] = O.box_nms(prob[1::2], nms, thr, keep_top_k=topk)
-        pn[0::2] = O.box_nms(prob[0::2], nms, thr, keep_top_k=topk)
+    if nms > 0:
+        # one batched_nms call per spectrum, thermal first (evaluation.py:231-240) -- dispatched as torchvision does: a single
+        # coordinate-offset call up to 4000 box coordinates, a per-image loop above (16 images x ~4000 candidates: the loop)
+        pn[1::2] = O.box_nms(prob[1::2], nms, thr, keep_top_k=topk, dispatch='torchvision')
+        pn[0::2] = O.box_nms(prob[0::2], nms, thr, keep_top_k=topk, dispatch='torchvision')
     t2 = time.perf_counter()
     kps = [O.keypoints_from_map(pn[b, 0], thr) for b in range(2 * n_pairs)]
     rows = [O.interpolate_descriptors(kps[b], desc[b], H, W) for b in range(2 * n_pairs)]
@@ -141,16 +143,24 @@ def cpu_baseline(sd, cfg, n_pairs=16, H=H, W=W, PRED_CFG=PRED_CFG):
                         desc_thermal=rows[2 * p + 1], match_query=q, match_train=t, match_dist=dist))
     t4 = time.perf_counter()
     dt = t4 - t0
+    # second field (not part of `value`): the same NMS as ONE O(kept x candidates) pass over the concatenation of a spectrum --
+    # what rounds 1-3 timed; timed here on the thermal spectrum only (the optical one costs the same), results must be equal
+    single = None
+    if nms > 0:
+        ts = time.perf_counter()
+        same = np.array_equal(O.box_nms(prob[1::2], nms, thr, keep_top_k=topk), pn[1::2])
+        single = {'seconds_one_spectrum': round(time.perf_counter() - ts, 3), 'equal_to_per_image_dispatch': bool(same)}
     rec = {'value': n_pairs / dt, 'unit': 'image-pairs/s', 'cores': threads, 'kind': 'port',
-           'host_cpus': ncpu,
+           'host_cpus': ncpu, 'nms_dispatch': 'torchvision batched_nms: per-image loop above 4000 box coordinates',
+           'box_nms_single_call': single,
            'stage_seconds': {'forward': round(t1 - t0, 3), 'box_nms+topk': round(t2 - t1, 3),
                              'keypoints+descriptor_sampling': round(t3 - t2, 3), 'mutual_nn_match': round(t4 - t3, 3)},
            'thread_probe_seconds_per_pair_forward': {str(k): round(v, 3) for k, v in probe.items()},
-           'sample': '%d pairs %dx%d, full path (oracle: ATen-CPU forward%s, C greedy NMS, numpy sampling + NNMatcher), '
-                     '%.1f s on %d torch threads; %.0f %% of it is the box-NMS stage (the reference batches all images of a '
-                     'spectrum into ONE O(kept x candidates) torchvision call, utils.py:99-103), %.0f %% the forward'
+           'sample': '%d pairs %dx%d, full path (oracle: ATen-CPU forward%s, C greedy NMS dispatched per image like torchvision\'s '
+                     'batched_nms above 4000 box coordinates, numpy sampling + NNMatcher), %.1f s on %d torch threads: %.0f %% the '
+                     'forward, %.0f %% the box-NMS stage'
                      % (n_pairs, H, W, ' with the fp16 rounding points of autocast emulated in fp32 arithmetic'
-                        if cfg.get('mixed_precision') else '', dt, threads, 100 * (t2 - t1) / dt, 100 * (t1 - t0) / dt)}
+                        if cfg.get('mixed_precision') else '', dt, threads, 100 * (t1 - t0) / dt, 100 * (t2 - t1) / dt)}
     return rec, res, prob, desc
 
 
@@ -223,6 +233,8 @@ def main():
         sys.exit('bench.py: --gpus %d does not match WORLD_SIZE=%d' % (args.gpus, world))
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import torch.distributed as dist
+    from multipoint_amd.dist import bind_rank_to_numa_node
+    cpu_set = bind_rank_to_numa_node(local_rank) if world > 1 else None      # before the first GPU call; silent when not exposed
     if not torch.cuda.is_available():
         sys.exit('bench.py needs an MI355X; torch.cuda.is_available() is False')
     torch.cuda.set_device(local_rank)
@@ -235,7 +247,7 @@ def main():
 
     import multipoint_amd.models as models
     from multipoint_amd.pipeline import PairPipeline
-    from multipoint_amd.dist import gather_pair_metrics, pair_metric_records, shard_pairs
+    from multipoint_amd.dist import gather_pair_metrics, gather_scalar, pair_metric_records, ranks_seen, shard_pairs
     from multipoint_amd.datasets.synthetic_weights import SHIPPED_MODEL_CONFIG, make_weights
 
     cfg = dict(SHIPPED_MODEL_CONFIG)
@@ -280,7 +292,10 @@ def main():
         else:
             out = pipe.run_interleaved(batch, None, flags)
         if args.host_input:
-            consumed[slot].record(torch.cuda.current_stream(device))
+            # the forward runs on the pipeline's own stream: its inputs_consumed event (the caller's stream is ordered behind it too)
+            consumed[slot] = out.inputs_consumed if hasattr(out, 'inputs_consumed') and out.inputs_consumed is not None else consumed[slot]
+            if not hasattr(out, 'inputs_consumed'):
+                consumed[slot].record(torch.cuda.current_stream(device))
         return out
 
     def fence():
@@ -296,17 +311,26 @@ def main():
         pipe.check_converged(device)
     net.profile(True)
     fence()
+    # per-step hipEvents on the caller's stream, which run_interleaved orders behind each step's forward (the post-processing of
+    # step i overlaps the forward of step i+1 by design): the differences are the steady-state step times
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record(torch.cuda.current_stream(device))
+    for i in range(args.steps):
         res = step()
+        marks[i + 1].record(torch.cuda.current_stream(device))
     fence()
     dt = time.perf_counter() - t0
+    step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     prof = net.profile_read()
     net.profile(False)
+    dt_local = dt
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    per_rank_ms = [round(v / args.steps * 1e3, 3) for v in gather_scalar(dt_local, device)]
+    n_ranks_seen = ranks_seen(device) if use_dist else 1
 
     # per-pair metric records, gathered over RCCL (the only collective of the path)
     metrics = None
@@ -329,7 +353,8 @@ def main():
     roof = None
     wino = os.environ.get('MP_NO_WINOGRAD') != '1' and not c5
     # the library's choice for conv2 (api.hip uses_wino43): F(4x4,3x3) unless switched off, fused, or the frame is no multiple of 4
-    f43 = wino and os.environ.get('MP_WINO43', '2') != '0' and H % 4 == 0 and W % 4 == 0
+    f43 = wino and os.environ.get('MP_WINO43', '2') != '0'
+    gen2 = f43 and (os.environ.get('MP_WINO43_GEN') == '2' or H % 4 != 0 or W % 4 != 0)      # conv_wino43b.hip: never fused
     dom = by_name.get('enc.conv1+2') or by_name.get('enc.conv2')
     n_launch = 1
     if dom:
@@ -372,17 +397,16 @@ def main():
             # v_mfma_f32_4x4x1_16b_f32 (512 FLOP) each -> 16 x 10 x 9 = 1440 per item
             items = 2 * P * ((H + 15) // 16) * ((W + 31) // 32)
             issued = (conv2_flop / 4.0 + items * 1440 * 512.0) if fused else flop / 4.0
-            inst = 'conv_wino43_kernel<true,false,8,true,false>' if fused else 'conv_wino43_kernel<true,false,8,false,false>'
+            inst = 'conv_wino43_kernel<true,false,8,true,false>' if fused else ('conv_wino43b_kernel<true,false,8,false>' if gen2 else 'conv_wino43_kernel<true,false,8,false,false>')
             kernel = ('conv_wino43_kernel<true,false,8,true,false> (encoder conv1 -- Cin = 1, produced per unit of 4 channels on the matrix pipe '
                       '(v_mfma_f32_4x4x1_16b_f32) straight into the LDS patch ring -- fused into enc.conv2 64->64 @480x640 by Winograd '
                       'F(4x4,3x3) on v_mfma_f32_16x16x4_f32, weights staged by LDS-DMA, + bias/ReLU/BN + 2x2 max-pool)') if fused else \
                      ('conv_wino43_kernel<true,false,8,false,false> (enc.conv2 64->64 @480x640 by Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32, '
                       'weights and channel-quad-planar input patches staged by LDS-DMA, + bias/ReLU/BN + 2x2 max-pool)')
-        else:
-            issued = (conv2_flop if fused else flop) / 2.25
-            inst = 'conv_wino_kernel<true,false,false,8>'
-            kernel = ('conv_wino_kernel<true,false,false,8> (enc.conv2 64->64 @480x640 by Winograd F(2x2,3x3) on '
-                      'v_mfma_f32_32x32x2_f32, operands staged by LDS-DMA, + bias/ReLU/BN + 2x2 max-pool)')
+        else:                                                   # MP_WINO43=0: no Winograd kernel, as MP_NO_WINOGRAD=1
+            issued = conv2_flop if fused else flop
+            inst = 'conv_mfma_kernel<9,32,true,true,false>' if fused else 'conv_mfma_persist_kernel<9,32,true,false>'
+            kernel = inst + ' (direct convolution)'
         ach = issued / (ms * 1e-3) / 1e12
         alg = flop / (ms * 1e-3) / 1e12
         traffic = pmc_traffic(args.workload, inst)
@@ -398,16 +422,14 @@ def main():
                 'launches_per_step': n_launch, 'ms_per_launch': round(ms, 4),
                 'mfma_flop_issued_per_launch': issued, 'algorithmic_flop_per_launch': flop,
                 'algorithmic_tflops': round(alg, 2),
-                # the MFMA utilisation the F(2x2,3x3) kernel (2.25x fewer FLOPs than direct) would need for this launch time
                 # the fused launch parks the first block's 64-channel output in a per-workgroup scratch and DMAs it back (6 GB each
                 # way at the L2 boundary): the same bytes the two separate launches moved (5.3 + 7.6 GB), now inside one launch
                 'traffic_note': ('L2-boundary bytes: images in, pooled output out, weights from L2 (round 2 moved 14.2 GB: the first block\'s '
                                  'output made a round trip through a global scratch; the un-fused pair of launches 5.3 + 7.6 GB)') if (f43 and fused) else None,
-                'f22_equivalent_frac': round((conv2_flop if fused else flop) / (ms * 1e-3) / 1e12 / 2.25 / peak, 4) if f43 else None,
                 'note': 'achieved/frac = MFMA FLOPs issued by the launch / hipEvent time on the launch stream inside the timed '
                         'region / dense MFMA peak (matrix-pipe utilisation; agrees with SQ_VALU_MFMA_BUSY_CYCLES in profiles/).  '
                         'frac_algorithmic / algorithmic_* use the direct-convolution FLOP count 2*9*Cin*Cout per output pixel'
-                        + (' (conv1 + conv2)' if fused else '') + '; Winograd F(2x2,3x3) issues 2.25x fewer, F(4x4,3x3) 4x fewer.  Timed while '
+                        + (' (conv1 + conv2)' if fused else '') + '; Winograd F(4x4,3x3) issues 4x fewer.  Timed while '
                         'the previous batch\'s NMS/top-k/sampling/matching kernels run on the side stream.'}
     conv_ms = sum(float(np.sum([m for m, _ in v])) / args.steps for k, v in by_name.items())
     conv_flop = sum(float(np.sum([f for _, f in v])) / args.steps for v in by_name.values())
@@ -422,6 +444,8 @@ def main():
                   else 'image-pairs/sec (encoder+heads forward only) @ %dx%d' % (H, W),
         'value': round(value, 2), 'unit': 'image-pairs/s', 'n_gpus': world, 'steps': args.steps,
         'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 3), 'higher_is_better': True,
+        # hipEvent time between the forwards of consecutive steps on rank 0 (the first differences include the pipeline filling up)
+        'step_ms': {'min': round(min(step_ms), 3), 'median': round(float(np.median(step_ms)), 3), 'max': round(max(step_ms), 3)},
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16' if c5 else 'f32', 'data': 'synthetic',
         'config': {'workload': ('BASELINE configs[4] (per-GPU share): %d pairs (=%d images) 1024x1280, fp16 MFMA conv path '
                                 '(fp32 accumulate), box-NMS size 4 + top-k 2000, bilinear desc sampling, mutual-NN match'
@@ -441,6 +465,12 @@ def main():
         'forward_tflops': round(conv_flop / (conv_ms * 1e-3) / 1e12, 2) if conv_ms > 0 else None,
         'layer_ms': layers,
     }
+    if use_dist:
+        # proof in the line that the job was what it says: members the RCCL communicator has (an all-reduce of ones), every rank's
+        # own loop time, the gathered metric rows, the CPUs rank 0 bound itself to (its GPU's NUMA node; null: not exposed)
+        out['ranks'] = {'ranks_seen': n_ranks_seen, 'per_rank_ms_per_step': per_rank_ms,
+                        'gathered_records': int(metrics.shape[0]) if metrics is not None else None,
+                        'rank0_cpu_affinity': ('%d CPUs: %d-%d' % (len(cpu_set), cpu_set[0], cpu_set[-1])) if cpu_set else None}
     if metrics is not None:
         out['pair_metrics'] = {'pairs': int(metrics.shape[0]), 'mean_kp_optical': float(metrics[:, 1].mean()),
                                'mean_kp_thermal': float(metrics[:, 2].mean()),

@@ -21,6 +21,7 @@ class PairResults:
         self.match_idx, self.match_dist, self.match_count = match_idx, match_dist, match_count
         self.H, self.W = H, W
         self.done = None            # event recorded on the stream that produced these tensors
+        self.inputs_consumed = None # event: the forward has read the input images (they may be overwritten after it)
 
     def wait(self):
         """Make the current stream wait for the post-processing stream that produced the results."""
@@ -94,10 +95,13 @@ class PairPipeline:
         return torch.stack((optical, thermal), dim=1).reshape(2 * P, *optical.shape[1:])
 
     def run_interleaved(self, images, valid_mask=None, is_optical=None):
-        """One batch: forward on the caller's stream, then NMS / top-k / sampling / matching on a side
-        stream (`overlap_post=True`): those kernels are small and latency-bound, so they run in the
-        shadow of the NEXT batch's convolutions instead of serialising behind this one.  The returned
-        tensors belong to the side stream: `PairResults.wait()` (or a device synchronise) orders them."""
+        """One batch: the forward on a high-priority stream of the pipeline's own, then NMS / top-k / sampling / matching
+        on a second side stream (`overlap_post=True`): those kernels are small and latency-bound, so they run in the
+        shadow of the NEXT batch's convolutions instead of serialising behind this one.  The returned tensors belong to
+        the side stream: `PairResults.wait()` (or a device synchronise) orders them.  The CALLER's stream is ordered
+        behind the forward (not behind the post-processing): work it enqueues after this call -- overwriting `images` in
+        place, for one -- cannot overtake the forward's reads; `PairResults.inputs_consumed` is the same event for
+        callers that write the inputs from another stream (bench.py --host-input)."""
         dev = images.device
         B, _, H, W = images.shape
         if B % 2:
@@ -119,6 +123,9 @@ class PairPipeline:
                 fwd.wait_stream(main)                               # is still pending there (nothing, in a steady pipeline: no packet)
             with torch.cuda.stream(fwd):
                 out = self.net({'image': images, 'is_optical': is_optical})
+                consumed = torch.cuda.Event()
+                consumed.record(fwd)
+            main.wait_event(consumed)                               # the caller's stream stays ordered behind the forward
             for t in (images, valid_mask, is_optical if is_optical.is_cuda else None):
                 if t is not None:
                     t.record_stream(fwd)
@@ -129,10 +136,13 @@ class PairPipeline:
         else:
             out = self.net({'image': images, 'is_optical': is_optical})
             post = main
+            consumed = torch.cuda.Event()
+            consumed.record(main)
         with torch.cuda.stream(post):
             res = self._post(out, valid_mask, dev, B, H, W)
             res.done = torch.cuda.Event()
             res.done.record(post)
+        res.inputs_consumed = consumed
         self._last = res
         return res
 
@@ -191,9 +201,9 @@ class PairPipeline:
             is_optical = (torch.arange(B) % 2 == 0).reshape(B, 1)
         out = self.net({'image': images, 'is_optical': is_optical})
         res = self._post(out, valid_mask, dev, B, H, W)
-        for _ in range(4):
-            # both conditions are re-evaluated after EVERY pass: the exact NMS of a redone pass can keep more keypoints than
-            # the asynchronous rounds left, i.e. overflow lists that fitted before
+        for attempt in range(5):
+            # both conditions are evaluated after EVERY pass, the last one included (check first, at most four redone passes): the
+            # exact NMS of a redone pass can keep more keypoints than the asynchronous rounds left, i.e. overflow lists that fitted
             redo_nms = self.nms > 0 and U.nms_unresolved(dev)
             K = res.kp_yx.shape[1]
             # (no device-to-host read of the counts when top-k bounds them by the capacity anyway)
@@ -201,12 +211,12 @@ class PairPipeline:
             overflow = need > K
             if not (redo_nms or overflow):
                 break
+            if attempt == 4:
+                raise RuntimeError('run_converged: keypoint lists / NMS did not settle after 4 redone passes (capacity %d)' % K)
             # lists that overflowed their capacity (topk == 0: the reference keeps EVERY keypoint, utils.py:109-116) are
             # rebuilt with the exact size -- dropping the row-major tail would silently change nn_map / m_score
             res = self._post(out, valid_mask, dev, B, H, W, nms_rounds=0 if redo_nms else None,
                              capacity=((need + 255) // 256) * 256 if overflow else K)
-        else:
-            raise RuntimeError('run_converged: keypoint lists / NMS did not settle after 4 passes (capacity %d)' % res.kp_yx.shape[1])
         self._last = res
         return res
 

@@ -372,8 +372,13 @@ def nms_greedy_py(boxes, scores, iou):
     return np.asarray(keep, dtype=np.int64)
 
 
-def box_nms(prob, size, min_prob, iou=0.1, keep_top_k=0, use_c=True):
+def box_nms(prob, size, min_prob, iou=0.1, keep_top_k=0, use_c=True, dispatch='single'):
     """utils.py:78-122.  prob: numpy (H,W) or (B,1,H,W) fp32.  Returns the dense NMS'ed map.
+
+    dispatch (4-D input only; the RESULT does not depend on it, the run time does): 'single' = one greedy pass over the
+    coordinate-offset concatenation of all images, whatever its size; 'torchvision' = what torchvision.ops.batched_nms does on the
+    CPU: that single call up to 4000 box coordinates (boxes.numel()), above it one nms call per image (_batched_nms_vanilla) and the
+    kept indices ordered by score.  bench.py's cpu_baseline times the second: it is the reference's path.
 
     :97  points = (prob > min_prob).nonzero()                 (row-major)
     :101 boxes = cat(points[:,2:] - size*0.5, points[:,2:] + size*0.5)   (fp32)
@@ -395,9 +400,17 @@ def box_nms(prob, size, min_prob, iou=0.1, keep_top_k=0, use_c=True):
         yx = pts[:, 2:].astype(np.float32)
         boxes = np.concatenate([yx - half, yx + half], axis=1)
         idxs = pts[:, 0]
-        max_coordinate = boxes.max()
-        offsets = idxs.astype(np.float32) * (max_coordinate + np.float32(1))
-        keep = fn(boxes + offsets[:, None], scores, iou)
+        if dispatch == 'torchvision' and boxes.size > 4000:
+            parts = []
+            for b in np.unique(idxs):                               # images never interact: per-image greedy passes
+                sel = np.nonzero(idxs == b)[0]
+                parts.append(sel[fn(boxes[sel], scores[sel], iou)])
+            keep = np.sort(np.concatenate(parts))
+            keep = keep[np.argsort(-scores[keep], kind='stable')]   # descending score, ascending index on ties (the stated rule)
+        else:
+            max_coordinate = boxes.max()
+            offsets = idxs.astype(np.float32) * (max_coordinate + np.float32(1))
+            keep = fn(boxes + offsets[:, None], scores, iou)
         if keep_top_k > 0:
             sel = [keep[idxs[keep] == b][:keep_top_k] for b in range(prob.shape[0])]
             keep = np.concatenate(sel) if sel else keep

@@ -84,3 +84,45 @@ def test_shard_pairs_partition():
         assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
     x = torch.arange(6).reshape(3, 2)
     assert torch.equal(gather_pair_metrics(x), x)            # no process group: identity
+
+
+def _worker_rank_program(rank, world, port, n_pairs, out_dir):
+    """The collective part of bench.py's rank program (max step time, per-rank times, the count of ranks the communicator has,
+    the metric gather) over gloo."""
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from multipoint_amd.dist import (bind_rank_to_numa_node, gather_pair_metrics, gather_scalar, pair_metric_records,
+                                     ranks_seen, shard_pairs)
+    bound = bind_rank_to_numa_node(rank)                    # no GPU topology in the CPU container: silently None
+    mine = shard_pairs(n_pairs, rank, world)
+    dt = 0.010 * (rank + 1)                                 # this rank's loop time
+    t = torch.tensor([dt], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    rec = gather_pair_metrics(pair_metric_records(_results_for(mine), mine)) if mine else \
+        gather_pair_metrics(torch.zeros((0, 4), dtype=torch.int32))
+    torch.save({'max': float(t.item()), 'per_rank': gather_scalar(dt, 'cpu'), 'seen': ranks_seen('cpu'), 'rec': rec,
+                'bound': bound}, os.path.join(out_dir, 'rank%d.pt' % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_rank_program_world4_ragged(tmp_path):
+    """World size 4 with ragged shards (6 pairs: ranks 0, 1 own two, ranks 2, 3 one): every rank ends up with the same
+    gathered rows = the single-rank rows, the max over the ranks' times, all four per-rank times and a rank count of 4."""
+    from multipoint_amd.dist import pair_metric_records
+    n_pairs, world = 6, 4
+    mp.spawn(_worker_rank_program, args=(world, _free_port(), n_pairs, str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(tmp_path / ('rank%d.pt' % r), weights_only=False) for r in range(world)]
+    single = pair_metric_records(_results_for(list(range(n_pairs))), list(range(n_pairs)))
+    for o in outs:
+        assert o['seen'] == world and abs(o['max'] - 0.040) < 1e-12
+        assert [round(v, 6) for v in o['per_rank']] == [0.01, 0.02, 0.03, 0.04]
+        assert torch.equal(o['rec'], outs[0]['rec']) and o['rec'].shape == (n_pairs, 4)
+        assert torch.equal(o['rec'][torch.argsort(o['rec'][:, 0])], single)
+        assert o['bound'] is None or len(o['bound']) > 0
+
+
+def test_rank_helpers_without_a_process_group():
+    from multipoint_amd.dist import gather_scalar, hw_queues_note, ranks_seen
+    assert ranks_seen('cpu') == 1 and gather_scalar(1.5, 'cpu') == [1.5]
+    assert hw_queues_note()['GPU_MAX_HW_QUEUES'] is not None      # importing multipoint_amd.dist sets the deployment default

@@ -36,6 +36,29 @@ def test_bench_rank_program_under_torchrun_rccl():
     assert d['pair_metrics']['pairs'] == 4                       # the gathered records: one row per pair of the job
     assert d['roofline']['frac'] > 0 and d['roofline']['frac_algorithmic'] > 0
     assert d['cpu_baseline'] is None
+    # the job is what the line says: RCCL saw one rank, its own loop time is the job's, every pair's record arrived
+    assert d['ranks']['ranks_seen'] == 1 and d['ranks']['gathered_records'] == 4
+    assert len(d['ranks']['per_rank_ms_per_step']) == 1 and abs(d['ranks']['per_rank_ms_per_step'][0] - d['ms_per_step']) <= 0.01 * d['ms_per_step']
+    assert d['step_ms']['min'] <= d['step_ms']['median'] <= d['step_ms']['max']
+
+
+def test_value_under_torchrun_equals_the_plain_line():
+    """N = 1 under torchrun (RCCL initialised, barrier + all-reduce around the timed loop) must report the same rate as the plain
+    N = 1 run within the run-to-run noise: the distributed plumbing costs the timed region nothing."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    common = ['--gpus', '1', '--steps', '12', '--warmup', '4', '--pairs-per-gpu', '16', '--no-cpu-baseline']
+    plain = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + common, env=env, capture_output=True, text=True,
+                           timeout=600, cwd=ROOT)
+    assert plain.returncode == 0, plain.stderr[-2000:]
+    tr = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr',
+                         '127.0.0.1', '--master-port', '29534', os.path.join(ROOT, 'bench.py')] + common, env=env,
+                        capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert tr.returncode == 0, tr.stderr[-2000:]
+    a = json.loads([l for l in plain.stdout.splitlines() if l.startswith('{')][-1])
+    b = json.loads([l for l in tr.stdout.splitlines() if l.startswith('{')][-1])
+    assert 'ranks' not in a and b['ranks']['ranks_seen'] == 1
+    assert abs(a['value'] - b['value']) <= 0.06 * a['value'], (a['value'], b['value'])
 
 
 def test_emulated_world2_equals_single_rank(oracle):

@@ -93,3 +93,21 @@ def test_edge_cases(oracle):
     out = oracle.box_nms(c, 4, 0.015)
     assert out[0, 0] == np.float32(0.3) and out[0, 1] == 0 and (out > 0).sum() > 6
     assert oracle.keypoints_from_map(out, 0.015).dtype == np.int64
+
+
+def test_box_nms_dispatch_does_not_change_the_result():
+    """torchvision.ops.batched_nms loops over the images above 4000 box coordinates and takes ONE coordinate-offset call below:
+    the oracle restates both dispatches (bench.py times the reference's), and they must agree -- images never interact."""
+    import numpy as np
+    from oracle import mp_oracle as O
+    rng = np.random.default_rng(5)
+    prob = rng.random((3, 1, 40, 56), dtype=np.float32)
+    prob[prob < 0.6] = 0.0
+    prob[1, 0, 10:14, 10:14] = 0.9                          # exact ties
+    assert (prob > 0.015).sum() * 4 > 4000                  # the per-image branch is taken
+    for topk in (0, 50):
+        a = O.box_nms(prob, 4, 0.015, keep_top_k=topk)
+        b = O.box_nms(prob, 4, 0.015, keep_top_k=topk, dispatch='torchvision')
+        assert np.array_equal(a, b)
+    small = np.zeros((2, 1, 16, 16), dtype=np.float32); small[0, 0, 3, 3] = 0.5; small[1, 0, 8, 9] = 0.7
+    assert np.array_equal(O.box_nms(small, 4, 0.015), O.box_nms(small, 4, 0.015, dispatch='torchvision'))
