@@ -45,7 +45,7 @@ typedef struct mp_model_config {
     int final_batchnorm;
     int reflection_pad;         /* 1: ReflectionPad2d(1), 0: ZeroPad2d(1)  (MultiPoint.py:33-36) */
     int bn_first;               /* MultiPoint.py:137-141 */
-    int double_convolution;     /* 1: two 3x3 convolutions per stage; 0: one (MultiPoint.py:144-148; fp32 path only) */
+    int double_convolution;     /* 1: two 3x3 convolutions per stage; 0: one (MultiPoint.py:144-148) */
     int channel_version;        /* 0: [1,64,64,128,128], heads 256; 1: [1,32,64,96,128]; 2: [1,8,16,32,64] (heads = descriptor_size) */
     /* model.type 'SuperPointMagicLeap' (multipoint/models/SuperPointMagicLeap.py): same layer shapes, no
      * BatchNorm, zero padding, state_dict keys conv1a..conv4b / convPa,convPb / convDa,convDb, heat map =

@@ -297,9 +297,9 @@ void pack_wino43_weights(const std::vector<const float*>& srcs, const std::vecto
 // fp16 flavour for conv_f16_kernel: chunks of 64 input channels, steps of 16:
 //   [slice][chunk][step = tap*4 + kgroup][nblock(2)][lane(64)][8]
 //   element e of lane l = half(W[cout = slice*64 + nblock*32 + (l&31)][cin = chunk*64 + kgroup*16 + (l>>5)*8 + e][tap])
-void pack_conv_weights_h(const std::vector<const float*>& srcs, const std::vector<int>& couts, int cin,
+void pack_conv_weights_h(const std::vector<const float*>& srcs, const std::vector<int>& couts, int cin, int cin_real,
                          int taps, std::vector<uint16_t>& out)
-{
+{      // cin_real < cin: the input tensor carries zero padding channels (channel_version 1 / 2): their weights stay zero
     int cout = 0;
     for (int c : couts) cout += c;
     const int nslices = (cout + 63) / 64, nchunks = cin / 64;
@@ -315,10 +315,10 @@ void pack_conv_weights_h(const std::vector<const float*>& srcs, const std::vecto
                             for (int e = 0; e < 8; ++e, ++o) {
                                 int co = s * 64 + nb * 32 + (l & 31);
                                 const int ci = c * 64 + g * 16 + (l >> 5) * 8 + e;
-                                if (co >= cout) continue;
+                                if (co >= cout || ci >= cin_real) continue;
                                 size_t t = 0;
                                 while (co >= couts[t]) { co -= couts[t]; ++t; }
-                                out[o] = f2h_bits(srcs[t][((size_t)co * cin + ci) * taps + tap]);
+                                out[o] = f2h_bits(srcs[t][((size_t)co * cin_real + ci) * taps + tap]);
                             }
 }
 
@@ -354,7 +354,8 @@ int build_conv(mp_handle* h, TensorMap& tm, ConvLayer& L, const char* name,
     }
     std::vector<float> packed;
     pack_conv_weights(srcs, couts, cin, cin_real, taps, packed);
-    L.name = name; L.cin = cin; L.cout = pad_cout ? ((cout + 31) / 32) * 32 : cout; L.taps = taps; L.nslices = padded / 64;
+    const int pm = h->cfg.mixed_precision ? 64 : 32;           // channel padding granule: the fp16 kernels walk K in chunks of 64
+    L.name = name; L.cin = cin; L.cout = pad_cout ? ((cout + pm - 1) / pm) * pm : cout; L.taps = taps; L.nslices = padded / 64;
     L.pool = pool; L.relu = relu;
     int rc;
     if ((rc = upload(h, packed, &L.wpack))) return rc;
@@ -368,7 +369,7 @@ int build_conv(mp_handle* h, TensorMap& tm, ConvLayer& L, const char* name,
     }
     if (h->cfg.mixed_precision) {
         std::vector<uint16_t> ph;
-        pack_conv_weights_h(srcs, couts, cin, taps, ph);
+        pack_conv_weights_h(srcs, couts, cin, cin_real, taps, ph);
         void* d = nullptr;
         MP_HIP(hipMalloc(&d, ph.size() * 2));
         h->weight_allocs.push_back(d);
@@ -401,7 +402,9 @@ int build_encoder(mp_handle* h, TensorMap& tm, Encoder& E, const std::string& pr
     const int chan2[9] = {1, sc[1], sc[1], sc[2], sc[2], sc[3], sc[3], sc[4], sc[4]};
     const int chan1[9] = {1, sc[1], sc[2], sc[3], sc[4], 0, 0, 0, 0};
     const int* chan = dbl ? chan2 : chan1;
-    auto pad32 = [](int c) { return ((c + 31) / 32) * 32; };
+    // tensors carry zero padding channels up to a multiple of 32 (fp32 kernels) or 64 (fp16 kernels: their K chunk)
+    const int pgran = h->cfg.mixed_precision ? 64 : 32;
+    auto pad32 = [pgran](int c) { return ((c + pgran - 1) / pgran) * pgran; };
     static const bool pool2[8] = {false, true, false, true, false, true, false, false};
     static const bool pool1[8] = {true, true, true, false, false, false, false, false};
     const bool* pool = dbl ? pool2 : pool1;
@@ -627,7 +630,9 @@ int forward_f16(mp_handle* h, const float* images, int B, int H, int W, int nset
     const int Hc = H / 8, Wc = W / 8;
     const long long npx = (long long)B * Hc * Wc;
     const int D = h->cfg.descriptor_size;
-    const int headc = h->cfg.descriptor_head ? 512 : 256;
+    const int hc = h->head_channels;                                 // 256 (channel_version 0) or descriptor_size
+    const int headc = h->cfg.descriptor_head ? 2 * hc : hc;
+    const int encc = h->heads3.cin;                                  // encoder output channels incl. padding: 128 (64 for channel_version 2)
     // same carve-up as the fp32 path (sizes in elements), element type fp16
     const size_t nP = (size_t)B * H * W * 64, nQ = (size_t)B * H * W * 16;
     const size_t nL = (size_t)npx * 128, nD = (size_t)npx * 128, nR = (size_t)npx * 256;
@@ -644,29 +649,30 @@ int forward_f16(mp_handle* h, const float* images, int B, int H, int W, int nset
         if (nb == 0) continue;
         const Encoder& E = h->enc[e];
         // the first block inside the conv2 launch (conv_f16_res.hip F1): reflection padding, the LDS-resident-weights kernel
-        const bool fuse1 = h->f16_res && h->f16_fuse1 && h->cfg.reflection_pad && E.conv[0].pool && E.conv[0].cin == 64 &&
-                           E.conv[0].cout == 64 && E.conv[0].nslices == 1;
+        const bool fuse1 = h->f16_res && h->f16_fuse1 && h->cfg.reflection_pad && !E.first_pool && E.conv[0].pool &&
+                           E.conv[0].cin == 64 && E.conv[0].cout == 64 && E.conv[0].nslices == 1;
         if (!fuse1) {
             Conv1ParamsH c1{};
             c1.in = images; c1.out = P; c1.w = E.first.w_h; c1.bias = E.first.bias_h; c1.scale = E.first.scale;
             c1.shift = E.first.shift; c1.img_list = lptr[e]; c1.B = nb; c1.H = H; c1.W = W;
             c1.pad_zero = h->cfg.reflection_pad ? 0 : 1; c1.bn_first = h->cfg.bn_first;
+            c1.pool = E.first_pool ? 1 : 0;                          // double_convolution: false -- MaxPool2d follows the block directly
             prof_begin(h, "enc.conv1", 2.0 * 9 * 64 * (double)nb * H * W, s);
             launch_conv_first_f16(c1, s);
             prof_end(h, s);
         }
-        int hh = H, ww = W;
+        int hh = E.first_pool ? H / 2 : H, ww = E.first_pool ? W / 2 : W;
         _Float16* src = P;
         _Float16* dst = Q;
-        for (int i = 0; i < 7; ++i) {
+        for (int i = 0; i < E.nconv; ++i) {
             const ConvLayer& L = E.conv[i];
-            if ((rc = run_conv_h(h, L, src, L.cin, 0, i == 6 ? X : dst, L.cout, 0, nb, hh, ww, lptr[e], s,
+            if ((rc = run_conv_h(h, L, src, L.cin, 0, i == E.nconv - 1 ? X : dst, L.cout, 0, nb, hh, ww, lptr[e], s,
                                  (i == 0 && fuse1) ? &E.first : nullptr, images))) return rc;
             if (L.pool) { hh /= 2; ww /= 2; }
             _Float16* t = src; src = dst; dst = t;
         }
     }
-    if ((rc = run_conv_h(h, h->heads3, X, 128, 0, P, headc, 0, B, Hc, Wc, nullptr, s))) return rc;
+    if ((rc = run_conv_h(h, h->heads3, X, encc, 0, P, headc, 0, B, Hc, Wc, nullptr, s))) return rc;
     if ((rc = run_conv_h(h, h->det1, P, headc, 0, Lg, 128, 0, B, Hc, Wc, nullptr, s))) return rc;
     if (prob || logits) {
         prof_begin(h, "det.softmax_shuffle", 0.0, s);
@@ -674,7 +680,7 @@ int forward_f16(mp_handle* h, const float* images, int B, int H, int W, int nset
         prof_end(h, s);
     }
     if (desc) {
-        if ((rc = run_conv_h(h, h->desc1, P, headc, 256, R, D, 0, B, Hc, Wc, nullptr, s))) return rc;
+        if ((rc = run_conv_h(h, h->desc1, P, headc, hc, R, D, 0, B, Hc, Wc, nullptr, s))) return rc;
         prof_begin(h, "desc.l2norm", 0.0, s);
         launch_desc_l2norm_f16(R, desc, npx, D, h->cfg.normalize_descriptors ? 1 : 0, s);
         prof_end(h, s);
@@ -904,13 +910,8 @@ int mp_load_weights(mp_handle* h, const mp_model_config* cfg, const mp_tensor* t
     if (!cfg || (!tensors && n_tensors > 0)) return fail(h, MP_EINVAL, "mp_load_weights: NULL argument");
     if (cfg->channel_version < 0 || cfg->channel_version > 2)
         return fail(h, MP_EINVAL, "unsupported model config: channel_version must be 0, 1 or 2 (MultiPoint.py:38-53)");
-    if (cfg->channel_version != 0 && cfg->mixed_precision)
-        return fail(h, MP_EINVAL, "unsupported model config: the fp16 path (mixed_precision) needs channel_version 0 "
-                                  "(its K chunks are 64 channels wide)");
     if (cfg->channel_version != 0 && cfg->key_layout == 1)
         return fail(h, MP_EINVAL, "unsupported model config: SuperPointMagicLeap has channel_version 0 shapes");
-    if (!cfg->double_convolution && cfg->mixed_precision)
-        return fail(h, MP_EINVAL, "unsupported model config: the fp16 path (mixed_precision) needs double_convolution: true");
     if (!cfg->double_convolution && cfg->key_layout == 1)
         return fail(h, MP_EINVAL, "unsupported model config: SuperPointMagicLeap has two convolutions per stage");
     if (cfg->descriptor_head && cfg->descriptor_size != 64 && cfg->descriptor_size != 128 &&

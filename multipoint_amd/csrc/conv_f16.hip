@@ -550,12 +550,8 @@ __global__ __launch_bounds__(256) void conv_first_f16_kernel(const Conv1ParamsH 
         sft[e] = f32x2{p.shift[c8 + 2 * e], p.shift[c8 + 2 * e + 1]};
     }
     __syncthreads();
-    _Float16* out = p.out + (long long)img * p.H * p.W * 64;
     const int psub = tid >> 3;                    // 32 pixels per pass
-#pragma unroll 2
-    for (int it = 0; it < (FTH * FTW) / 32; ++it) {
-        const int pix = it * 32 + psub;
-        const int py = pix / FTW, px = pix % FTW;
+    auto pixel = [&](int py, int px) __attribute__((always_inline)) -> h8 {
         float x[9];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
@@ -571,6 +567,33 @@ __global__ __launch_bounds__(256) void conv_first_f16_kernel(const Conv1ParamsH 
                                     : act_h2<true, false>(a[0], a[1], bia[e], scl[e], sft[e]);
             o[2 * e] = r[0]; o[2 * e + 1] = r[1];
         }
+        return o;
+    };
+    if (p.pool) {
+        // double_convolution: false -- Conv -> ReLU -> BN -> MaxPool2d(2,2) under autocast: the maximum of four fp16 values (exact)
+        const int Ho = p.H >> 1, Wo = p.W >> 1;
+        _Float16* out = p.out + (long long)img * Ho * Wo * 64;
+        for (int it = 0; it < (FTH * FTW) / 4 / 32; ++it) {
+            const int pix = it * 32 + psub;
+            const int py = pix / (FTW / 2), px = pix % (FTW / 2);
+            const h8 a = pixel(2 * py, 2 * px), b = pixel(2 * py, 2 * px + 1), c = pixel(2 * py + 1, 2 * px), d = pixel(2 * py + 1, 2 * px + 1);
+            h8 o;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const _Float16 m0 = a[i] > b[i] ? a[i] : b[i], m1 = c[i] > d[i] ? c[i] : d[i];
+                o[i] = m0 > m1 ? m0 : m1;
+            }
+            const int oy = (y0 >> 1) + py, ox = (x0 >> 1) + px;
+            if (oy < Ho && ox < Wo) *reinterpret_cast<h8*>(out + ((long long)oy * Wo + ox) * 64 + c8) = o;
+        }
+        return;
+    }
+    _Float16* out = p.out + (long long)img * p.H * p.W * 64;
+#pragma unroll 2
+    for (int it = 0; it < (FTH * FTW) / 32; ++it) {
+        const int pix = it * 32 + psub;
+        const int py = pix / FTW, px = pix % FTW;
+        const h8 o = pixel(py, px);
         const int oy = y0 + py, ox = x0 + px;
         if (oy < p.H && ox < p.W) __builtin_nontemporal_store(o, reinterpret_cast<h8*>(out + ((long long)oy * p.W + ox) * 64 + c8));   // streaming, as conv_first.hip
     }

@@ -151,6 +151,7 @@ struct Conv1ParamsH {
     const int* img_list;
     int B, H, W;
     int pad_zero, bn_first;
+    int pool;             // double_convolution: false (MultiPoint.py:147-148): MaxPool2d(2,2) follows the block -> out [B][H/2][W/2][64]
 };
 int launch_conv_f16(const ConvParamsH& p, int taps, int mbw, bool pool, hipStream_t s);
 // 64 -> 64 3x3 layers with the packed weights resident in LDS (conv_f16_res.hip)

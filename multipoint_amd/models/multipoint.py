@@ -43,10 +43,6 @@ class MultiPoint:
             raise ValueError('channel_version must be 0, 1 or 2 (MultiPoint.py:38-53)')
         if self.config.get('conv_algorithm', 'auto') not in self.CONV_ALGORITHMS:
             raise ValueError('conv_algorithm must be one of %s' % ', '.join(self.CONV_ALGORITHMS))
-        if self.config['channel_version'] != 0 and self.config['mixed_precision']:
-            raise ValueError('mixed_precision (fp16 MFMA path) needs channel_version 0')
-        if not self.config['double_convolution'] and self.config['mixed_precision']:
-            raise ValueError('mixed_precision (fp16 MFMA path) needs double_convolution=True')
         self.training = False
         self.device = None
         self._handle = None

@@ -44,9 +44,10 @@ def unbiased(ps, frac=0.1, sigmas=4.0):
 
 
 def fixture_views(z, out, which):
-    """(got, ref) arrays for logits / prob / desc of fixture case 'a' (full maps) or 'b' (sampled) -- `out` holds full maps."""
-    if which == 'a':
-        return {'logits': (out['logits'], z['a_logits']), 'prob': (out['prob'], z['a_prob']), 'desc': (out['desc'], z['a_desc'])}, 1
+    """(got, ref) arrays for logits / prob / desc of fixture case 'a', 'c', 'd' (full maps) or 'b' (sampled) -- `out` holds full maps."""
+    if which != 'b':
+        w = which
+        return {'logits': (out['logits'], z[w + '_logits']), 'prob': (out['prob'], z[w + '_prob']), 'desc': (out['desc'], z[w + '_desc'])}, 1
     d = np.asarray(out['desc'])
     return {'logits': (np.asarray(out['logits']).ravel()[z['b_logits_idx']], z['b_logits_val']),
             'prob': (np.asarray(out['prob']).ravel()[z['b_prob_idx']], z['b_prob_val']),

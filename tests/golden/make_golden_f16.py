@@ -60,6 +60,18 @@ def main():
     out.update(b_seed=12, b_B=1, b_H=240, b_W=320, b_prob_idx=pi, b_prob_val=p[pi], b_logits_idx=li, b_logits_val=lg[li],
                b_desc_cells=cells, b_desc_val=d.reshape(1, d.shape[1], -1)[0][:, cells],
                b_n_above_thr=int((p > 0.015).sum()))
+    # the other model configs MultiPoint.forward wraps in autocast just the same (MultiPoint.py:99-104 does not look at the
+    # config): c = channel_version 1 ([1,32,64,96,128], heads = descriptor_size), d = channel_version 2 with one convolution per
+    # stage (double_convolution: false) -- full maps at 2 x 64 x 64, the config update as JSON
+    for c, upd, seed in (('c', {'channel_version': 1}, 13), ('d', {'channel_version': 2, 'double_convolution': False}, 14)):
+        cfg_v = dict(cfg); cfg_v.update(upd)
+        sd_v = O.make_weights(0, cfg_v)
+        img = O.make_images(seed, 2, 64, 64)
+        o = ref_forward(cfg_v, sd_v, img)
+        l = ref_forward(cfg_v, sd_v, img, logits=True)
+        out.update({c + '_seed': seed, c + '_B': 2, c + '_H': 64, c + '_W': 64, c + '_cfg': json.dumps(upd),
+                    c + '_prob': o['prob'].float().numpy(), c + '_desc': o['desc'].float().numpy(),
+                    c + '_logits': l['logits'].float().numpy()})
     np.savez_compressed(os.path.join(HERE, 'forward_f16.npz'), weight_seed=0, dtypes=json.dumps(dtypes), **out)
     print(json.dumps(dtypes, indent=0)[:600])
 

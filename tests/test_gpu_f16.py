@@ -69,7 +69,9 @@ def test_f16_logits_are_fp16_values(oracle, f16):
 
 
 @pytest.mark.parametrize('upd', [{'multispectral': True}, {'reflection_pad': False}, {'bn_first': True},
-                                 {'descriptor_size': 256}, {'final_batchnorm': False}])
+                                 {'descriptor_size': 256}, {'final_batchnorm': False}, {'channel_version': 1},
+                                 {'channel_version': 2, 'descriptor_size': 128}, {'double_convolution': False},
+                                 {'channel_version': 1, 'double_convolution': False, 'reflection_pad': False}])
 def test_f16_model_variants(oracle, upd):
     net, sd, cfg = _net(oracle, upd, seed=3)
     B, H, W = 3, 48, 80
@@ -179,7 +181,7 @@ def test_f16_error_distribution_is_unbiased_noise(oracle, f16):
     assert abs(pstats['mean_signed_rel']) <= 0.05 * pstats['mean_abs_rel'], pstats          # observed 3e-3 of it
 
 
-@pytest.mark.parametrize('c', ['a', 'b'])
+@pytest.mark.parametrize('c', ['a', 'b', 'c', 'd'])
 def test_f16_forward_against_reference_autocast_fixture(oracle, golden_dir, f16, c):
     """The HIP fp16 path against the REFERENCE's own mixed_precision outputs (tests/golden/forward_f16.npz: the imported
     reference under torch.autocast('cpu', float16), make_golden_f16.py) -- the same distributional bar that pins the oracle
@@ -189,6 +191,11 @@ def test_f16_forward_against_reference_autocast_fixture(oracle, golden_dir, f16,
     net, sd, cfg = f16
     z = np.load(os.path.join(golden_dir, 'forward_f16.npz'))
     assert int(z['weight_seed']) == 0
+    if c + '_cfg' in z.files:
+        # cases c, d: channel_version 1, and channel_version 2 with one convolution per stage -- MultiPoint.forward wraps ANY config in
+        # autocast (MultiPoint.py:99-104); the fp16 kernels run them on tensors zero-padded to multiples of 64 channels
+        import json
+        net, sd, cfg = _net(oracle, json.loads(str(z[c + '_cfg'])), seed=0)
     img = oracle.make_images(int(z[c + '_seed']), int(z[c + '_B']), int(z[c + '_H']), int(z[c + '_W']))
     net.set_force_return_logits(True)
     try:
@@ -202,7 +209,10 @@ def test_f16_forward_against_reference_autocast_fixture(oracle, golden_dir, f16,
     print('\n[f16 vs reference fixture %s] logits %s\n desc %s\n prob %s' % (c, ls, ds, ps))
     assert ls['median'] <= 0.5 and ls['p999'] <= 4.0 and ls['max'] <= 6.0, ls
     assert ds['median'] <= 0.5 and ds['p999'] <= 4.0 and ds['max'] <= 6.0, ds
-    assert abs(ls['mean_signed']) <= 0.05 * ls['mean_abs'] and abs(ds['mean_signed']) <= 0.05 * ds['mean_abs'], (ls, ds)
+    # (no bias: only meaningful where the two evaluations differ at all -- the shallow channel_version 2 network agrees to a handful of
+    # half-step flips, whose mean says nothing)
+    for st in (ls, ds):
+        assert st['mean_abs'] < 0.05 or abs(st['mean_signed']) <= 0.05 * st['mean_abs'], st
     assert ps['median_abs_rel'] <= 1e-2 and ps['p999_abs_rel'] <= 5e-2, ps
     assert S.unbiased(ps), ps
     assert np.abs(v['prob'][0] - v['prob'][1]).max() <= PROB_TOL_F16

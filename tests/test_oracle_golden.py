@@ -168,13 +168,16 @@ def test_dataset_augmentation_golden(golden_dir):
 
 # ------------------------------------------------------------------ fp16 (mixed_precision) oracle pinned to the reference
 def _f16_case(oracle, z, c):
+    import json
     cfg = dict(oracle.SHIPPED_MODEL_CONFIG); cfg['mixed_precision'] = True
+    if c + '_cfg' in z.files:                    # cases c, d: another model config under autocast
+        cfg.update(json.loads(str(z[c + '_cfg'])))
     sd = oracle.make_weights(int(z['weight_seed']), cfg)
     img = oracle.make_images(int(z[c + '_seed']), int(z[c + '_B']), int(z[c + '_H']), int(z[c + '_W']))
     return cfg, sd, img
 
 
-@pytest.mark.parametrize('c', ['a', 'b'])
+@pytest.mark.parametrize('c', ['a', 'b', 'c', 'd'])
 def test_f16_oracle_against_reference_autocast_fixture(oracle, golden_dir, c):
     """tests/golden/forward_f16.npz = the imported reference with `mixed_precision: true`, run under
     torch.autocast('cpu', float16) in place of torch.cuda.amp.autocast (make_golden_f16.py; MultiPoint.py:99-104).  Two
@@ -192,7 +195,10 @@ def test_f16_oracle_against_reference_autocast_fixture(oracle, golden_dir, c):
     ls, ds, ps = S.logits_stats(*v['logits']), S.desc_stats(*v['desc'], channel_axis=ax), S.prob_rel_stats(*v['prob'])
     assert ls['median'] <= 0.5 and ls['p999'] <= 4.0 and ls['max'] <= 6.0, ls
     assert ds['median'] <= 0.5 and ds['p999'] <= 4.0 and ds['max'] <= 6.0, ds
-    assert abs(ls['mean_signed']) <= 0.05 * ls['mean_abs'] and abs(ds['mean_signed']) <= 0.05 * ds['mean_abs'], (ls, ds)
+    # (no bias: only meaningful where the two evaluations differ at all -- the shallow channel_version 2 network agrees to a handful of
+    # half-step flips, whose mean says nothing)
+    for st in (ls, ds):
+        assert st['mean_abs'] < 0.05 or abs(st['mean_signed']) <= 0.05 * st['mean_abs'], st
     assert ps['median_abs_rel'] <= 1e-2 and ps['p999_abs_rel'] <= 5e-2, ps
     assert S.unbiased(ps), ps
     if c == 'b':
