@@ -202,6 +202,32 @@ def parity_block(res, net, images, flags, cres, prob_cpu, desc_cpu, PRED, H, W):
     return par
 
 
+def parity_structured(PRED, H, W, device, n_pairs=4):
+    """Second parity leg: STRUCTURED images (piecewise-constant polygons, ramps, saturated regions, texture) through weights with
+    the statistics of a trained network (oracle/trained_like.py, severity 'wide'), at the headline shape -- where exact ties of the
+    heat map exist and a Winograd convolution may resolve them differently than the reference.  Per convolution algorithm
+    (model.conv_algorithm): keypoints compared with the CPU oracle's, every differing one accounted for."""
+    from oracle import mp_oracle as O
+    from oracle import trained_like as T
+    from oracle import flip_accounting as FA
+    import multipoint_amd.models as models
+    cfg = dict(O.SHIPPED_MODEL_CONFIG)
+    sd = T.trained_like_weights(1, cfg, **T.SEVERITIES['wide'])
+    img = T.structured_images(4, 2 * n_pairs, H, W)
+    prob_cpu = O.forward(sd, img, cfg)['prob'].numpy()
+    nms_fn = lambda m: O.box_nms(m, PRED['nms'], PRED['detection_threshold'], keep_top_k=0)
+    rec = {'pairs': n_pairs, 'images': 'oracle/trained_like.py structured_images(4, %d, %d, %d), weights trained_like_weights(1, wide)' % (2 * n_pairs, H, W)}
+    for algo in ('auto', 'direct'):
+        c = dict(cfg); c['conv_algorithm'] = algo
+        net = models.MultiPoint(c); net.load_state_dict(sd); net.to(device); net.eval()
+        prob_gpu = net({'image': img.to(device)})['prob'].cpu().numpy()
+        s, _ = FA.account_batch(prob_cpu, prob_gpu, nms_fn, PRED['nms'], PRED['detection_threshold'], 0.1, PRED['topk'])
+        rec[algo] = {'keypoints_total': s['keypoints_total'], 'keypoints_differing': s['keypoints_differing'],
+                     'explained': s['keypoints_differing'] - s['unexplained'], 'unexplained': s['unexplained'],
+                     'max_unexplained_margin': s['max_unexplained_margin'], 'max_prob_abs_err': s['max_prob_err']}
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -480,6 +506,8 @@ def main():
         out['cpu_baseline'] = cb
         if not args.forward_only:
             out['parity'] = parity_block(res, net, images, flags, cres, prob_cpu, desc_cpu, PRED, H, W)
+            if not c5:
+                out['parity']['structured'] = parity_structured(PRED, H, W, device)
     else:
         out['cpu_baseline'] = None
     print(json.dumps(out), flush=True)

@@ -59,7 +59,8 @@ typedef struct mp_model_config {
     int mixed_precision;
     /* Algorithm of the 3x3 convolutions (no reference counterpart: ATen picks its own).  0 auto (= 1), 1 winograd43: Winograd
      * F(4x4,3x3) on the fp32 MFMA -- the fastest; equal to the fp32 reference within 2e-5 (prob) / 2e-6 (desc), which can reorder
-     * EXACT ties of the heat map (flat or saturated image regions: up to 5 % of the keypoints of a piecewise-constant image); 2
+     * EXACT ties of the heat map (flat or saturated image regions; a top-k cut inside a plateau of tied scores picks other members of
+     * the plateau: parity.structured of bench.py); 2
      * winograd43_general: the same arithmetic on the any-frame-size kernel only; 3 direct: implicit-GEMM convolution, a k-ordered
      * fp32 multiply-add chain per output like the reference's -- keeps exact ties, 2.4x slower.  INTEGRATION.md has the numbers. */
     int conv_algorithm;

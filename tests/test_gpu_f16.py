@@ -83,13 +83,15 @@ def test_f16_model_variants(oracle, upd):
     assert (out['desc'].cpu() - ref['desc']).abs().max().item() <= DESC_TOL_F16
 
 
-def test_f16_full_path_config5_shape(oracle, f16):
-    """BASELINE configs[4] shape on one GPU's share: pairs of 1024x1280 images, top-k 2000, whole path."""
+@pytest.mark.parametrize('P', [2, 8])
+def test_f16_full_path_config5_shape(oracle, f16, P):
+    """BASELINE configs[4] shape: pairs of 1024x1280 images, top-k 2000, whole path.  P = 8 is the real per-GPU share of the
+    configuration (64 pairs over 8 GPUs): one interleaved batch of 16 images through the fp16 kernels and the pipeline."""
     import multipoint_amd.utils as U
     from multipoint_amd.pipeline import PairPipeline
     from multipoint_amd.datasets import SyntheticPairs
     net, sd, cfg = f16
-    P, H, W, K = 2, 1024, 1280, 2000
+    H, W, K = 1024, 1280, 2000
     imgs = np.empty((2 * P, 1, H, W), dtype=np.float32)
     for p in range(P):
         imgs[2 * p], imgs[2 * p + 1] = SyntheticPairs.make_pair(0, p, H, W)
