@@ -979,10 +979,9 @@ int mp_load_weights(mp_handle* h, const mp_model_config* cfg, const mp_tensor* t
     return MP_OK;
 }
 
-int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optical, int B, int H, int W,
-               float* prob, float* logits, float* desc, void* stream)
+static int forward_checked(mp_handle* h, const float* images, const unsigned char* is_optical, int B, int H, int W,
+                           float* prob, float* logits, float* desc, void* stream)
 {
-    if (!h) return MP_EINVAL;
     if (!h->loaded) return fail(h, MP_ESTATE, "mp_forward: no weights loaded (call mp_load_weights)");
     if (!images || B <= 0 || H <= 0 || W <= 0) return fail(h, MP_EINVAL, "mp_forward: bad image tensor");
     if ((H % 8) != 0 || (W % 8) != 0)
@@ -1111,6 +1110,17 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
     }
     MP_HIP(hipGetLastError());
     return MP_OK;
+}
+
+int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optical, int B, int H, int W,
+               float* prob, float* logits, float* desc, void* stream)
+{
+    if (!h) return MP_EINVAL;
+    const int rc = forward_checked(h, images, is_optical, B, H, W, prob, logits, desc, stream);
+    // a forward that failed half-way may have left arrival counters of the split launches (single-pair latency path) non-zero: a
+    // later launch on this handle would then never see its last range arrive.  Re-zero them (stream-ordered; the error text stays)
+    if (rc != MP_OK && h->split_ctr) (void)hipMemsetAsync(h->split_ctr, 0, 1024 * 4, static_cast<hipStream_t>(stream));
+    return rc;
 }
 
 int mp_box_nms(mp_handle* h, const float* prob, const unsigned char* valid_mask, int B, int H, int W,

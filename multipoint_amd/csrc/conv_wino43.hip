@@ -750,6 +750,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                                                __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                 }
+                // Hand-off protocol (MI355X_MICROARCH.md, "valid forms": sc1 payload -> asm vmcnt(0) -> sc1 flag, sc1 loads on the
+                // consumer side): the shares are write-through (sc1) stores, the explicit vmcnt(0) below waits for their
+                // acknowledgement from the fabric, the barrier for every wave's, and only then does the counter move -- also an
+                // agent-scope atomic, so it cannot overtake them; the finisher reads the shares with sc1 loads, which bypass its
+                // L1.  No release/acquire fence: those write back / invalidate whole caches (1.7-6.5 us per workgroup, measured 40
+                // us with __threadfence), which is the latency this path exists to avoid.  The counters are left at zero by the
+                // finishing workgroup; api.hip re-zeroes them after any launch or forward that failed.
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's shares have been written ...
                 __syncthreads();                                        // ... and every wave's, before the group's count moves
                 if (tid == 0)

@@ -111,8 +111,9 @@ def test_load_state_dict_is_strict(oracle):
     single = dict(cfg); single['double_convolution'] = False
     assert [k for k, _, _ in M.MultiPoint(single).state_dict_spec()] == list(oracle.make_weights(0, single).keys())
     assert 'encoder.16.weight' in oracle.make_weights(0, single) and 'encoder.19.weight' not in oracle.make_weights(0, single)
-    with pytest.raises(ValueError, match='double_convolution'):
-        M.MultiPoint({'double_convolution': False, 'mixed_precision': True})
+    # MultiPoint.forward wraps ANY config in autocast (MultiPoint.py:99-104): mixed_precision is accepted with every model config
+    for upd in ({'double_convolution': False}, {'channel_version': 1}, {'channel_version': 2, 'double_convolution': False}):
+        assert M.MultiPoint(dict(upd, mixed_precision=True)).config['mixed_precision'] is True
     with pytest.raises(ValueError):
         net.set_force_return_logits(1)
     with pytest.raises(NotImplementedError):
@@ -359,12 +360,18 @@ def test_failed_hazard_check_leaves_no_object(tmp_path, monkeypatch):
     assert os.path.exists(b._compile('k.hip'))
 
 
-def test_hardware_queue_default_is_set_by_the_package():
-    """GPU_MAX_HW_QUEUES must be in the environment before the runtime initialises, for every user of the package (not only
-    bench.py): multipoint_amd/__init__.py sets it."""
-    r = subprocess.run([__import__('sys').executable, '-c', 'import os; os.environ.pop("GPU_MAX_HW_QUEUES", None); import multipoint_amd; '
-                        'print(os.environ["GPU_MAX_HW_QUEUES"])'], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), timeout=300)
+def test_hardware_queue_default_is_set_by_the_multi_gpu_module_only():
+    """GPU_MAX_HW_QUEUES must be in the environment before the runtime initialises for every user of the MULTI-GPU path (an RCCL
+    communicator is what makes the default of 4 queues hurt): importing multipoint_amd.dist sets it (an explicit setting wins),
+    importing the package alone leaves the host application's runtime configuration alone."""
+    cwd = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    run = lambda code: subprocess.run([sys.executable, '-c', code], capture_output=True, text=True, cwd=cwd, timeout=300)
+    r = run('import os; os.environ.pop("GPU_MAX_HW_QUEUES", None); import multipoint_amd; print(os.environ.get("GPU_MAX_HW_QUEUES"))')
+    assert r.returncode == 0 and r.stdout.strip() == 'None', r.stderr[-500:]
+    r = run('import os; os.environ.pop("GPU_MAX_HW_QUEUES", None); import multipoint_amd.dist; print(os.environ["GPU_MAX_HW_QUEUES"])')
     assert r.returncode == 0 and r.stdout.strip() == '8', r.stderr[-500:]
+    r = run('import os; os.environ["GPU_MAX_HW_QUEUES"] = "2"; import multipoint_amd.dist; print(os.environ["GPU_MAX_HW_QUEUES"])')
+    assert r.returncode == 0 and r.stdout.strip() == '2', r.stderr[-500:]
 
 
 def test_bench_traffic_figure_only_next_to_the_kernel_it_was_measured_on(tmp_path, monkeypatch):

@@ -114,7 +114,7 @@ summarize('c5_', '_c5', 'conv_f16_res_kernel<32, true, false, 2, true>', 1,
 
 # the bench lines of tools/collect_all.sh (run AFTER the PMC passes were summarised: bench.py reads the traffic figure from the
 # committed profiles/<tag>_pmc_hbm_traffic*.json) -> profiles/<tag>_bench_*.json, and the SQ counter summary of the fp16 convolutions
-for name, out in (('bench_n1', 'bench_n1'), ('bench_c5', 'bench_c5_f16_n1'), ('bench_rccl', 'bench_rccl_world1'), ('bench_f22', 'bench_f22_only_n1'),
+for name, out in (('bench_n1', 'bench_n1'), ('bench_c5', 'bench_c5_f16_n1'), ('bench_rccl', 'bench_rccl_world1'), ('bench_gen2', 'bench_gen2_only_n1'), ('bench_direct', 'bench_direct_n1'),
                   ('bench_c5_stream', 'bench_c5_streaming_kernel_n1')):
     path = os.path.join(src, name + '.json')
     if os.path.exists(path):
@@ -123,5 +123,6 @@ for name, out in (('bench_n1', 'bench_n1'), ('bench_c5', 'bench_c5_f16_n1'), ('b
             json.dump(json.loads(lines[-1]), open(os.path.join(dst, '%s_%s.json' % (tag, out)), 'w'), indent=1)
 if os.path.exists(os.path.join(src, 'latency.txt')):
     shutil.copy(os.path.join(src, 'latency.txt'), os.path.join(dst, tag + '_latency.txt'))
-if os.path.exists(os.path.join(src, 'sq_c5.txt')):
-    shutil.copy(os.path.join(src, 'sq_c5.txt'), os.path.join(dst, tag + '_pmc_sq_counters_c5.txt'))
+for name, out in (('sq_c5.txt', '_pmc_sq_counters_c5.txt'), ('sq_c3.txt', '_pmc_sq_counters_c3.txt'), ('bench_240x320.txt', '_bench_240x320.txt')):
+    if os.path.exists(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, tag + out))
