@@ -98,7 +98,7 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)p; }
 
 // Packed fp32 arithmetic as explicit instructions: hipcc scalarises a third of the transform's packed multiply-adds (4 v_fma_f32
-// for 2 v_pk_fma_f32 per pass), and next to an MFMA stream every vector instruction costs matrix-pipe time (DESIGN.md 3.6).
+// for 2 v_pk_fma_f32 per pass), and next to an MFMA stream every vector instruction costs matrix-pipe time (DESIGN.md A.3).
 // The transform coefficients come in scalar register pairs (VOP3P takes no literal on gfx950).
 // Two coefficients share one scalar register pair (low / high half, picked by op_sel: the selected half feeds both lanes), so the
 // six coefficients of the input transform occupy three pairs instead of six (SGPRs are what the fused-first-block instantiation
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
         bt6(td, tr);                                      // tr[i'] = (B^T d)[i'][column sub6]
         p1_a = p1_base + next_byte; p1_b = p1_base + 4u * PX * 16u + next_byte;
     };
-    // the LDS write path takes two 8-byte stores per MFMA gap for free and saturates beyond (DESIGN.md 3.6): the transform's
+    // the LDS write path takes two 8-byte stores per MFMA gap for free and saturates beyond (DESIGN.md A.3): the transform's
     // stores go out in pairs, one pair per gap
     auto tf_pass1w = [&](int k) __attribute__((always_inline)) {                // rows 2k, 2k+1 of the scratch
         if (MPQX & 1) return;

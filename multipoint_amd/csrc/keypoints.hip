@@ -18,7 +18,7 @@ namespace {
 
 // 256 threads and < 64 VGPRs.  (Sized in round 1 to fit on a CU next to a resident F(2x2,3x3) convolution workgroup; the
 // F(4x4,3x3) workgroups of rounds 2 / 3 own their CU -- 512 threads x 231-256 registers, 158 KiB of LDS -- so these kernels now
-// run at launch boundaries and beside the head tail, DESIGN.md 3.3.)
+// run at launch boundaries and beside the head tail, DESIGN.md 3.7.)
 constexpr int BT = 256;                       // threads per workgroup (4 waves)
 
 __device__ __forceinline__ int wave_incl_scan(int v, int lane)

@@ -102,7 +102,7 @@ void launch_conv_first(const Conv1Params& p, hipStream_t s);
 // convolution.  The same set scaled by 3/4 -- a = 3/4, b = 3/2 -- keeps every transform coefficient an exact binary
 // fraction (a^2 = 9/16, b^2 = 9/4, a^2 b^2 = 81/64, a^2 + b^2 = 45/16), keeps the even/odd structure (12 multiply-adds per
 // 1-D input transform, as before) and cuts the maximum error 3.4x and the rms error 2x (CPU emulation over a grid of dyadic
-// (a, b): the minimum is broad around a b ~ 1, b / a ~ 2; DESIGN.md section 3.8).  Shared by the kernel and the host-side
+// (a, b): the minimum is broad around a b ~ 1, b / a ~ 2; DESIGN.md section 3.2).  Shared by the kernel and the host-side
 // weight transform U = G g G^T (api.hip).
 #ifndef MP_W43_A
 #define MP_W43_A 0.75

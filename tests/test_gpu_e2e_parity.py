@@ -77,7 +77,7 @@ def test_e2e_keypoint_flip_accounting(oracle, monkeypatch, variant, P, root_tol)
     assert summary['unexplained'] == 0 and summary['max_unexplained_margin'] == 0.0, summary
     assert summary['roots_within_measured_noise']
     if variant == 'fp16':
-        # two correct fp16 implementations agree only to the fp16 noise floor (DESIGN 3.5): the lists overlap, they are not
+        # two correct fp16 implementations agree only to the fp16 noise floor (DESIGN.md 3.5): the lists overlap, they are not
         # equal -- observed 62-64 of 8 031 keypoints (0.8 %), every one of them an explained flip; the bound is 3 %
         assert summary['keypoints_differing'] <= 0.03 * summary['keypoints_total'], summary
         assert desc_err <= 4e-3
