@@ -14,7 +14,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int NPIX = 18 * 34, PX = 34;
-constexpr int VB4 = 4 * 32 * 36, UB4 = 4 * 64 * 36, RB4 = 10 * 64 * 4, SW4 = 8 * 36 * 2;
+constexpr int VB4 = 4 * 32 * 36, UB4 = 4 * 64 * 36, RB4 = 11 * 64 * 4, SW4 = 8 * 36 * 2;
 
 __device__ __forceinline__ void dma16(const float* sbase, unsigned voff_bytes, unsigned lds_byte)
 {
@@ -67,10 +67,11 @@ __global__ __launch_bounds__(NW * 64, 1) void unit_probe(const float* __restrict
     constexpr bool DA = (VAR & 128) != 0;
     constexpr int WR = 788;                      // dwords per wave region: 12 * 64 + row skew, and WR / 4 = 1 (mod 4)
     constexpr int VPB = 8 * WR;                  // dwords per V' buffer
-    __shared__ __attribute__((aligned(16))) float smem[(DA ? 2 * VPB : 2 * VB4 + 8 * SW4) + 2 * UB4 + 3 * RB4 + 256];
+    constexpr int SCR = (VAR & 1024) ? 0 : 8 * SW4;       // (the half-window transform has no scratch)
+    __shared__ __attribute__((aligned(16))) float smem[(DA ? 2 * VPB : 2 * VB4 + SCR) + 2 * UB4 + 3 * RB4 + 256];
     float* const Vs = smem;                      // (design A: V')
     float* const scr = smem + 2 * VB4;           // (legacy only)
-    float* const Us = smem + (DA ? 2 * VPB : 2 * VB4 + 8 * SW4);
+    float* const Us = smem + (DA ? 2 * VPB : 2 * VB4 + SCR);
     float* const raw = Us + 2 * UB4;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -308,7 +309,10 @@ __global__ __launch_bounds__(NW * 64, 1) void unit_probe(const float* __restrict
     // transformed window: no hand-over.  Waves 0, 1 take the two halves of unit n+2, waves 2, 3 of unit n+3; the column pass runs in
     // the even unit (42 reads, 36 packed VALU, X = 18 pairs stay in registers), the row pass in the odd unit (36 VALU, 18 ds_write2_b32)
     constexpr bool HW = (VAR & 1024) != 0;
-    const int hw_tile = lane & 31, hw_cp = lane >> 5, hw_half = wave & 1, hw_unit = wave >> 1;
+    // NW = 8 (VAR & 1024): the same half-window tasks on FOUR of the eight waves (waves 0-3, or -- VAR & 32768 -- the even waves);
+    // waves ti = 0, 1 run the column pass in even units, ti = 2, 3 in odd units (staggered: every unit carries both passes)
+    const int hw_ti = NW == 8 ? ((VAR & 32768) ? wave >> 1 : wave & 3) : wave;
+    const int hw_tile = lane & 31, hw_cp = lane >> 5, hw_half = hw_ti & 1, hw_unit = hw_ti >> 1;
     const unsigned hw_rd = raw_lds + (unsigned)((((4 * (hw_tile / 8)) * PX + 4 * (hw_tile % 8)) * 4 + 2 * hw_cp) * 4) + (unsigned)hw_unit * (RB4 * 4u);
     const unsigned hw_rd_cf = raw_lds + (unsigned)lane * 8u + (unsigned)hw_unit * (RB4 * 4u);
     const unsigned hw_sh = hw_half ? (unsigned)PX * 16u : 0u;                     // half B reads e0, e2, e4 one row lower
@@ -324,17 +328,38 @@ __global__ __launch_bounds__(NW * 64, 1) void unit_probe(const float* __restrict
     f32x2 hd[2][7], ho[6];    // a column's 7 inputs (e0, e2, e4, m1..m4), double-buffered; a row's 6 outputs
 #pragma unroll
     for (int i = 0; i < 7; ++i) { hd[0][i] = f32x2{1.f, 2.f}; hd[1][i] = f32x2{1.f, 2.f}; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) ho[i] = f32x2{(float)lane, 3.f};
+    // real layouts (VAR & 65536: half per wave, lane = 2 tile + cp, P = 36; VAR & 131072: half per lane, P = 38)
+    constexpr bool R1 = (VAR & 65536) != 0, R2 = (VAR & 131072) != 0;
+    constexpr int RP = R2 ? 38 : 36;
+    int r_tile, r_cp, r_half;
+    if (R2) { const int l5 = lane & 31; r_cp = l5 & 1; r_half = (l5 >> 1) & 1; r_tile = 16 * (hw_ti & 1) + 4 * (2 * (lane >> 5) + (l5 >> 4)) + ((l5 >> 2) & 3); }
+    else { r_tile = lane >> 1; r_cp = lane & 1; r_half = hw_ti & 1; }
+    const int r_ty = (r_tile >> 2) & 3, r_tx = 4 * (r_tile >> 4) + (r_tile & 3);
+    const unsigned r_rd = raw_lds + (unsigned)(((4 * r_ty) * RP + r_ty + 4 * r_tx) * 16 + 8 * r_cp) + (unsigned)hw_unit * (RB4 * 4u);
+    const unsigned r_sh = r_half ? (unsigned)RP * 16u : 0u;
+    const unsigned r_w0 = lds_addr(Vs) + (unsigned)(hw_unit * VB4 + (2 * r_cp * 32 + r_tile) * 36) * 4u;
+    const unsigned r_wr0 = r_w0 + (r_half ? 5u : 0u) * 24u, r_wr1 = r_w0 + (r_half ? (R2 ? 4u : 3u) : 1u) * 24u, r_wr2 = r_w0 + (r_half ? (R2 ? 3u : 4u) : 2u) * 24u;
     auto hw_read = [&](const int c) __attribute__((always_inline)) {           // column c: rows e0/e2/e4 (shifted for half B) and m1..m4
         if (ELIM & (1 | 16)) return;
+        if (R1 || R2) {
+            const unsigned a = r_rd, b = r_rd + r_sh;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) hd[0][i] = reinterpret_cast<lds_pair_ptr>(b)[2 * (2 * i * RP + ((2 * i) >> 2)) + 2 * c];
+#pragma unroll
+            for (int i = 1; i < 5; ++i) hd[0][2 + i] = reinterpret_cast<lds_pair_ptr>(a)[2 * (i * RP + (i >> 2)) + 2 * c];
+            return;
+        }
         const unsigned a = ((VAR & 2048) ? hw_rd_cf : hw_rd) + (unsigned)c * 16u, b = a + hw_sh;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) hd[c & 1][i] = reinterpret_cast<lds_pair_ptr>(b)[2 * i * PX * 2];
+        for (int i = 0; i < 3; ++i) hd[NW == 8 ? 0 : c & 1][i] = reinterpret_cast<lds_pair_ptr>(b)[2 * i * PX * 2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) hd[c & 1][3 + i] = reinterpret_cast<lds_pair_ptr>(a)[(1 + i) * PX * 2];
+        for (int i = 0; i < 4; ++i) hd[NW == 8 ? 0 : c & 1][3 + i] = reinterpret_cast<lds_pair_ptr>(a)[(1 + i) * PX * 2];
     };
     auto hw_col = [&](const int c) __attribute__((always_inline)) {            // 6 packed multiply-adds: three rows of X of column c
         if (ELIM & (1 | 32)) return;
-        const f32x2* d = hd[c & 1];
+        const f32x2* d = hd[NW == 8 ? 0 : c & 1];
         hx[0][c] = pk_fma_k<0>(d[0], hw_k2, pk_fnma_k<1>(d[1], hw_k2, d[2]));
         const f32x2 t0 = pk_fnma_k<1>(d[4], hw_k1, d[6]), t1 = pk_fnma_k<1>(d[3], hw_k1, d[5]);
         hx[1][c] = pk_fma_k<0>(t1, hw_k3, t0);
@@ -343,7 +368,7 @@ __global__ __launch_bounds__(NW * 64, 1) void unit_probe(const float* __restrict
     auto hw_row = [&](const int k) __attribute__((always_inline)) { if (!(ELIM & (1 | 32))) bt6(hx[k], ho, kc); };
     auto hw_st = [&](const int k, const int jj) __attribute__((always_inline)) {   // V[row][2 jj, 2 jj + 1] of both channels
         if (ELIM & (1 | 256)) return;
-        const unsigned a0 = (VAR & 2048) ? lds_addr(Vs) + (unsigned)lane * 8u + (unsigned)k * 1024u + (unsigned)hw_unit * (VB4 * 4u) : k == 0 ? hw_row0 : k == 1 ? hw_row1 : hw_row2;
+        const unsigned a0 = (VAR & 262144) ? (k == 0 ? r_wr0 : k == 1 ? r_wr1 : r_wr2) : (VAR & 2048) ? lds_addr(Vs) + (unsigned)lane * 8u + (unsigned)k * 1024u + (unsigned)hw_unit * (VB4 * 4u) : k == 0 ? hw_row0 : k == 1 ? hw_row1 : hw_row2;
         if (jj == 0) asm volatile("ds_write2_b32 %0, %1, %2 offset0:0 offset1:1\n\tds_write2_b32 %3, %4, %5 offset0:0 offset1:1"
                                   :: "v"(a0), "v"(ho[0][0]), "v"(ho[1][0]), "v"(a0 + 4608u), "v"(ho[0][1]), "v"(ho[1][1]) : "memory");
         else if (jj == 1) asm volatile("ds_write2_b32 %0, %1, %2 offset0:2 offset1:3\n\tds_write2_b32 %3, %4, %5 offset0:2 offset1:3"
@@ -390,6 +415,16 @@ __global__ __launch_bounds__(NW * 64, 1) void unit_probe(const float* __restrict
                         else if (g == 5 && e == 2) { tf_p2b(0); tf_p2w(0, vb ^ 1, 0); }
                         else if (g == 5 && e == 3) tf_p2w(0, vb ^ 1, 1);
                         else if (g == 6 && e == 1) tf_p2w(0, vb ^ 1, 2);
+                        } else if (duty == 3 || duty == 4) {
+                            if ((vb == 0) == (duty == 3)) {      // column pass: column g read in group g, evaluated in group g + 1
+                                if (g >= 1 && g < 7 && e == 1) hw_col(g - 1);
+                                if (g < 6 && e == 2) hw_read(g);
+                            } else {                             // row pass: row k evaluated in group 2 k, three store pairs behind it
+                                if ((g & 1) == 0 && g < 6 && e == 2) hw_row(g >> 1);
+                                if ((g & 1) == 0 && g < 6 && e == 3) hw_st(g >> 1, 0);
+                                if ((g & 1) == 1 && g < 6 && e == 1) hw_st(g >> 1, 1);
+                                if ((g & 1) == 1 && g < 6 && e == 2) hw_st(g >> 1, 2);
+                            }
                         } else if (duty == 1) {
                         if (g == 0 && e == 2) tf_p1(0, rt_byte);
                         else if (g == 0 && e == 3) tf_p1(TW - 1, rt_byte);
@@ -474,7 +509,13 @@ __global__ __launch_bounds__(NW * 64, 1) void unit_probe(const float* __restrict
             if ((c & 62) == 62) rptr = rsrc + ((long long)(blockIdx.x * 7919 + c) * 2560) % (rsrc_floats - 80 * 2560);
         }
     };
-    if (DUTY) {             // the choice is made ONCE per wave: two instantiations of the whole loop
+    using D3 = std::integral_constant<int, 3>; using D4 = std::integral_constant<int, 4>;
+    if (HW && NW == 8) {    // three instantiations: column pass in even units / in odd units / no transform
+        const bool tw = (VAR & 32768) ? (wave & 1) == 0 : wave < 4;
+        if (!tw) loop(D0{}, D0{});
+        else if (hw_unit == 0) loop(D3{}, D3{});
+        else loop(D4{}, D4{});
+    } else if (DUTY) {      // the choice is made ONCE per wave: two instantiations of the whole loop
         if (wave < 4) loop(D1{}, D0{}); else loop(D0{}, D1{});
     } else {
         loop(D2{}, D2{});
@@ -490,6 +531,7 @@ __global__ __launch_bounds__(NW * 64, 1) void unit_probe(const float* __restrict
 #pragma unroll
         for (int k = 0; k < TW; ++k) sum += tr[k][0][0] + tr[k][5][1];
     }
+    if (HW && NW == 8) sum += hd[0][0][0] + hd[0][6][1];
     if (HW) sum += hx[0][0][0] + hx[2][5][1] + ho[0][0] + ho[5][1];
     if (sum == 123.456f) out[tid] = sum;
     if (tid == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
@@ -528,10 +570,11 @@ int main()
     (void)hipMalloc(&r, rf * 4); (void)hipMemset(r, 0, rf * 4);
     (void)hipMalloc(&out, 1 << 20); (void)hipMalloc(&cyc, 64);
     run<8, 0>("everything", w, r, rf, out, cyc);
-    run<4, 0, 1024 + 2048 + 4096>("HW cf, U DMAs spread", w, r, rf, out, cyc);
-    run<4, 0, 1024 + 2048 + 4096 + 8192>("  + no M0 save/restore", w, r, rf, out, cyc);
-    run<4, 0, 1024 + 2048 + 4096 + 16384>("  + one M0 per run, inst offsets", w, r, rf, out, cyc);
-    run<4, 2, 1024 + 2048 + 4096>("HW cf, no DMA", w, r, rf, out, cyc);
-    run<4, 0, 1024 + 2048 + 16384>("HW cf, bunched DMAs, inst offsets", w, r, rf, out, cyc);
+    run<8, 0, 1024 + 2048>("HW8 stand-in addresses", w, r, rf, out, cyc);
+    run<8, 0, 1024 + 2048 + 65536>("HW8 real reads M1", w, r, rf, out, cyc);
+    run<8, 0, 1024 + 2048 + 131072>("HW8 real reads M2", w, r, rf, out, cyc);
+    run<8, 0, 1024 + 2048 + 65536 + 262144>("HW8 real reads+stores M1", w, r, rf, out, cyc);
+    run<8, 0, 1024 + 2048 + 131072 + 262144>("HW8 real reads+stores M2", w, r, rf, out, cyc);
+    run<8, 0, 1024 + 2048 + 262144>("HW8 real stores M1 only", w, r, rf, out, cyc);
     return 0;
 }
