@@ -552,7 +552,7 @@ int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, 
     int big;
     if (f43) {
         p.wpack = L.u43pack; p.in_planar = in_planar; p.out_planar = out_planar;
-        if (f43 == 1 && !fuse && B <= 2 && h->splitk_max > 1 && h->split_ctr) {
+        if (!fuse && B <= 2 && h->splitk_max > 1 && h->split_ctr) {
             // single-pair latency (the reference's shipped batchsize: 1): a launch with fewer items than half the CUs (conv7 /
             // conv8 of one 480x640 pair: 40 items of 32 units on 256 CUs) cuts the input channels into 2, 4 or 8 ranges --
             // (cin / 4) / ranges units each, even and >= 4 -- as long as the items still fit the machine once.  Only for

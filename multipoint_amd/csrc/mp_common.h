@@ -46,7 +46,7 @@ struct ConvParams {
     // the device = workgroups of a one-per-CU persistent grid, and log2 of its XCD count (workgroup b runs on XCD b mod nxcd;
     // each XCD has its own L2, so a persistent workgroup walks a contiguous share of ITS XCD's items)
     int ncu, xcd_shift;
-    // conv_wino43.hip, small launches (single-pair latency): the input channels of an item are cut into 2^ks_shift ranges that
+    // conv_wino43.hip / conv_wino43b.hip, small launches (single-pair latency): the input channels of an item are cut into 2^ks_shift ranges that
     // run as separate items; their pre-bias output tiles meet in split_scratch and the LAST range to arrive (split_ctr, one
     // counter per group, left at zero) sums them in range order and runs the epilogue.  ks_shift = 0: off.
     int ks_shift;

@@ -78,12 +78,16 @@ def test_forward_kernel_variants(oracle, monkeypatch, env, B, H, W):
     assert (out['desc'].cpu() - ref['desc']).abs().max().item() <= DESC_TOL
 
 
-@pytest.mark.parametrize('B,H,W', [(2, 480, 640), (2, 240, 320), (1, 128, 96), (3, 64, 64)])
-def test_split_input_channels_on_small_launches(oracle, monkeypatch, B, H, W):
+@pytest.mark.parametrize('B,H,W,gen', [(2, 480, 640, ''), (2, 240, 320, ''), (1, 128, 96, ''), (3, 64, 64, ''),
+                                       (1, 88, 120, '2'), (2, 72, 104, '2'), (2, 240, 320, '2')])
+def test_split_input_channels_on_small_launches(oracle, monkeypatch, B, H, W, gen):
     """Single-pair latency path (forwards of one or two images): an F(4x4,3x3) launch with fewer items than half the CUs runs the input channels of an item as
-    2 / 4 / 8 separate items whose pre-bias output tiles the last one to arrive sums in range order (conv_wino43.hip, SPLIT).
+    2 / 4 / 8 separate items whose pre-bias output tiles the last one to arrive sums in range order (conv_wino43.hip and -- gen '2':
+    every layer; default routing: the layers whose frame is no multiple of 4 -- conv_wino43b.hip, SPLIT).
     Against the oracle, against the unsplit launch (MP_SPLITK_MAX=1: another summation order, same tolerance class as any two
     kernel variants), and bit-identical from run to run -- the arrival order must not show."""
+    if gen:
+        monkeypatch.setenv('MP_WINO43_GEN', gen)
     img = oracle.make_images(77 + W, B, H, W)
     net, sd = _net(oracle, oracle.SHIPPED_MODEL_CONFIG, seed=9)
     a = net({'image': img.cuda()})
