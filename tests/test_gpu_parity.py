@@ -425,6 +425,36 @@ def test_pipeline_falls_back_to_converging_nms(oracle, shipped):
         few.check_converged()
 
 
+def test_inputs_may_be_overwritten_after_run_interleaved(oracle, shipped):
+    """The forward of run_interleaved runs on the pipeline's own stream; the caller's stream is ordered behind its reads of the
+    input (PairResults.inputs_consumed is the same event for other streams): overwriting `images` in place right after the call
+    must not change the results."""
+    from multipoint_amd.pipeline import PairPipeline
+    net, _ = shipped
+    pred = {'nms': 4, 'detection_threshold': 0.015, 'topk': 300,
+            'matching': {'method': 'bfmatcher', 'method_kwargs': {'crossCheck': True}, 'knn_matches': False}}
+    pipe = PairPipeline(net, pred, capacity=512)
+    clean = oracle.make_images(31, 8, 240, 320).cuda()
+    ref = pipe.run_interleaved(clean.clone())
+    pipe.check_converged()
+    ref = (ref.kp_count.clone(), ref.kp_yx.clone(), ref.match_count.clone(), ref.match_idx.clone())
+    side = torch.cuda.Stream()
+    for trial in range(4):
+        images = clean.clone()
+        res = pipe.run_interleaved(images)
+        assert res.inputs_consumed is not None
+        if trial % 2 == 0:
+            images.normal_()                                   # caller's stream: ordered behind the forward's reads
+        else:
+            with torch.cuda.stream(side):                      # another stream: waits for the event
+                side.wait_event(res.inputs_consumed)
+                images.zero_()
+        pipe.check_converged()
+        torch.cuda.synchronize()
+        assert torch.equal(res.kp_count, ref[0]) and torch.equal(res.kp_yx, ref[1])
+        assert torch.equal(res.match_count, ref[2]) and torch.equal(res.match_idx, ref[3])
+
+
 # ------------------------------------------------------------------------------- sampling / matching
 def test_interpolate_descriptors(oracle, U, golden_dir):
     g = np.load(os.path.join(golden_dir, 'sampling.npz'))                     # rows from the reference itself
