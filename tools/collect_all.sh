@@ -17,7 +17,7 @@ python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127
 MP_WINO43_GEN=2 python3 bench.py --no-cpu-baseline > "$R/bench_gen2.json" 2> "$R/bench_gen2.err"
 MP_NO_WINOGRAD=1 python3 bench.py --no-cpu-baseline --steps 10 > "$R/bench_direct.json" 2> "$R/bench_direct.err"
 MP_F16_NO_RES=1 python3 bench.py --workload c5 --no-cpu-baseline > "$R/bench_c5_stream.json" 2> "$R/bench_c5_stream.err"
-{ python3 tools/latency.py; MP_SPLITK_MAX=1 python3 tools/latency.py | sed -e 's/^/MP_SPLITK_MAX=1  /'; python3 tools/bench_layers.py 2 480 640; } 2>&1 | grep -v amdgpu.ids > "$R/latency.txt"
+{ python3 tools/latency.py; MP_SPLITK_MAX=1 python3 tools/latency.py | sed -e 's/^/MP_SPLITK_MAX=1  /'; python3 tools/bench_layers.py 2 480 640; echo "== bench_layers 2 240 320"; python3 tools/bench_layers.py 2 240 320; } 2>&1 | grep -v amdgpu.ids > "$R/latency.txt"
 bash tools/pmc_f16.sh "$R/sq_c5" > "$R/sq_c5.txt" 2>&1
 bash tools/pmc_f16.sh "$R/sq_c3" 64 > "$R/sq_c3.txt" 2>&1
 # 240x320 (BASELINE configs[0] frame: the deep layers are 30x40, no multiple of the 4x4 tile): B = 64 throughput and single-pair latency,
