@@ -21,7 +21,7 @@ class ModelConfig(ctypes.Structure):
     _fields_ = [(n, c_int) for n in ('multispectral', 'descriptor_head', 'descriptor_size',
                                      'normalize_descriptors', 'final_batchnorm', 'reflection_pad',
                                      'bn_first', 'double_convolution', 'channel_version', 'batchnorm',
-                                     'key_layout', 'softmax_mode', 'mixed_precision', 'conv_algorithm')]
+                                     'key_layout', 'softmax_mode', 'mixed_precision', 'conv_algorithm', 'batch_invariant')]
 
 
 class Tensor(ctypes.Structure):

@@ -67,6 +67,7 @@ struct mp_handle {
     DevBuf split_ws;                // F(4x4,3x3) split launches: the ranges' pre-bias output tiles
     int* split_ctr = nullptr;       // ... and their arrival counters (1024, zero between launches)
     int splitk_max = 8;             // most ranges the input channels of a small launch are cut into (MP_SPLITK_MAX; 1: never)
+    int splitk_env = 8;             // ... as mp_create set it (model.batch_invariant overrides it per loaded model)
     DevBuf nms_state;               // 64 round counters + tile flags
     DevBuf kp_scratch;              // segment counts + list totals of the keypoint compaction
     int* nms_total = nullptr;       // device: undecided candidates summed over all calls since the last read
@@ -870,6 +871,7 @@ int mp_create(mp_handle** out, int device)
     { const char* e = getenv("MP_PERSIST_MIN_ITEMS"); if (e && atoi(e) > 0) hh->persist = atoi(e); }
     { const char* e = getenv("MP_NO_PERSIST"); if (e && e[0] == '1') hh->persist = 0; }
     { const char* e = getenv("MP_SPLITK_MAX"); if (e && atoi(e) >= 1 && atoi(e) <= 8) hh->splitk_max = atoi(e); }
+    hh->splitk_env = hh->splitk_max;
     if (hipHostMalloc(reinterpret_cast<void**>(&hh->pinned), 4096) != hipSuccess) {
         delete hh;
         return fail(h, MP_ENOMEM, "mp_create: hipHostMalloc failed");
@@ -927,6 +929,7 @@ int mp_load_weights(mp_handle* h, const mp_model_config* cfg, const mp_tensor* t
     if (cfg->conv_algorithm == 1) { h->wino = true; h->wino43 = 2; h->wino43_gen = 0; }
     else if (cfg->conv_algorithm == 2) { h->wino = true; h->wino43 = 2; h->wino43_gen = 2; }
     else if (cfg->conv_algorithm == 3) { h->wino = false; }
+    h->splitk_max = cfg->batch_invariant ? 1 : h->splitk_env;
     TensorMap tm;
     for (int i = 0; i < n_tensors; ++i) {
         if (!tensors[i].name || (!tensors[i].data && tensors[i].numel > 0))

@@ -33,6 +33,9 @@ class MultiPoint:
     # the 3x3 convolutions -- 'auto' | 'winograd43' | 'winograd43_general' | 'direct' (include/multipoint_hip.h:
     # mp_model_config.conv_algorithm)
     CONV_ALGORITHMS = {'auto': 0, 'winograd43': 1, 'winograd43_general': 2, 'direct': 3}
+    # ... and optional key model.batch_invariant (bool, default False): forwards of one or two images skip the split small launches
+    # of the single-pair latency path, so that their bits equal those of the same images inside a larger batch
+    # (mp_model_config.batch_invariant)
 
     def __init__(self, config=None):
         if config:
@@ -196,7 +199,7 @@ class MultiPoint:
                           'final_batchnorm', 'reflection_pad', 'bn_first', 'double_convolution', 'channel_version')]
         vals += [self._abi_extra['batchnorm'], self._abi_extra['key_layout'], self._abi_extra['softmax_mode'],
                  int(bool(c['mixed_precision'])),      # MultiPoint.py:99-103: forward under autocast -> fp16 MFMA path
-                 self.CONV_ALGORITHMS[c.get('conv_algorithm', 'auto')]]
+                 self.CONV_ALGORITHMS[c.get('conv_algorithm', 'auto')], int(bool(c.get('batch_invariant', False)))]
         cfg = _lib.ModelConfig(*vals)
         keep = []
         arr = []

@@ -21,8 +21,9 @@ class SuperPointMagicLeap(MultiPoint):
 
     def __init__(self, config=None):
         fixed = dict(self._fixed)
-        if isinstance(config, dict) and 'conv_algorithm' in config:      # the one multipoint_amd-only setting passes through
-            fixed['conv_algorithm'] = config['conv_algorithm']
+        for k in ('conv_algorithm', 'batch_invariant'):                   # the multipoint_amd-only settings pass through
+            if isinstance(config, dict) and k in config:
+                fixed[k] = config[k]
         super().__init__(fixed)
         self.user_config = config
 

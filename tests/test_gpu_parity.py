@@ -113,6 +113,29 @@ def test_split_input_channels_on_small_launches(oracle, monkeypatch, B, H, W, ge
     assert (a['prob'] - b['prob']).abs().max().item() <= 3e-5 and (a['desc'] - b['desc']).abs().max().item() <= 3e-6
 
 
+@pytest.mark.parametrize('H,W', [(480, 640), (240, 320)])
+def test_batch_invariant_setting(oracle, H, W):
+    """model.batch_invariant (mp_model_config.batch_invariant): forwards of one or two images leave the split small launches out,
+    so a shard of two images has the bits of the same images inside a larger batch; without it they differ (and stay inside
+    the tolerance)."""
+    img = oracle.make_images(5 + H, 6, H, W).cuda()
+    cfg = dict(oracle.SHIPPED_MODEL_CONFIG)
+    fast, _ = _net(oracle, cfg, seed=9)
+    cfg['batch_invariant'] = True
+    inv, _ = _net(oracle, cfg, seed=9)
+    big = inv({'image': img})
+    big_fast = fast({'image': img})
+    assert torch.equal(big['prob'], big_fast['prob']) and torch.equal(big['desc'], big_fast['desc'])      # batched forwards: one path
+    for lo in (0, 2, 4):
+        part = inv({'image': img[lo:lo + 2]})
+        assert torch.equal(part['prob'], big['prob'][lo:lo + 2]) and torch.equal(part['desc'], big['desc'][lo:lo + 2])
+    one = inv({'image': img[3:4]})
+    assert torch.equal(one['prob'], big['prob'][3:4]) and torch.equal(one['desc'], big['desc'][3:4])
+    part = fast({'image': img[0:2]})
+    assert not torch.equal(part['desc'], big['desc'][0:2])
+    assert (part['prob'] - big['prob'][0:2]).abs().max().item() <= 3e-5 and (part['desc'] - big['desc'][0:2]).abs().max().item() <= 3e-6
+
+
 @pytest.mark.parametrize('env', [{}, {'MP_WINO43': '0'}, {'MP_NO_WINOGRAD': '1'}])
 @pytest.mark.parametrize('upd', [{}, {'multispectral': True, 'bn_first': True}, {'reflection_pad': False},
                                  {'channel_version': 1, 'descriptor_size': 128}])

@@ -405,3 +405,9 @@ def test_conv_algorithm_is_a_model_setting():
     with pytest.raises(ValueError):
         M.MultiPoint({'conv_algorithm': 'winograd22'})
     assert M.SuperPointMagicLeap({'conv_algorithm': 'direct'}).config['conv_algorithm'] == 'direct'
+    # model.batch_invariant: the other multipoint_amd-only key, same rules
+    assert 'batch_invariant' not in M.MultiPoint.default_config
+    assert M.MultiPoint({'batch_invariant': True}).config['batch_invariant'] is True
+    assert M.SuperPointMagicLeap({'batch_invariant': True}).config['batch_invariant'] is True
+    from multipoint_amd import _lib
+    assert [n for n, _ in _lib.ModelConfig._fields_][-2:] == ['conv_algorithm', 'batch_invariant']
