@@ -1,5 +1,6 @@
-"""Developer tool (GPU box): random frame sizes / batch sizes / model variants -- the default kernels (F(4x4,3x3) with the fused
-first block) against F(2x2,3x3) (MP_WINO43=0) and the direct kernels (MP_NO_WINOGRAD=1) on the same inputs; `f16` as the first
+"""Developer tool (GPU box): random frame sizes / batch sizes / model variants -- the default routing (conv_wino43.hip with the
+fused first block where it applies, conv_wino43b.hip elsewhere; split launches for B <= 2) against the any-frame kernel alone
+(MP_WINO43_GEN=2) and the direct kernels (MP_NO_WINOGRAD=1) on the same inputs; `f16` as the first
 argument: the mixed_precision path (resident weights + fused first block) against the streaming kernels (MP_F16_NO_RES=1) and
 the fp16 oracle.     python tools/fuzz_shapes.py [f16] [trials] [seed]"""
 import os, sys, random, torch
@@ -19,10 +20,11 @@ for trial in range(NTR):
     if trial % 4 == 1: cfg['multispectral'] = True
     if trial % 4 == 2: cfg['bn_first'] = True
     if trial % 6 == 5 and not F16: cfg['descriptor_size'] = 128
-    H = 8 * random.randint(2, 40); W = 8 * random.randint(2, 60); B = random.randint(1, 5)
+    if trial % 5 == 3 and not F16: cfg['reflection_pad'] = False
+    H = 8 * random.randint(2, 40); W = 8 * random.randint(2, 60); B = random.choice([1, 1, 2, 2, 3, 4, 5])
     img = O.make_images(trial, B, H, W).cuda()
     flags = torch.tensor([[i % 2 == 0] for i in range(B)])
-    os.environ.pop('MP_WINO43', None); os.environ.pop('MP_NO_FUSE43', None)
+    os.environ.pop('MP_WINO43_GEN', None); os.environ.pop('MP_NO_FUSE43', None)
     a = net(cfg, trial)({'image': img, 'is_optical': flags})
     if F16:
         os.environ['MP_F16_NO_RES'] = '1'
@@ -31,15 +33,15 @@ for trial in range(NTR):
         ref = O.forward(O.make_weights(trial, cfg), img.cpu(), cfg, is_optical=flags)
         c = {'prob': ref['prob'].cuda(), 'desc': ref['desc'].cuda()}
     else:
-        os.environ['MP_WINO43'] = '0'
+        os.environ['MP_WINO43_GEN'] = '2'
         b = net(cfg, trial)({'image': img, 'is_optical': flags})
-        os.environ.pop('MP_WINO43')
+        os.environ.pop('MP_WINO43_GEN')
         os.environ['MP_NO_WINOGRAD'] = '1'
         c = net(cfg, trial)({'image': img, 'is_optical': flags})
         os.environ.pop('MP_NO_WINOGRAD')
     dp = max((a['prob'] - b['prob']).abs().max().item(), (a['prob'] - c['prob']).abs().max().item())
     dd = max((a['desc'] - b['desc']).abs().max().item(), (a['desc'] - c['desc']).abs().max().item())
     worst = max(worst, dp, dd)
-    print(trial, B, H, W, {k: cfg[k] for k in ('multispectral', 'bn_first', 'descriptor_size')}, '%.2e %.2e' % (dp, dd), flush=True)
+    print(trial, B, H, W, {k: cfg[k] for k in ('multispectral', 'bn_first', 'descriptor_size', 'reflection_pad')}, '%.2e %.2e' % (dp, dd), flush=True)
     assert (dp < 2e-2 and dd < 4e-3) if F16 else (dp < 1e-4 and dd < 1e-4), 'MISMATCH'
 print('worst', worst)
