@@ -12,7 +12,7 @@ OUT=${1:-gpurun_out/prof}
 mkdir -p "$OUT"
 for WL in c3 c5; do
   if [ $WL = c3 ]; then P=""; ARG=""; LAY="64"; else P="c5_"; ARG="--workload c5"; LAY="16 1024 1280 f16"; fi
-  BENCH="python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline $ARG"
+  BENCH="python3 bench.py --steps 40 --warmup 5 --no-cpu-baseline $ARG"      # (45 launches of each kernel: the first, cold one weighs 2 % in the average)
   SHORT="python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline $ARG"
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o ${P}stats -- $BENCH > "$OUT/${P}stats.log" 2>&1
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT" -o ${P}fetch -- $SHORT > "$OUT/${P}fetch.log" 2>&1
