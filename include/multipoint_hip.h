@@ -66,7 +66,7 @@ typedef struct mp_model_config {
     int conv_algorithm;
     /* 1: a forward's output bits do not depend on how many images it holds.  By default (0) forwards of ONE or TWO images --
      * the reference's shipped batchsize 1 -- run launches that are too small to fill the GPU with their input channels cut into
-     * ranges (single-pair latency: 0.52 instead of 0.56 ms at 480x640), which sums the same products in another order than the
+     * ranges (single-pair latency: 0.51 instead of 0.56 ms at 480x640, 0.33 instead of 0.44 ms at 240x320), which sums the same products in another order than the
      * batched launch does: equal within 3e-5 (prob) / 3e-6 (desc), deterministic from run to run, but not bit-identical to the
      * same images inside a larger batch.  Set it when shards of <= 2 images must reproduce a batched run bit for bit. */
     int batch_invariant;

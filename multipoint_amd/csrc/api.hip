@@ -65,7 +65,6 @@ struct mp_handle {
     DevBuf ws3;                     // matching arg-min arrays
     DevBuf ws4;                     // pair metrics: warped keypoints + inverse match map
     DevBuf split_ws;                // F(4x4,3x3) split launches: the ranges' pre-bias output tiles
-    int* split_ctr = nullptr;       // ... and their arrival counters (1024, zero between launches)
     int splitk_max = 8;             // most ranges the input channels of a small launch are cut into (MP_SPLITK_MAX; 1: never)
     int splitk_env = 8;             // ... as mp_create set it (model.batch_invariant overrides it per loaded model)
     DevBuf nms_state;               // 64 round counters + tile flags
@@ -553,7 +552,7 @@ int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, 
     int big;
     if (f43) {
         p.wpack = L.u43pack; p.in_planar = in_planar; p.out_planar = out_planar;
-        if (!fuse && B <= 2 && h->splitk_max > 1 && h->split_ctr) {
+        if (!fuse && B <= 2 && h->splitk_max > 1) {
             // single-pair latency (the reference's shipped batchsize: 1): a launch with fewer items than half the CUs (conv7 /
             // conv8 of one 480x640 pair: 40 items of 32 units on 256 CUs) cuts the input channels into 2, 4 or 8 ranges --
             // (cin / 4) / ranges units each, even and >= 4 -- as long as the items still fit the machine once.  Only for
@@ -567,7 +566,7 @@ int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, 
             if (ks > 0 && items <= 1024) {
                 int rc = ensure(h, h->split_ws, (size_t)(items << ks) * (2 * 16 * 512 * 8));
                 if (rc) return rc;
-                p.ks_shift = ks; p.split_scratch = static_cast<float*>(h->split_ws.p); p.split_ctr = h->split_ctr;
+                p.ks_shift = ks; p.split_scratch = static_cast<float*>(h->split_ws.p);
             }
         }
         big = f43 == 2 ? launch_conv_wino43b(p, L.pool, s) : launch_conv_wino43(p, L.pool, s, fuse != nullptr);
@@ -876,12 +875,6 @@ int mp_create(mp_handle** out, int device)
         delete hh;
         return fail(h, MP_ENOMEM, "mp_create: hipHostMalloc failed");
     }
-    if (hipMalloc(reinterpret_cast<void**>(&hh->split_ctr), 1024 * 4) != hipSuccess ||
-        hipMemset(hh->split_ctr, 0, 1024 * 4) != hipSuccess) {
-        (void)hipHostFree(hh->pinned);
-        delete hh;
-        return fail(h, MP_ENOMEM, "mp_create: hipMalloc failed");
-    }
     *out = hh;
     return MP_OK;
 }
@@ -896,7 +889,6 @@ void mp_destroy(mp_handle* h)
     if (h->ws3.p) (void)hipFree(h->ws3.p);
     if (h->ws4.p) (void)hipFree(h->ws4.p);
     if (h->split_ws.p) (void)hipFree(h->split_ws.p);
-    if (h->split_ctr) (void)hipFree(h->split_ctr);
     if (h->nms_state.p) (void)hipFree(h->nms_state.p);
     if (h->kp_scratch.p) (void)hipFree(h->kp_scratch.p);
     if (h->nms_total) (void)hipFree(h->nms_total);
@@ -1119,11 +1111,7 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
                float* prob, float* logits, float* desc, void* stream)
 {
     if (!h) return MP_EINVAL;
-    const int rc = forward_checked(h, images, is_optical, B, H, W, prob, logits, desc, stream);
-    // a forward that failed half-way may have left arrival counters of the split launches (single-pair latency path) non-zero: a
-    // later launch on this handle would then never see its last range arrive.  Re-zero them (stream-ordered; the error text stays)
-    if (rc != MP_OK && h->split_ctr) (void)hipMemsetAsync(h->split_ctr, 0, 1024 * 4, static_cast<hipStream_t>(stream));
-    return rc;
+    return forward_checked(h, images, is_optical, B, H, W, prob, logits, desc, stream);
 }
 
 int mp_box_nms(mp_handle* h, const float* prob, const unsigned char* valid_mask, int B, int H, int W,

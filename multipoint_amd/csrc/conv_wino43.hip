@@ -186,7 +186,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     __shared__ __attribute__((aligned(16))) float raw[3 * RB4 + 256];
     __shared__ __attribute__((aligned(16))) float scr[8 * SW4];
     __shared__ __attribute__((aligned(16))) float prm[3 * 64];
-    __shared__ int split_flag;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -720,13 +719,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
             // wait in registers so that every pixel is ONE 16-byte store of the lane's 4 channels
             constexpr int NO = POOL ? 2 : 4;                            // output rows / columns per tile
             f32x2 keep[NO][NO];
-            // SPLIT: this item's share of the sum over input channels leaves as pre-bias output tiles; the last range of the
-            // group to arrive adds the shares up in range order (deterministic) and continues with the ordinary epilogue
-            bool finish = true;
-            const unsigned long long* part0 = nullptr;
+            // SPLIT: this item's share of the sum over input channels leaves as pre-bias output tiles; split_reduce_kernel (conv_split.hip),
+            // the next launch on the stream, adds the ranges' shares up in range order (deterministic) and runs the rest of the epilogue
             if constexpr (SPLIT) {
-                // (agent-scope relaxed atomics = sc1 stores / loads: coherent across the XCDs' L2s by themselves -- a device-wide
-                // fence would write back and invalidate the whole L2 instead: 40 us)
                 unsigned long long* const part = reinterpret_cast<unsigned long long*>(p.split_scratch) + (long long)item * (2 * 16 * 512) + tid;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -746,31 +741,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                         at6(tcol[a], y);
 #pragma unroll
                         for (int b = 0; b < 4; ++b)
-                            __hip_atomic_store(&part[(h * 16 + a * 4 + b) * 512], __builtin_bit_cast(unsigned long long, y[b]),
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            part[(h * 16 + a * 4 + b) * 512] = __builtin_bit_cast(unsigned long long, y[b]);
                     }
                 }
-                // Hand-off protocol (MI355X_MICROARCH.md, "valid forms": sc1 payload -> asm vmcnt(0) -> sc1 flag, sc1 loads on the
-                // consumer side): the shares are write-through (sc1) stores, the explicit vmcnt(0) below waits for their
-                // acknowledgement from the fabric, the barrier for every wave's, and only then does the counter move -- also an
-                // agent-scope atomic, so it cannot overtake them; the finisher reads the shares with sc1 loads, which bypass its
-                // L1.  No release/acquire fence: those write back / invalidate whole caches (1.7-6.5 us per workgroup, measured 40
-                // us with __threadfence), which is the latency this path exists to avoid.  The counters are left at zero by the
-                // finishing workgroup; api.hip re-zeroes them after any launch or forward that failed.
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this wave's shares have been written ...
-                __syncthreads();                                        // ... and every wave's, before the group's count moves
-                if (tid == 0)
-                    split_flag = __hip_atomic_fetch_add(&p.split_ctr[item >> p.ks_shift], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __syncthreads();
-                finish = split_flag == (1 << p.ks_shift) - 1;
-                if (finish) {
-                    if (tid == 0)                                       // ready for the next launch
-                        __hip_atomic_store(&p.split_ctr[item >> p.ks_shift], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    part0 = reinterpret_cast<const unsigned long long*>(p.split_scratch) +
-                            (long long)((item >> p.ks_shift) << p.ks_shift) * (2 * 16 * 512) + tid;
-                }
             }
-            if (finish) {
+            if constexpr (!SPLIT) {
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 f32x2 tcol[4][6];                                       // T[a][j] = sum_i A^T[a][i] M[i][j]
@@ -787,50 +762,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                 }
                 const f32x2 bb = {b4[2 * h], b4[2 * h + 1]}, ss = {s4[2 * h], s4[2 * h + 1]}, tt = {t4[2 * h], t4[2 * h + 1]};
                 f32x2 yv[4][4];                                         // [row a][col b] -> this pair's 2 channels
-                f32x2 ysum[SPLIT ? 4 : 1][4];
-                if constexpr (SPLIT) {
-                    // the shares come from memory (sc1 loads, ~1.5 us a trip): every load of a batch is issued before the first
-                    // value is used -- two rows of up to 4 ranges per batch, of 8 ranges row by row (64 registers)
-                    const int KS = 1 << p.ks_shift;
-                    auto gather = [&](auto ab_tag, auto a0_tag) __attribute__((always_inline)) {
-                        constexpr int AB = decltype(ab_tag)::value, KMAX = AB == 2 ? 4 : 8, a0 = decltype(a0_tag)::value;
-                        unsigned long long rawv[KMAX][AB * 4];
-#pragma unroll
-                        for (int k = 0; k < KMAX; ++k)
-                            if (k < KS) {
-#pragma unroll
-                                for (int i = 0; i < AB * 4; ++i)
-                                    rawv[k][i] = __hip_atomic_load(&part0[(long long)k * (2 * 16 * 512) + (h * 16 + a0 * 4 + i) * 512],
-                                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            }
-#pragma unroll
-                        for (int i = 0; i < AB * 4; ++i) {
-                            f32x2 y = __builtin_bit_cast(f32x2, rawv[0][i]);
-#pragma unroll
-                            for (int k = 1; k < KMAX; ++k)
-                                if (k < KS) y += __builtin_bit_cast(f32x2, rawv[k][i]);        // range order: deterministic
-                            ysum[a0 + i / 4][i % 4] = y;
-                        }
-                    };
-                    if (KS <= 4) {
-                        gather(std::integral_constant<int, 2>{}, std::integral_constant<int, 0>{});
-                        gather(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
-                    } else {
-                        gather(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{});
-                        gather(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
-                        gather(std::integral_constant<int, 1>{}, std::integral_constant<int, 2>{});
-                        gather(std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{});
-                    }
-                }
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     f32x2 y[4];
-                    if constexpr (SPLIT) {
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) y[b] = ysum[a][b];
-                    } else {
-                        at6(tcol[a], y);
-                    }
+                    at6(tcol[a], y);
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
                         f32x2 v = y[b] + bb;
@@ -960,8 +895,9 @@ int launch_conv_wino43(const ConvParams& p, bool pool, hipStream_t s, bool fuse_
     if (fuse_first) return pool && p.cin == 64 ? launch_q<true, 8, true>(p, s) : 2;          // 2: shape not covered
     if (p.ks_shift > 0) {
         const int ncs = (p.cin / 4) >> p.ks_shift;
-        if (ncs < 4 || (ncs & 1) || (ncs << p.ks_shift) * 4 != p.cin || !p.split_scratch || !p.split_ctr) return 2;
-        return pool ? launch_shape<true, true>(p, s) : launch_shape<false, true>(p, s);
+        if (ncs < 4 || (ncs & 1) || (ncs << p.ks_shift) * 4 != p.cin || !p.split_scratch) return 2;
+        const int rc = pool ? launch_shape<true, true>(p, s) : launch_shape<false, true>(p, s);
+        return rc ? rc : launch_split_reduce(p, 1, pool, s);
     }
     return pool ? launch_shape<true>(p, s) : launch_shape<false>(p, s);
 }

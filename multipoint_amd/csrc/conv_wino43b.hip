@@ -162,7 +162,7 @@ __device__ __forceinline__ float acc_read(float a)
 
 // SPLIT (single-pair latency, conv_wino43.hip's protocol): the launcher cut the input channels into 2^ks_shift ranges -- an item is
 // (tile block, virtual slice = slice * ranges + range) and runs the units of its range only; its pre-bias output tiles go to
-// p.split_scratch, and the LAST range of a group to arrive (p.split_ctr) sums the shares in range order and runs the epilogue.
+// p.split_scratch, where split_reduce_kernel (conv_split.hip, the next launch) sums the shares in range order and runs the epilogue.
 template <bool POOL, bool BNF, int TC4, bool ZPAD, bool SPLIT = false>
 __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const ConvParams p)
 {
@@ -198,7 +198,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const ConvParams p
     unsigned* const rvl = reinterpret_cast<unsigned*>(prm + 3 * 64) + wave * 192 + lane;
     const int half = wave & 1;                         // transform: rows {0, 1, 2} (0) or {5, 3, 4} (1) of the window; pair = wave >> 1
     const int NC = SPLIT ? (p.cin / UC4) >> p.ks_shift : p.cin / UC4;      // units per item (even)
-    __shared__ int split_flag;
+
 
     // ---- work items: (tile block, slice) of this XCD's contiguous eighth ----
     const XcdRange xr = xcd_range(p.nitems, p.xcd_shift);
@@ -569,10 +569,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const ConvParams p
             constexpr int NO = POOL ? 2 : 4;                            // output rows / columns per tile
             const int Ho = POOL ? p.H >> 1 : p.H, Wo = POOL ? p.W >> 1 : p.W;
             const int py0 = POOL ? oy >> 1 : oy, px0 = POOL ? ox >> 1 : ox;
-            // MODE 0: the ordinary epilogue; 1 (SPLIT): this range's pre-bias output tiles -> split_scratch; 2 (SPLIT, the last range
-            // to arrive): the sum of the ranges' shares -> activation, [pool], store
+            // MODE 0: the ordinary epilogue; 1 (SPLIT): this range's pre-bias output tiles -> split_scratch
             unsigned long long* const part = SPLIT ? reinterpret_cast<unsigned long long*>(p.split_scratch) + (long long)item * (64 * 256) + tid : nullptr;
-            const unsigned long long* part0 = nullptr;
             auto epilogue = [&](auto mode_tag) __attribute__((always_inline)) {
             constexpr int MODE = decltype(mode_tag)::value;
 #pragma unroll
@@ -586,7 +584,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const ConvParams p
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 f32x2 tcol[4][6];                                       // T[a][j] = sum_i A^T[a][i] M[i][j]
-                if constexpr (MODE != 2) {
+                {
 #pragma unroll
                 for (int j = 0; j < 6; ++j) {
                     f32x2 mm[6], y[4];
@@ -604,52 +602,17 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const ConvParams p
                 }
                 }
                 if constexpr (MODE == 1) {
-                    // (agent-scope relaxed atomics = sc1 stores: coherent across the XCDs' L2s by themselves)
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
                         f32x2 y[4];
                         at6(tcol[a], y);
 #pragma unroll
-                        for (int b = 0; b < 4; ++b)
-                            __hip_atomic_store(&part[((m * 2 + h) * 16 + a * 4 + b) * 256], __builtin_bit_cast(unsigned long long, y[b]),
-                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        for (int b = 0; b < 4; ++b) part[((m * 2 + h) * 16 + a * 4 + b) * 256] = __builtin_bit_cast(unsigned long long, y[b]);
                     }
                 } else {
                 const f32x2 bb = {b4[2 * h], b4[2 * h + 1]}, ss = {s4[2 * h], s4[2 * h + 1]}, tt = {t4[2 * h], t4[2 * h + 1]};
-                // MODE 2: the ranges' shares of TWO rows (8 pre-bias outputs) of (m, h) at a time -- all loads issued before the first
-                // value is used (sc1 loads, ~1.5 us a trip; 128 registers for 8 ranges), summed in range order: deterministic.  (All
-                // four rows at once: 256 registers, 580 spills; the next batch issued under the current one's sum: 70 spills whose
-                // reloads drain the loads again -- both slower.)
-                f32x2 ysum[2][4];
-                auto gather2 = [&](const int r0) __attribute__((always_inline)) {
-                    const int KS = 1 << p.ks_shift;
-                    unsigned long long rawv[8][8];
-#pragma unroll
-                    for (int k = 0; k < 8; ++k)
-                        if (k < KS) {
-#pragma unroll
-                            for (int i = 0; i < 8; ++i)
-                                rawv[k][i] = __hip_atomic_load(&part0[(long long)k * (64 * 256) + ((m * 2 + h) * 16 + r0 * 4 + i) * 256],
-                                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        }
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        f32x2 v = __builtin_bit_cast(f32x2, rawv[0][i]);
-#pragma unroll
-                        for (int k = 1; k < 8; ++k)
-                            if (k < KS) v += __builtin_bit_cast(f32x2, rawv[k][i]);
-                        ysum[i >> 2][i & 3] = v;
-                    }
-                };
                 // row a of the 4x4 output tile, pre-bias
-                auto out_row = [&](const int a, f32x2 (&y)[4]) __attribute__((always_inline)) {
-                    if constexpr (MODE == 2) {
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) y[b] = ysum[a & 1][b];
-                    } else {
-                        at6(tcol[a], y);
-                    }
-                };
+                auto out_row = [&](const int a, f32x2 (&y)[4]) __attribute__((always_inline)) { at6(tcol[a], y); };
                 auto act = [&](f32x2 v) __attribute__((always_inline)) -> f32x2 {
                     v = v + bb;
                     if (BNF) { v = v * ss + tt; return f32x2{relu_q(v[0]), relu_q(v[1])}; }
@@ -672,7 +635,6 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const ConvParams p
                 for (int a = 0; a < NO; ++a) {
                     __builtin_amdgcn_sched_barrier(0);
                     f32x2 res[NO];
-                    if constexpr (MODE == 2) { if (POOL) gather2(2 * a); else if ((a & 1) == 0) gather2(a); }
                     if constexpr (POOL) {
                         f32x2 y0[4], y1[4];
                         out_row(2 * a, y0); out_row(2 * a + 1, y1);
@@ -713,25 +675,8 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const ConvParams p
             }
             }
             };
-            if constexpr (!SPLIT) {
-                epilogue(std::integral_constant<int, 0>{});
-            } else {
-                epilogue(std::integral_constant<int, 1>{});
-                // hand-off (conv_wino43.hip documents the protocol: sc1 payload -> vmcnt(0) -> barrier -> agent-scope counter; the
-                // finisher reads with sc1 loads and leaves the counter at zero)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __syncthreads();
-                if (tid == 0)
-                    split_flag = __hip_atomic_fetch_add(&p.split_ctr[item >> p.ks_shift], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __syncthreads();
-                if (split_flag == (1 << p.ks_shift) - 1) {
-                    if (tid == 0)
-                        __hip_atomic_store(&p.split_ctr[item >> p.ks_shift], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    part0 = reinterpret_cast<const unsigned long long*>(p.split_scratch) +
-                            (long long)((item >> p.ks_shift) << p.ks_shift) * (64 * 256) + tid;
-                    epilogue(std::integral_constant<int, 2>{});
-                }
-            }
+            // (SPLIT: split_reduce_kernel, the next launch on the stream, sums the ranges' shares in range order and runs the rest)
+            epilogue(std::integral_constant<int, SPLIT ? 1 : 0>{});
         }
         if (!has_next) { dma_wait(); return; }      // the prefetch DMAs still in flight write THIS workgroup's LDS: drain them
         if (next_slice != cur.slice) {
@@ -794,9 +739,10 @@ int launch_conv_wino43b(const ConvParams& p, bool pool, hipStream_t s)
 {
     if (p.ks_shift > 0) {        // api.hip: single-pair launches with fewer items than CUs
         const int ncs = (p.cin / UC4) >> p.ks_shift;
-        if (ncs < 2 || (ncs & 1) || (ncs << p.ks_shift) * UC4 != p.cin || !p.split_scratch || !p.split_ctr) return 2;
-        if (p.pad_zero) return pool ? launch_shape<true, true, true>(p, s) : launch_shape<false, true, true>(p, s);
-        return pool ? launch_shape<true, false, true>(p, s) : launch_shape<false, false, true>(p, s);
+        if (ncs < 2 || (ncs & 1) || (ncs << p.ks_shift) * UC4 != p.cin || !p.split_scratch) return 2;
+        const int rc = p.pad_zero ? (pool ? launch_shape<true, true, true>(p, s) : launch_shape<false, true, true>(p, s))
+                                  : (pool ? launch_shape<true, false, true>(p, s) : launch_shape<false, false, true>(p, s));
+        return rc ? rc : launch_split_reduce(p, 2, pool, s);
     }
     if (p.pad_zero) return pool ? launch_shape<true, true>(p, s) : launch_shape<false, true>(p, s);
     return pool ? launch_shape<true, false>(p, s) : launch_shape<false, false>(p, s);

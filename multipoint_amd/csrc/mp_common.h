@@ -47,11 +47,10 @@ struct ConvParams {
     // each XCD has its own L2, so a persistent workgroup walks a contiguous share of ITS XCD's items)
     int ncu, xcd_shift;
     // conv_wino43.hip / conv_wino43b.hip, small launches (single-pair latency): the input channels of an item are cut into 2^ks_shift ranges that
-    // run as separate items; their pre-bias output tiles meet in split_scratch and the LAST range to arrive (split_ctr, one
-    // counter per group, left at zero) sums them in range order and runs the epilogue.  ks_shift = 0: off.
+    // run as separate items; their pre-bias output tiles meet in split_scratch, and split_reduce_kernel (conv_split.hip, the next
+    // launch on the stream) sums them in range order and runs the rest of the epilogue.  ks_shift = 0: off.
     int ks_shift;
-    float* split_scratch;     // [virtual item][2][16][512] f32x2
-    int* split_ctr;           // [group]
+    float* split_scratch;     // [virtual item][32 or 64 values][512 or 256 threads] f32x2 (128 KiB per virtual item)
 };
 
 // persistent schedule shared by the persistent kernels: the items are cut into one contiguous range per XCD, and the
@@ -116,6 +115,8 @@ int launch_conv_wino43(const ConvParams& p, bool pool, hipStream_t s, bool fuse_
 // second generation (conv_wino43b.hip): one wave per SIMD, whole-window input transform; any frame size
 bool conv_wino43b_supports(const ConvParams& p);
 int launch_conv_wino43b(const ConvParams& p, bool pool, hipStream_t s);
+// the split small launches' second half (conv_split.hip): sums the ranges' shares, activation, [pool], store; gen 1 / 2 = which kernel wrote them
+int launch_split_reduce(const ConvParams& p, int gen, bool pool, hipStream_t s);
 
 // fp16 path (mixed_precision: activations and packed weights fp16, fp32 accumulate; conv_f16.hip).
 // Same tiling as ConvParams; a chunk is 64 input channels, so cin must be a multiple of 64.

@@ -82,10 +82,10 @@ def test_forward_kernel_variants(oracle, monkeypatch, env, B, H, W):
                                        (1, 88, 120, '2'), (2, 72, 104, '2'), (2, 240, 320, '2')])
 def test_split_input_channels_on_small_launches(oracle, monkeypatch, B, H, W, gen):
     """Single-pair latency path (forwards of one or two images): an F(4x4,3x3) launch with fewer items than half the CUs runs the input channels of an item as
-    2 / 4 / 8 separate items whose pre-bias output tiles the last one to arrive sums in range order (conv_wino43.hip and -- gen '2':
+    2 / 4 / 8 separate items whose pre-bias output tiles split_reduce_kernel (conv_split.hip) sums in range order (conv_wino43.hip and -- gen '2':
     every layer; default routing: the layers whose frame is no multiple of 4 -- conv_wino43b.hip, SPLIT).
     Against the oracle, against the unsplit launch (MP_SPLITK_MAX=1: another summation order, same tolerance class as any two
-    kernel variants), and bit-identical from run to run -- the arrival order must not show."""
+    kernel variants), and bit-identical from run to run."""
     if gen:
         monkeypatch.setenv('MP_WINO43_GEN', gen)
     img = oracle.make_images(77 + W, B, H, W)
