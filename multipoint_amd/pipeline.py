@@ -94,14 +94,18 @@ class PairPipeline:
         P = optical.shape[0]
         return torch.stack((optical, thermal), dim=1).reshape(2 * P, *optical.shape[1:])
 
-    def run_interleaved(self, images, valid_mask=None, is_optical=None):
+    def run_interleaved(self, images, valid_mask=None, is_optical=None, order_caller=True):
         """One batch: the forward on a high-priority stream of the pipeline's own, then NMS / top-k / sampling / matching
         on a second side stream (`overlap_post=True`): those kernels are small and latency-bound, so they run in the
         shadow of the NEXT batch's convolutions instead of serialising behind this one.  The returned tensors belong to
         the side stream: `PairResults.wait()` (or a device synchronise) orders them.  The CALLER's stream is ordered
         behind the forward (not behind the post-processing): work it enqueues after this call -- overwriting `images` in
         place, for one -- cannot overtake the forward's reads; `PairResults.inputs_consumed` is the same event for
-        callers that write the inputs from another stream (bench.py --host-input)."""
+        callers that write the inputs from another stream (bench.py --host-input).  `order_caller=False` leaves that wait out
+        for callers that never touch `images` again (or wait on `inputs_consumed` themselves): the caller's stream then stays
+        idle, and the NEXT call need not order the forward stream behind it -- a cross-queue dependency that costs ~40 us of
+        idle GPU between two forwards (`rocprofv3 --kernel-trace`: 55 instead of 13 us between the head tail of batch n and the
+        first convolution of batch n+1)."""
         dev = images.device
         B, _, H, W = images.shape
         if B % 2:
@@ -125,7 +129,8 @@ class PairPipeline:
                 out = self.net({'image': images, 'is_optical': is_optical})
                 consumed = torch.cuda.Event()
                 consumed.record(fwd)
-            main.wait_event(consumed)                               # the caller's stream stays ordered behind the forward
+            if order_caller:
+                main.wait_event(consumed)                           # the caller's stream stays ordered behind the forward
             for t in (images, valid_mask, is_optical if is_optical.is_cuda else None):
                 if t is not None:
                     t.record_stream(fwd)
