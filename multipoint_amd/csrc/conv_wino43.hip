@@ -61,7 +61,6 @@ namespace {
 // an item's 32 tiles are 4 rows x 8 columns (16 x 32 output pixels, raw patch 18 x 34) or -- TC4 = 4 -- 8 rows x 4 columns (32 x 16
 // pixels, patch 34 x 18): launch_q picks the shape with fewer phantom tiles (60 x 80 layers: 8 instead of 12 items per image)
 constexpr int NPIX = 18 * 34;                      // 612 patch pixels = 16-byte granules (4 channels each), either shape
-constexpr int NPIXP = 624;                         // ... rounded up to blocks of 16
 constexpr int UC4 = 4;                             // input channels per unit
 constexpr int VB4 = UC4 * 32 * 36;                 // floats per V buffer  [ch][tile][pos]   (18 KiB)
 constexpr int UB4 = UC4 * 64 * 36;                 // floats per U buffer  [ch][cout][pos]   (36 KiB)
