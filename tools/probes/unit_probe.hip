@@ -67,6 +67,7 @@ __global__ __launch_bounds__(NW * 64, 1) void unit_probe(const float* __restrict
     constexpr bool DA = (VAR & 128) != 0;
     constexpr int WR = 788;                      // dwords per wave region: 12 * 64 + row skew, and WR / 4 = 1 (mod 4)
     constexpr int VPB = 8 * WR;                  // dwords per V' buffer
+    constexpr int V2B = 2 * 32 * 74 * 4;         // bytes per V2 buffer (fits the 18432-byte V buffer + slack? 18944: the probe's V area is 2 * VB4 floats = 36864 bytes: ok)
     constexpr int SCR = (VAR & 1024) ? 0 : 8 * SW4;       // (the half-window transform has no scratch)
     __shared__ __attribute__((aligned(16))) float smem[(DA ? 2 * VPB : 2 * VB4 + SCR) + 2 * UB4 + 3 * RB4 + 256];
     float* const Vs = smem;                      // (design A: V')
@@ -100,7 +101,7 @@ __global__ __launch_bounds__(NW * 64, 1) void unit_probe(const float* __restrict
 #pragma unroll
         for (int m = 0; m < NM; ++m) acc[s][m] = f32x4{0.f, 0.f, 0.f, 0.f};
     // transform tasks
-    unsigned p1_base[TW], scr_w[TW], scr_r[TW], p2_addr[TW];
+    unsigned p1_base[TW], scr_w[TW], scr_r[TW], p2_addr[TW], p2v2[TW];
 #pragma unroll
     for (int k = 0; k < TW; ++k) {
         const int t = DUTY ? (tid & 255) + 256 * k : tid + NT * k;
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(NW * 64, 1) void unit_probe(const float* __restrict
         scr_w[k] = lds_addr(myscr + sub6 * 2);
         scr_r[k] = lds_addr(myscr + sub6 * 12);
         p2_addr[k] = lds_addr(Vs) + (unsigned)((2 * w_cp * 32 + w_tile) * 36 + 6 * sub6) * 4u;
+        p2v2[k] = lds_addr(Vs) + (unsigned)(((w_cp * 32 + w_tile) * 74 + 12 * sub6) * 4);
     }
     f32x2 td[TW][6], tr[TW][6];
 #pragma unroll
@@ -144,6 +146,13 @@ __global__ __launch_bounds__(NW * 64, 1) void unit_probe(const float* __restrict
                 const f32x2 y = reinterpret_cast<lds_pair_ptr0>(a + (unsigned)(2 * (2 * (g - 6) + 1) * 64 + 4) * 4u)[0];
                 bf[slot] = f32x4{x[0], x[1], y[0], y[1]};
             }
+            return;
+        }
+        if (VAR & 524288) {
+            typedef const __attribute__((address_space(3))) float* lds_f_ptr;
+            const unsigned a = lds_addr(Vs) + (unsigned)(vb * V2B + (((lane >> 5) * 32 + tb * 16 + (lane & 15)) * 74 + ((lane >> 4) & 1)) * 4);
+            const lds_f_ptr pp = reinterpret_cast<lds_f_ptr>(a);
+            bf[slot] = f32x4{pp[8 * g], pp[8 * g + 2], pp[8 * g + 4], pp[8 * g + 6]};
             return;
         }
         bf[slot] = *reinterpret_cast<const f32x4*>(&Vs[vb * VB4 + b_base + 4 * g]);
@@ -280,6 +289,13 @@ __global__ __launch_bounds__(NW * 64, 1) void unit_probe(const float* __restrict
             else asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %5\n\ts_nop 0\n\tds_write_addtid_b32 %1 offset:2048\n\tds_write_addtid_b32 %2 offset:2304\n\t"
                               "ds_write_addtid_b32 %3 offset:2560\n\tds_write_addtid_b32 %4 offset:2816\n\ts_mov_b32 m0, %0"
                               : "=&s"(keep) : "v"(tr[k][4][0]), "v"(tr[k][4][1]), "v"(tr[k][5][0]), "v"(tr[k][5][1]), "s"(m0v) : "memory");
+            return;
+        }
+        if (VAR & 524288) {     // V2: the channel pair of a position is 8 contiguous bytes: two ds_write_b64 per slot
+            unsigned long long sv;
+            const unsigned a2 = p2v2[k] + (unsigned)buf * (unsigned)V2B + 16u * (unsigned)q;
+            asm volatile("s_mov_b64 %0, exec\n\ts_and_b64 exec, exec, %4\n\tds_write_b64 %1, %2 offset:%5\n\tds_write_b64 %1, %3 offset:%6\n\ts_mov_b64 exec, %0"
+                         : "=&s"(sv) : "v"(a2), "v"(tr[k][2 * q]), "v"(tr[k][2 * q + 1]), "s"(0x3F3F3F3F3F3F3F3Full), "n"(0), "n"(8) : "memory");
             return;
         }
         const unsigned a0 = p2_addr[k] + (unsigned)buf * (VB4 * 4u), a1 = a0 + 32u * 36u * 4u;
@@ -570,11 +586,12 @@ int main()
     (void)hipMalloc(&r, rf * 4); (void)hipMemset(r, 0, rf * 4);
     (void)hipMalloc(&out, 1 << 20); (void)hipMalloc(&cyc, 64);
     run<8, 0>("everything", w, r, rf, out, cyc);
+    run<8, 1>("no input transform", w, r, rf, out, cyc);
+    run<8, 256>("no V stores", w, r, rf, out, cyc);
+    run<8, 0, 524288>("V as [cp][tile][pos][2]: b64 stores", w, r, rf, out, cyc);        // (two ds_read2_b32 per fragment: slower, 3425)
     run<8, 0, 1024 + 2048>("HW8 stand-in addresses", w, r, rf, out, cyc);
-    run<8, 0, 1024 + 2048 + 65536>("HW8 real reads M1", w, r, rf, out, cyc);
-    run<8, 0, 1024 + 2048 + 131072>("HW8 real reads M2", w, r, rf, out, cyc);
     run<8, 0, 1024 + 2048 + 65536 + 262144>("HW8 real reads+stores M1", w, r, rf, out, cyc);
     run<8, 0, 1024 + 2048 + 131072 + 262144>("HW8 real reads+stores M2", w, r, rf, out, cyc);
-    run<8, 0, 1024 + 2048 + 262144>("HW8 real stores M1 only", w, r, rf, out, cyc);
+    run<4, 0, 1024 + 2048 + 4096>("NW4 HW cf, U DMAs spread", w, r, rf, out, cyc);
     return 0;
 }
