@@ -102,8 +102,11 @@ def test_split_input_channels_on_small_launches(oracle, monkeypatch, B, H, W, ge
     monkeypatch.setenv('MP_SPLITK_MAX', '2')
     net2, _ = _net(oracle, oracle.SHIPPED_MODEL_CONFIG, seed=9)
     c = net2({'image': img.cuda()})
+    monkeypatch.setenv('MP_SPLITK_MAX', '4')
+    net4, _ = _net(oracle, oracle.SHIPPED_MODEL_CONFIG, seed=9)
+    d = net4({'image': img.cuda()})
     ref = oracle.forward(sd, img, oracle.SHIPPED_MODEL_CONFIG)
-    for o in (a, b, c):
+    for o in (a, b, c, d):
         assert (o['prob'].cpu() - ref['prob']).abs().max().item() <= PROB_TOL
         assert (o['desc'].cpu() - ref['desc']).abs().max().item() <= DESC_TOL
     if B <= 2:
