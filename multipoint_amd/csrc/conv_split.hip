@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void split_reduce_kernel(const ConvParams p)
 #pragma unroll
         for (int k = 1; k < 8; ++k)
             if (k < KS) v += __builtin_bit_cast(f32x2, rawv[k][i]);         // range order: deterministic
-        v = v + bb;
+        v = w43_add_bias(v, 2 * ap + (i >> 2), i & 3, bb);          // (the shares are the SCALED transform's values: at6s, mp_common.h)
         if (BNF) { v = v * ss + tt; v = f32x2{relu_s(v[0]), relu_s(v[1])}; }
         else { v = f32x2{relu_s(v[0]), relu_s(v[1])}; v = v * ss + tt; }
         yv[i >> 2][i & 3] = v;

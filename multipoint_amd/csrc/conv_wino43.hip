@@ -149,18 +149,7 @@ __device__ __forceinline__ void bt6(const f32x2 d[6], f32x2 r[6])
     r[4] = pk_fnma_k<1>(t3, K_AB, t2);                      // t2 - b t3
     r[5] = pk_fma_k<0>(d[1], K_PS, pk_fnma_k<1>(d[3], K_PS, d[5]));      // a^2 b^2 d1 + (d5 - (a^2+b^2) d3)
 }
-// 1-D output transform A^T m (6 -> 4), packed over two output channels.  A^T[i][p] = p^i:
-//   [1 1 1 1 1 0; 0 a -a b -b 0; 0 a^2 a^2 b^2 b^2 0; 0 a^3 -a^3 b^3 -b^3 1]
-__device__ __forceinline__ void at6(const f32x2 m[6], f32x2 y[4])
-{
-    constexpr float a1 = (float)W43A, b1 = (float)W43B, a2 = (float)(W43A * W43A), b2 = (float)(W43B * W43B),
-                    a3 = (float)(W43A * W43A * W43A), b3 = (float)(W43B * W43B * W43B);
-    const f32x2 s1 = m[1] + m[2], d1 = m[1] - m[2], s2 = m[3] + m[4], d2 = m[3] - m[4];
-    y[0] = (m[0] + s1) + s2;
-    y[1] = __builtin_elementwise_fma(d2, f32x2{b1, b1}, d1 * f32x2{a1, a1});
-    y[2] = __builtin_elementwise_fma(s2, f32x2{b2, b2}, s1 * f32x2{a2, a2});
-    y[3] = __builtin_elementwise_fma(d2, f32x2{b3, b3}, d1 * f32x2{a3, a3}) + m[5];
-}
+// (1-D output transform: at6s(), mp_common.h)
 
 // F1: the layer's input is the first encoder block (Cin = 1 -> 64, conv_first.hip's arithmetic) of p.img, computed by this
 // kernel itself, PER UNIT and straight into the raw LDS ring (round 3; round 2 evaluated it per item into a global scratch that
@@ -730,14 +719,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                         f32x2 m[6], y[4];
 #pragma unroll
                         for (int i = 0; i < 6; ++i) m[i] = f32x2{acc[6 * i + j][2 * h], acc[6 * i + j][2 * h + 1]};
-                        at6(m, y);
+                        at6s(m, y);
 #pragma unroll
                         for (int a = 0; a < 4; ++a) tcol[a][j] = y[a];
                     }
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
                         f32x2 y[4];
-                        at6(tcol[a], y);
+                        at6s(tcol[a], y);
 #pragma unroll
                         for (int b = 0; b < 4; ++b)
                             part[(h * 16 + a * 4 + b) * 512] = __builtin_bit_cast(unsigned long long, y[b]);
@@ -754,7 +743,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                     f32x2 m[6], y[4];
 #pragma unroll
                     for (int i = 0; i < 6; ++i) m[i] = f32x2{acc[6 * i + j][2 * h], acc[6 * i + j][2 * h + 1]};
-                    at6(m, y);
+                    at6s(m, y);
 #pragma unroll
                     for (int a = 0; a < 4; ++a) tcol[a][j] = y[a];
                 }
@@ -764,10 +753,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
                     f32x2 y[4];
-                    at6(tcol[a], y);
+                    at6s(tcol[a], y);
 #pragma unroll
                     for (int b = 0; b < 4; ++b) {
-                        f32x2 v = y[b] + bb;
+                        f32x2 v = w43_add_bias(y[b], a, b, bb);
                         if (BNF) { v = v * ss + tt; v = f32x2{relu_q(v[0]), relu_q(v[1])}; }
                         else { v = f32x2{relu_q(v[0]), relu_q(v[1])}; v = v * ss + tt; }
                         yv[a][b] = v;

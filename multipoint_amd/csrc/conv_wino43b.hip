@@ -124,17 +124,7 @@ __device__ __forceinline__ void bt6(const f32x2 d[6], f32x2 r[6])
     r[4] = pk_fnma_k<1>(t3, K_AB, t2);
     r[5] = pk_fma_k<0>(d[1], K_PS, pk_fnma_k<1>(d[3], K_PS, d[5]));
 }
-// 1-D output transform A^T m (6 -> 4), packed over two output channels.  A^T[i][p] = p^i
-__device__ __forceinline__ void at6(const f32x2 m[6], f32x2 y[4])
-{
-    constexpr float a1 = (float)W43A, b1 = (float)W43B, a2 = (float)(W43A * W43A), b2 = (float)(W43B * W43B),
-                    a3 = (float)(W43A * W43A * W43A), b3 = (float)(W43B * W43B * W43B);
-    const f32x2 s1 = m[1] + m[2], d1 = m[1] - m[2], s2 = m[3] + m[4], d2 = m[3] - m[4];
-    y[0] = (m[0] + s1) + s2;
-    y[1] = __builtin_elementwise_fma(d2, f32x2{b1, b1}, d1 * f32x2{a1, a1});
-    y[2] = __builtin_elementwise_fma(s2, f32x2{b2, b2}, s1 * f32x2{a2, a2});
-    y[3] = __builtin_elementwise_fma(d2, f32x2{b3, b3}, d1 * f32x2{a3, a3}) + m[5];
-}
+// (1-D output transform: at6s(), mp_common.h)
 
 // accumulator s * 2 + m: the first 64 are the compiler's (MFMA builtin: hipcc keeps them in the 256 AGPRs), the last 8 are pinned to
 // VGPRs by asm statements (288 > 256: with builtins only, hipcc still wants every MFMA result in an AGPR and shuttles the overflow
@@ -595,7 +585,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const ConvParams p
                         MPB_ACC_RD(hi, acc[6 * i + j][m], (6 * i + j) * 2 + m, 2 * h + 1);
                         mm[i] = f32x2{lo, hi};
                     }
-                    at6(mm, y);
+                    at6s(mm, y);
 #pragma unroll
                     for (int a = 0; a < 4; ++a) tcol[a][j] = y[a];
                     __builtin_amdgcn_sched_barrier(0);      // (register peak: the scheduler otherwise hoists every accumulator read)
@@ -605,16 +595,16 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const ConvParams p
 #pragma unroll
                     for (int a = 0; a < 4; ++a) {
                         f32x2 y[4];
-                        at6(tcol[a], y);
+                        at6s(tcol[a], y);
 #pragma unroll
                         for (int b = 0; b < 4; ++b) part[((m * 2 + h) * 16 + a * 4 + b) * 256] = __builtin_bit_cast(unsigned long long, y[b]);
                     }
                 } else {
                 const f32x2 bb = {b4[2 * h], b4[2 * h + 1]}, ss = {s4[2 * h], s4[2 * h + 1]}, tt = {t4[2 * h], t4[2 * h + 1]};
                 // row a of the 4x4 output tile, pre-bias
-                auto out_row = [&](const int a, f32x2 (&y)[4]) __attribute__((always_inline)) { at6(tcol[a], y); };
-                auto act = [&](f32x2 v) __attribute__((always_inline)) -> f32x2 {
-                    v = v + bb;
+                auto out_row = [&](const int a, f32x2 (&y)[4]) __attribute__((always_inline)) { at6s(tcol[a], y); };
+                auto act = [&](f32x2 v, const int r, const int c) __attribute__((always_inline)) -> f32x2 {
+                    v = w43_add_bias(v, r, c, bb);
                     if (BNF) { v = v * ss + tt; return f32x2{relu_q(v[0]), relu_q(v[1])}; }
                     v = f32x2{relu_q(v[0]), relu_q(v[1])};
                     return v * ss + tt;
@@ -639,7 +629,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const ConvParams p
                         f32x2 y0[4], y1[4];
                         out_row(2 * a, y0); out_row(2 * a + 1, y1);
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) { y0[b] = act(y0[b]); y1[b] = act(y1[b]); }
+                        for (int b = 0; b < 4; ++b) { y0[b] = act(y0[b], 2 * a, b); y1[b] = act(y1[b], 2 * a + 1, b); }
 #pragma unroll
                         for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -649,7 +639,7 @@ __global__ __launch_bounds__(256, 1) void conv_wino43b_kernel(const ConvParams p
                         f32x2 y0[4];
                         out_row(a, y0);
 #pragma unroll
-                        for (int b = 0; b < 4; ++b) res[b] = act(y0[b]);
+                        for (int b = 0; b < 4; ++b) res[b] = act(y0[b], a, b);
                     }
                     if (h == 0) {
 #pragma unroll

@@ -109,6 +109,31 @@ void launch_conv_first(const Conv1Params& p, hipStream_t s);
 #ifndef MP_W43_B
 #define MP_W43_B 1.5
 #endif
+// 1-D output transform A^T m (6 -> 4) of the F(4x4,3x3) kernels, packed over two output channels, with the powers of `a` factored
+// out of rows 1 and 2: A^T[i][p] = p^i over the points (0, a, -a, b, -b, inf) and b = 2a give
+//   y0 = m0 + s1 + s2,  y1 = a (d1 + 2 d2),  y2 = a^2 (s1 + 4 s2),  y3 = a^3 (d1 + 8 d2) + m5     (s = sums, d = differences)
+// so z = (y0, y1 / a, y2 / a^2, y3) takes 10 packed instructions instead of 13 (every bracket is ONE multiply-add with an exact
+// coefficient), and the factor sigma_r sigma_c, sigma = (1, a, a^2, 1), of output (r, c) goes into the multiply-add that adds the
+// bias anyway (w43_out_scale; 1, a .. a^4 are exact binary fractions).  Two roundings fewer per y1 / y2 than the plain form.
+typedef float mp_f32x2 __attribute__((ext_vector_type(2)));
+static_assert(MP_W43_B == 2 * MP_W43_A, "at6s() needs b = 2a");
+__device__ __forceinline__ void at6s(const mp_f32x2 m[6], mp_f32x2 z[4])
+{
+    constexpr float a3 = (float)(MP_W43_A * MP_W43_A * MP_W43_A);
+    const mp_f32x2 s1 = m[1] + m[2], d1 = m[1] - m[2], s2 = m[3] + m[4], d2 = m[3] - m[4];
+    z[0] = (m[0] + s1) + s2;
+    z[1] = __builtin_elementwise_fma(d2, mp_f32x2{2.f, 2.f}, d1);
+    z[2] = __builtin_elementwise_fma(s2, mp_f32x2{4.f, 4.f}, s1);
+    z[3] = __builtin_elementwise_fma(__builtin_elementwise_fma(d2, mp_f32x2{8.f, 8.f}, d1), mp_f32x2{a3, a3}, m[5]);
+}
+constexpr float w43_sigma(int r) { return r == 1 ? (float)MP_W43_A : r == 2 ? (float)(MP_W43_A * MP_W43_A) : 1.f; }
+constexpr float w43_out_scale(int r, int c) { return w43_sigma(r) * w43_sigma(c); }
+// pre-bias output (r, c) of a tile from the scaled transform's value + the bias: ONE multiply-add (an add where the factor is 1)
+__device__ __forceinline__ mp_f32x2 w43_add_bias(mp_f32x2 z, int r, int c, mp_f32x2 bias)
+{
+    const float k = w43_out_scale(r, c);
+    return k == 1.f ? z + bias : __builtin_elementwise_fma(z, mp_f32x2{k, k}, bias);
+}
 bool conv_wino43_supports(const ConvParams& p);
 long long conv_wino43_items(const ConvParams& p);      // work items the launch would have (B x tile blocks x slices)
 int launch_conv_wino43(const ConvParams& p, bool pool, hipStream_t s, bool fuse_first = false);

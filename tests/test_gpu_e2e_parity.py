@@ -106,9 +106,11 @@ def test_structured_images_at_the_headline_shape(oracle):
     img = T.structured_images(4, 2 * n_pairs, H, W)
     prob_cpu = oracle.forward(sd, img, cfg)['prob'].numpy()
     nms = lambda m: oracle.box_nms(m, PRED['nms'], PRED['detection_threshold'], keep_top_k=0)
-    # observed (round 4, 8 images): auto 1406 of 7906 keypoints differ -- ALL of them in one image whose top-k cut falls inside a plateau
-    # of exactly tied scores (703 keypoints swapped for 703 others of equal reference score; 7 of 8 images identical); direct 0 of 7203
-    for algo, bound in (('auto', 0.22), ('direct', 0.01)):
+    # observed (round 4, 8 images): auto 1658 of 8032 keypoints differ (1406 of 7906 before the output transform's rounding pattern
+    # changed) -- ALL of them in one image whose top-k cut falls inside a plateau of exactly tied scores (keypoints swapped for
+    # others of equal reference score; 7 of 8 images identical); direct 0 of 7203.  The bound is what ONE such image can produce:
+    # its whole top-k list exchanged = 2 x 1000 of ~8000
+    for algo, bound in (('auto', 0.26), ('direct', 0.01)):
         c = dict(cfg); c['conv_algorithm'] = algo
         net = M.MultiPoint(c); net.load_state_dict(sd); net.to('cuda'); net.eval()
         prob_gpu = net({'image': img.cuda()})['prob'].cpu().numpy()
