@@ -25,7 +25,8 @@ __global__ __launch_bounds__(NW * 64, 1) void probe(float* out, unsigned long lo
     __shared__ __attribute__((aligned(16))) float lds[NW * 64 * 4 * 2];
     for (int i = threadIdx.x; i < NW * 64 * 8; i += NW * 64) lds[i] = (float)i;
     __syncthreads();
-    const unsigned la = (unsigned)(size_t)(lds + threadIdx.x * 4);          // 16 bytes per lane, conflict-free
+    const unsigned la = (unsigned)(size_t)(lds + threadIdx.x * 4);          // 16 bytes per lane: conflict-free for ds_read_b128
+    const unsigned la8 = (unsigned)(size_t)(lds + threadIdx.x * 2);         // 8 bytes per lane: conflict-free for the 8-byte accesses
     f32x4 q[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) q[i] = f32x4{1.f, 2.f, 3.f, (float)i};
@@ -46,9 +47,10 @@ __global__ __launch_bounds__(NW * 64, 1) void probe(float* out, unsigned long lo
                 else if (CLS == 3) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[r]) : "v"(u[(r + 1) & 7]));
                 else if (CLS == 4) asm volatile("v_mov_b32 %0, %1" : "=v"(u[r]) : "v"(u[(r + 1) & 7]));
                 else if (CLS == 5) asm volatile("ds_read_b128 %0, %1" : "=v"(q[r]) : "v"(la));
-                else if (CLS == 6) asm volatile("ds_write2_b32 %0, %1, %2 offset0:0 offset1:1" :: "v"(la), "v"(v[r][0]), "v"(v[r][1]) : "memory");
-                else if (CLS == 7) asm volatile("ds_read_b64 %0, %1" : "=v"(v[r]) : "v"(la));
-                else asm volatile("ds_write_b64 %0, %1" :: "v"(la), "v"(v[r]) : "memory");
+                else if (CLS == 6) asm volatile("ds_write2_b32 %0, %1, %2 offset0:0 offset1:1" :: "v"(la8), "v"(v[r][0]), "v"(v[r][1]) : "memory");
+                else if (CLS == 7) asm volatile("ds_read_b64 %0, %1" : "=v"(v[r]) : "v"(la8));
+                else if (CLS == 8) asm volatile("ds_write_b64 %0, %1" :: "v"(la8), "v"(v[r]) : "memory");
+                else asm volatile("ds_write2_b64 %0, %1, %2 offset0:0 offset1:64" :: "v"(la8), "v"(v[r]), "v"(v[(r + 1) & 7]) : "memory");
             }
             (void)per;
             __builtin_amdgcn_sched_barrier(0);
@@ -101,5 +103,6 @@ int main()
     row<8, 3>("v_add_u32", out, cyc); row<8, 4>("v_mov_b32", out, cyc);
     row<4, 5>("ds_read_b128", out, cyc); row<4, 6>("ds_write2_b32", out, cyc); row<4, 7>("ds_read_b64", out, cyc); row<4, 8>("ds_write_b64", out, cyc);
     row<8, 5>("ds_read_b128", out, cyc); row<8, 6>("ds_write2_b32", out, cyc); row<8, 7>("ds_read_b64", out, cyc); row<8, 8>("ds_write_b64", out, cyc);
+    row<4, 9>("ds_write2_b64", out, cyc); row<8, 9>("ds_write2_b64", out, cyc);
     return 0;
 }
