@@ -108,16 +108,21 @@ def cpu_baseline(sd, cfg, n_pairs=16, H=H, W=W, PRED_CFG=PRED_CFG):
     Returns (record, per-pair results, prob maps (2n,1,H,W) interleaved optical/thermal, coarse descriptors)."""
     from oracle import mp_oracle as O
     from multipoint_amd.datasets import SyntheticPairs
-    ncpu = os.cpu_count() or 1
+    # the CPUs this process may run on (a rank bound to its GPU's NUMA node is given its original affinity back by the caller:
+    # the baseline is a host figure, not a per-NUMA-node one); the thread pool is sized by THAT, not by os.cpu_count()
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
     pairs = [SyntheticPairs.make_pair(0, p, H, W) for p in range(n_pairs)]
     imgs = torch.from_numpy(np.stack([x for pr in pairs for x in pr]))              # interleaved like the GPU batch
     flags = (torch.arange(2 * n_pairs) % 2 == 0).reshape(-1, 1)
     # ATen's CPU convolution does not scale to every hardware thread of a big host: pick the fastest pool size on a one-pair
     # probe (the choice and every timing are reported)
+    # (round 4 probed up to every CPU of the host: 256 threads took 10.9 s per pair to confirm what 16 / 32 / 64 already show --
+    # ATen's CPU convolutions stop scaling at 32-64 threads; capped at 64, one warm-up for the first candidate only)
     probe = {}
-    for nt in sorted({min(ncpu, k) for k in (16, 32, 64, 128, ncpu)}):
+    for i, nt in enumerate(sorted({min(ncpu, k) for k in (16, 32, 64)})):
         torch.set_num_threads(nt)
-        O.forward(sd, imgs[:2], cfg, is_optical=flags[:2])                           # warm-up
+        if i == 0:
+            O.forward(sd, imgs[:2], cfg, is_optical=flags[:2])                       # warm-up
         t0 = time.perf_counter(); O.forward(sd, imgs[:2], cfg, is_optical=flags[:2]); probe[nt] = time.perf_counter() - t0
     threads = min(probe, key=probe.get)
     torch.set_num_threads(threads)
@@ -151,7 +156,7 @@ def cpu_baseline(sd, cfg, n_pairs=16, H=H, W=W, PRED_CFG=PRED_CFG):
         same = np.array_equal(O.box_nms(prob[1::2], nms, thr, keep_top_k=topk), pn[1::2])
         single = {'seconds_one_spectrum': round(time.perf_counter() - ts, 3), 'equal_to_per_image_dispatch': bool(same)}
     rec = {'value': n_pairs / dt, 'unit': 'image-pairs/s', 'cores': threads, 'kind': 'port',
-           'host_cpus': ncpu, 'nms_dispatch': 'torchvision batched_nms: per-image loop above 4000 box coordinates',
+           'host_cpus': os.cpu_count(), 'cpus_in_affinity': ncpu, 'nms_dispatch': 'torchvision batched_nms: per-image loop above 4000 box coordinates',
            'box_nms_single_call': single,
            'stage_seconds': {'forward': round(t1 - t0, 3), 'box_nms+topk': round(t2 - t1, 3),
                              'keypoints+descriptor_sampling': round(t3 - t2, 3), 'mutual_nn_match': round(t4 - t3, 3)},
@@ -181,6 +186,7 @@ def parity_block(res, net, images, flags, cres, prob_cpu, desc_cpu, PRED, H, W):
     for side, off in (('optical', 0), ('thermal', 1)):
         tot = dif = same = 0
         derr = 0.0
+        per_pair = par.setdefault('_desc_err_per_pair', [0.0] * n)
         for p in range(n):
             b = 2 * p + off
             kp = host[p]['kp_' + side]; gd = host[p]['desc_' + side]
@@ -189,7 +195,8 @@ def parity_block(res, net, images, flags, cres, prob_cpu, desc_cpu, PRED, H, W):
             tot += per[b]['keypoints_total']; dif += per[b]['keypoints_differing']; same += per[b]['keypoints_differing'] == 0
             both = np.array([i for i, f in enumerate(flat) if f in per[b]['final_cpu']], dtype=np.int64)
             if len(both):
-                derr = max(derr, float(np.abs(O.interpolate_descriptors(kp[both], desc_cpu[b], H, W) - gd[both]).max()))
+                e = float(np.abs(O.interpolate_descriptors(kp[both], desc_cpu[b], H, W) - gd[both]).max())
+                derr = max(derr, e); per_pair[p] = max(per_pair[p], e)
         par[side] = {'keypoints_total': tot, 'keypoints_differing': dif, 'images_with_identical_keypoints': same,
                      'desc_max_abs_err_on_intersection': derr}
     par.update({'keypoints_total': summary['keypoints_total'], 'keypoints_differing': summary['keypoints_differing'],
@@ -228,6 +235,88 @@ def parity_structured(PRED, H, W, device, n_pairs=4):
     return rec
 
 
+def _timed_steps(fn, device, steps, warmup):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize(device)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    torch.cuda.synchronize(device)
+    return (time.perf_counter() - t0) / steps
+
+
+def secondary_block(device):
+    """Rates the round-4 verdict asked to see under the driver's clock, kept OUT of `value` / `config` (N = 1 only, ~15 s):
+    `c5` = BASELINE configs[4]'s per-GPU share (8 pairs 1024x1280, fp16 MFMA path, top-k 2000) with the hardware fraction of its
+    dominant launch; `direct` = the headline workload with `model.conv_algorithm: direct` (the tie-exact algorithm); `batch1` =
+    the reference's shipped run shape (configs/config_image_pair_dataset_prediction.yaml:43,47: batchsize 1, and topk 0 =
+    unlimited): pairs/s pipelined and the synchronous latency of one pair."""
+    import multipoint_amd.models as models
+    from multipoint_amd.pipeline import PairPipeline
+    from multipoint_amd.datasets.synthetic_weights import SHIPPED_MODEL_CONFIG, make_weights
+    sec = {}
+
+    def build(cfg, pred, pairs, h, w):
+        net = models.MultiPoint(cfg); net.load_state_dict(make_weights(0, cfg)); net.to(device); net.eval()
+        pipe = PairPipeline(net, pred, capacity=pred['topk'] or None, nms_rounds=8)
+        images = make_batch(list(range(pairs)), device, h, w)
+        flags = (torch.arange(2 * pairs) % 2 == 0).reshape(-1, 1)
+        return net, pipe, images, flags
+
+    # c5: 8 pairs 1024x1280 fp16, top-k 2000
+    cfg = dict(SHIPPED_MODEL_CONFIG); cfg['mixed_precision'] = True
+    pred = dict(PRED_CFG); pred['topk'] = 2000
+    net, pipe, images, flags = build(cfg, pred, 8, 1024, 1280)
+    steps = 20
+    _timed_steps(lambda: pipe.run_interleaved(images, None, flags, order_caller=False), device, 3, 3)
+    net.profile(True)
+    dt = _timed_steps(lambda: pipe.run_interleaved(images, None, flags, order_caller=False), device, steps, 0)
+    prof = net.profile_read(); net.profile(False)
+    pipe.check_converged(device)
+    dom = [(ms, fl) for name, ms, fl in prof if name in ('enc.conv1+2', 'enc.conv2')]
+    dom_ms = sum(m for m, _ in dom) / max(1, len(dom))
+    items = 16 * (1024 // 8) * (1280 // 32)
+    fused = any(name == 'enc.conv1+2' for name, _, _ in prof)
+    issued = 2.0 * 9 * 64 * 64 * 1024 * 1280 * 16 + (items * 22 * 32768.0 if fused else 0.0)
+    sec['c5'] = {'workload': 'BASELINE configs[4] per-GPU share: 8 pairs 1024x1280, fp16 MFMA path, top-k 2000, full path',
+                 'pairs_per_s': round(8 / dt, 1), 'ms_per_step': round(dt * 1e3, 3), 'steps': steps,
+                 'dominant_launch_ms': round(dom_ms, 4),
+                 'frac': round(issued / (dom_ms * 1e-3) / 1e12 / PEAK_FP16_MFMA_TFLOPS, 4) if dom_ms > 0 else None,
+                 'layer_ms': {k: round(sum(m for n, m, _ in prof if n == k) / steps, 4) for k in dict.fromkeys(n for n, _, _ in prof)}}
+    del net, pipe, images
+    torch.cuda.empty_cache()
+
+    # direct: the headline workload on the tie-exact algorithm
+    cfg = dict(SHIPPED_MODEL_CONFIG); cfg['conv_algorithm'] = 'direct'
+    net, pipe, images, flags = build(cfg, dict(PRED_CFG), PAIRS_PER_GPU, 480, 640)
+    dt = _timed_steps(lambda: pipe.run_interleaved(images, None, flags, order_caller=False), device, 8, 2)
+    pipe.check_converged(device)
+    sec['direct'] = {'workload': 'BASELINE configs[2] with model.conv_algorithm: direct (keeps exact ties of the heat map)',
+                     'pairs_per_s': round(PAIRS_PER_GPU / dt, 1), 'ms_per_step': round(dt * 1e3, 3), 'steps': 8}
+    del net, pipe, images
+    torch.cuda.empty_cache()
+
+    # batch1: one 480x640 pair per call (the reference's batchsize: 1), top-k 1000 and topk: 0
+    b1 = {'workload': 'one 480x640 pair per call (reference yaml: batchsize 1), default algorithm'}
+    for label, topk in (('topk1000', 1000), ('topk0', 0)):
+        pred = dict(PRED_CFG); pred['topk'] = topk
+        net, pipe, images, flags = build(dict(SHIPPED_MODEL_CONFIG), pred, 1, 480, 640)
+        dt_pipe = _timed_steps(lambda: pipe.run_interleaved(images, None, flags, order_caller=False), device, 200, 20)
+        pipe.check_converged(device)
+
+        def one_pair():                                              # exact NMS, lists regrown on overflow, results read back
+            r = pipe.run_converged(images)
+            r.match_count.cpu()
+        dt_sync = _timed_steps(one_pair, device, 100, 10)
+        b1[label] = {'pairs_per_s_pipelined': round(1 / dt_pipe, 1), 'ms_per_pair_pipelined': round(dt_pipe * 1e3, 4),
+                     'ms_per_pair_synchronous': round(dt_sync * 1e3, 4),
+                     'keypoints_per_image': [int(v) for v in pipe._last.kp_count.cpu().tolist()]}
+        del net, pipe, images
+    sec['batch1'] = b1
+    return sec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -242,6 +331,8 @@ def main():
     ap.add_argument('--host-input', action='store_true',
                     help='secondary measurement (never the headline value): every step first uploads its batch from pinned '
                          'host memory on a copy stream, double-buffered, overlapping the previous step (PCIe-inclusive rate)')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='skip the `secondary` object of the N = 1 line (c5 / direct / batchsize-1 rates, ~15 s)')
     ap.add_argument('--workload', choices=['c3', 'c5'], default='c3',
                     help='c3 (default, headline): 480x640 fp32 top-k 1000; c5: 1024x1280 fp16 MFMA path top-k 2000')
     args = ap.parse_args()
@@ -263,6 +354,7 @@ def main():
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import torch.distributed as dist
     from multipoint_amd.dist import bind_rank_to_numa_node
+    orig_affinity = os.sched_getaffinity(0) if hasattr(os, 'sched_getaffinity') else None
     cpu_set = bind_rank_to_numa_node(local_rank) if world > 1 else None      # before the first GPU call; silent when not exposed
     if not torch.cuda.is_available():
         sys.exit('bench.py needs an MI355X; torch.cuda.is_available() is False')
@@ -370,8 +462,27 @@ def main():
     metrics = None
     if not args.forward_only:
         pipe.check_converged(device)
+        # one more step, OUTSIDE the timed region, with the stages bracketed by timing events: t_forward / t_nms / t_match of the
+        # record are this rank's batch times with nothing else in flight
+        fence()
+        res = pipe.run_interleaved(images, None, flags, order_caller=args.ordered_caller, timings=True)
+        stage = res.stage_ms()
+        pipe.check_converged(device)
         res.wait()
-        metrics = gather_pair_metrics(pair_metric_records(res, pair_ids)).cpu().numpy()
+        metrics = gather_pair_metrics(pair_metric_records(res, pair_ids, stage_ms=stage)).cpu().numpy()
+
+    # the job must be what the line says: every rank in the communicator, every pair's record gathered
+    bad = []
+    if use_dist and n_ranks_seen != args.gpus:
+        bad.append('the communicator has %d ranks, --gpus is %d' % (n_ranks_seen, args.gpus))
+    if metrics is not None and metrics.shape[0] != P * world:
+        bad.append('%d pair records gathered, %d pairs per GPU x %d ranks expected' % (metrics.shape[0], P, world))
+    if metrics is not None and sorted(int(v) for v in metrics[:, 0]) != list(range(P * world)):
+        bad.append('the gathered pair ids are not 0..%d each once' % (P * world - 1))
+    if bad:
+        if use_dist:
+            dist.destroy_process_group()
+        sys.exit('bench.py: ' + '; '.join(bad) + ' -- no line printed')
 
     if rank != 0:
         if use_dist:
@@ -502,22 +613,38 @@ def main():
     if use_dist:
         # proof in the line that the job was what it says: members the RCCL communicator has (an all-reduce of ones), every rank's
         # own loop time, the gathered metric rows, the CPUs rank 0 bound itself to (its GPU's NUMA node; null: not exposed)
+        from multipoint_amd.dist import RECORD_FIELDS
         out['ranks'] = {'ranks_seen': n_ranks_seen, 'per_rank_ms_per_step': per_rank_ms,
                         'gathered_records': int(metrics.shape[0]) if metrics is not None else None,
+                        'record_fields': list(RECORD_FIELDS),
                         'rank0_cpu_affinity': ('%d CPUs: %d-%d' % (len(cpu_set), cpu_set[0], cpu_set[-1])) if cpu_set else None}
-    if metrics is not None:
-        out['pair_metrics'] = {'pairs': int(metrics.shape[0]), 'mean_kp_optical': float(metrics[:, 1].mean()),
-                               'mean_kp_thermal': float(metrics[:, 2].mean()),
-                               'mean_matches': float(metrics[:, 3].mean())}
     if world == 1 and not args.no_cpu_baseline:
+        if orig_affinity is not None:
+            os.sched_setaffinity(0, orig_affinity)                # the CPU figure is the host's, not one NUMA node's
         cb, cres, prob_cpu, desc_cpu = cpu_baseline(sd, cfg, min(P, 2 if c5 else 16), H, W, PRED)
         out['cpu_baseline'] = cb
         if not args.forward_only:
             out['parity'] = parity_block(res, net, images, flags, cres, prob_cpu, desc_cpu, PRED, H, W)
+            per_pair = out['parity'].pop('_desc_err_per_pair')
+            metrics[:len(per_pair), 7] = per_pair                # desc_err of the records the parity leg checked (world 1: no gather needed)
             if not c5:
                 out['parity']['structured'] = parity_structured(PRED, H, W, device)
     else:
         out['cpu_baseline'] = None
+    if metrics is not None:
+        # means over the gathered per-pair records (fields: multipoint_amd.dist.RECORD_FIELDS); the stage times are those of the
+        # untimed extra step each rank ran with timing events, the descriptor error only exists where a parity leg checked the pair
+        checked = metrics[~np.isnan(metrics[:, 7]), 7]
+        out['pair_metrics'] = {'pairs': int(metrics.shape[0]), 'mean_kp_optical': float(metrics[:, 1].mean()),
+                               'mean_kp_thermal': float(metrics[:, 2].mean()),
+                               'mean_matches': float(metrics[:, 3].mean()),
+                               't_forward_ms': round(float(metrics[:, 4].mean()), 4), 't_nms_ms': round(float(metrics[:, 5].mean()), 4),
+                               't_match_ms': round(float(metrics[:, 6].mean()), 4),
+                               'desc_err_max': float(checked.max()) if checked.size else None, 'desc_err_pairs_checked': int(checked.size)}
+    if world == 1 and not use_dist and not args.no_secondary and not args.forward_only and not args.host_input and not c5:
+        del pipe, net, images
+        torch.cuda.empty_cache()
+        out['secondary'] = secondary_block(device)
     print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()

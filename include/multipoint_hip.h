@@ -64,7 +64,8 @@ typedef struct mp_model_config {
      * winograd43_general: the same arithmetic on the any-frame-size kernel only; 3 direct: implicit-GEMM convolution, a k-ordered
      * fp32 multiply-add chain per output like the reference's -- keeps exact ties, 2.4x slower.  INTEGRATION.md has the numbers. */
     int conv_algorithm;
-    /* 1: a forward's output bits do not depend on how many images it holds.  By default (0) forwards of ONE or TWO images --
+    /* 1: a forward's output bits do not depend on how many images it holds.  By default (0) forwards of ONE or TWO images (counted over
+     * the whole forward, not per encoder of a multispectral model) --
      * the reference's shipped batchsize 1 -- run launches that are too small to fill the GPU with their input channels cut into
      * ranges (single-pair latency: 0.51 instead of 0.56 ms at 480x640, 0.33 instead of 0.44 ms at 240x320), which sums the same products in another order than the
      * batched launch does: equal within 3e-5 (prob) / 3e-6 (desc), deterministic from run to run, but not bit-identical to the

@@ -66,6 +66,7 @@ struct mp_handle {
     DevBuf ws4;                     // pair metrics: warped keypoints + inverse match map
     DevBuf split_ws;                // F(4x4,3x3) split launches: the ranges' pre-bias output tiles
     int splitk_max = 8;             // most ranges the input channels of a small launch are cut into (MP_SPLITK_MAX; 1: never)
+    int fwd_batch = 0;              // images of the forward in flight: the split launches are gated on THIS, not on an encoder's share of it
     int splitk_env = 8;             // ... as mp_create set it (model.batch_invariant overrides it per loaded model)
     DevBuf nms_state;               // 64 round counters + tile flags
     DevBuf kp_scratch;              // segment counts + list totals of the keypoint compaction
@@ -82,6 +83,8 @@ struct mp_handle {
     bool head_fuse = true;          // MP_NO_HEAD_FUSE=1: separate 1x1 convolution / softmax / normalisation launches
     bool fuse43 = true;             // first block evaluated inside the F(4x4,3x3) conv2 kernel (MP_NO_FUSE43=1: its own launch)
     int wino43_gen = 0;             // MP_WINO43_GEN: 0 conv_wino43.hip where it applies, conv_wino43b.hip for every other shape; 1 / 2: only that kernel
+    bool wino_env = true;           // wino / wino43 / wino43_gen as mp_create read them: mp_load_weights starts from these and
+    int wino43_env = 2, wino43_gen_env = 0;   // applies the model's conv_algorithm on top (a reload never inherits the previous model's)
     int* pinned = nullptr;          // small pinned host scratch (img lists, counters)
     bool f16_res = true;            // MP_F16_NO_RES=1: the streaming kernel (conv_f16.hip) also for the 64 -> 64 layers
     bool f16_fuse1 = true;          // MP_F16_NO_FUSE1=1: the first block of the fp16 path as its own launch
@@ -552,7 +555,7 @@ int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, 
     int big;
     if (f43) {
         p.wpack = L.u43pack; p.in_planar = in_planar; p.out_planar = out_planar;
-        if (!fuse && B <= 2 && h->splitk_max > 1) {
+        if (!fuse && h->fwd_batch <= 2 && h->splitk_max > 1) {
             // single-pair latency (the reference's shipped batchsize: 1): a launch with fewer items than half the CUs (conv7 /
             // conv8 of one 480x640 pair: 40 items of 32 units on 256 CUs) cuts the input channels into 2, 4 or 8 ranges --
             // (cin / 4) / ranges units each, even and >= 4 -- as long as the items still fit the machine once.  Only for
@@ -871,6 +874,7 @@ int mp_create(mp_handle** out, int device)
     { const char* e = getenv("MP_NO_PERSIST"); if (e && e[0] == '1') hh->persist = 0; }
     { const char* e = getenv("MP_SPLITK_MAX"); if (e && atoi(e) >= 1 && atoi(e) <= 8) hh->splitk_max = atoi(e); }
     hh->splitk_env = hh->splitk_max;
+    hh->wino_env = hh->wino; hh->wino43_env = hh->wino43; hh->wino43_gen_env = hh->wino43_gen;
     if (hipHostMalloc(reinterpret_cast<void**>(&hh->pinned), 4096) != hipSuccess) {
         delete hh;
         return fail(h, MP_ENOMEM, "mp_create: hipHostMalloc failed");
@@ -918,6 +922,7 @@ int mp_load_weights(mp_handle* h, const mp_model_config* cfg, const mp_tensor* t
     h->cfg = *cfg;
     // the convolution algorithm of the 3x3 layers is a MODEL setting (yaml model.conv_algorithm); the MP_* environment switches of
     // mp_create only apply to 'auto'
+    h->wino = h->wino_env; h->wino43 = h->wino43_env; h->wino43_gen = h->wino43_gen_env;     // 0 auto: what mp_create chose
     if (cfg->conv_algorithm == 1) { h->wino = true; h->wino43 = 2; h->wino43_gen = 0; }
     else if (cfg->conv_algorithm == 2) { h->wino = true; h->wino43 = 2; h->wino43_gen = 2; }
     else if (cfg->conv_algorithm == 3) { h->wino = false; }
@@ -1008,6 +1013,7 @@ static int forward_checked(mp_handle* h, const float* images, const unsigned cha
     // encoder(s): multispectral routes each image by is_optical (MultiPoint.py:107-122)
     int nsets = 1, counts[2] = {B, 0};
     const int* lptr[2] = {nullptr, nullptr};
+    h->fwd_batch = B;
     if (h->cfg.multispectral) {
         if (B > 512) return fail(h, MP_EINVAL, "mp_forward: multispectral B > 512 unsupported");
         nsets = 2;

@@ -24,28 +24,60 @@ def hw_queues_note():
             'runtime_initialised_at_query': bool(torch.cuda.is_initialized())}
 
 
-def bind_rank_to_numa_node(local_rank):
-    """Pin this rank's threads to the CPUs of its GPU's NUMA node (eight Python launch loops otherwise wander over the
-    sockets of a 256-CPU host).  Reads /sys/class/drm/card*/device/{numa_node,local_cpulist} -- no GPU call, so it can and
-    should run before the first one.  Returns the CPU set it bound to, or None when the topology is not exposed (then
-    nothing changes): binding is an optimisation, never a requirement."""
-    import glob
+def _visible_device_index(local_rank):
+    """The PHYSICAL index (KFD / ROCr enumeration order) of the GPU HIP device `local_rank` is, honouring HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when they are plain integer lists.  None when a filter is set that cannot be
+    mapped by hand (UUIDs, or two filters at once): the caller then does not bind at all -- a wrong node is worse than none."""
+    filters = [os.environ[k] for k in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES')
+               if os.environ.get(k, '') != '']
+    if not filters:
+        return local_rank
+    if len(filters) > 1 and len(set(filters)) > 1:
+        return None
     try:
-        cards = sorted(glob.glob('/sys/class/drm/card[0-9]*/device/local_cpulist'),
-                       key=lambda q: int(''.join(ch for ch in q.split('/')[4] if ch.isdigit()) or 0))
-        # render nodes without a compute device (ASPEED etc.) have no 'vendor' 0x1002: keep AMD GPUs only
-        gpus = []
-        for q in cards:
-            d = os.path.dirname(q)
-            try:
-                if open(os.path.join(d, 'vendor')).read().strip() == '0x1002':
-                    gpus.append(d)
-            except OSError:
-                pass
-        if local_rank >= len(gpus):
+        ids = [int(x) for x in filters[0].split(',') if x.strip() != '']
+    except ValueError:
+        return None
+    return ids[local_rank] if local_rank < len(ids) else None
+
+
+def _kfd_gpu_nodes():
+    """GPUs in KFD enumeration order (the order ROCr, and with it HIP, numbers them): [(node, 'dddd:bb:dd.f')] from
+    /sys/class/kfd/kfd/topology/nodes/*/properties (CPU nodes have simd_count 0).  No GPU context needed."""
+    import glob
+    out = []
+    for d in sorted(glob.glob('/sys/class/kfd/kfd/topology/nodes/[0-9]*'), key=lambda q: int(q.rsplit('/', 1)[1])):
+        props = {}
+        try:
+            for line in open(os.path.join(d, 'properties')):
+                k, _, v = line.strip().partition(' ')
+                props[k] = v
+        except OSError:
+            continue
+        if int(props.get('simd_count', '0') or 0) == 0:
+            continue
+        loc = int(props.get('location_id', '0') or 0)
+        dom = int(props.get('domain', '0') or 0)
+        out.append((int(d.rsplit('/', 1)[1]), '%04x:%02x:%02x.%x' % (dom, (loc >> 8) & 0xff, (loc >> 3) & 0x1f, loc & 7)))
+    return out
+
+
+def bind_rank_to_numa_node(local_rank):
+    """Pin this rank to the CPUs of its GPU's NUMA node (eight Python launch loops otherwise wander over the sockets of a
+    256-CPU host).  The GPU is resolved through its PCI bus id -- KFD topology order = HIP device order, filtered by the
+    *_VISIBLE_DEVICES variables when they are integer lists -- and /sys/bus/pci/devices/<bdf>/local_cpulist: no GPU call, so it
+    can and should run before the first one.  Returns the CPU set it bound to, or None when the topology is not exposed or a
+    device filter cannot be mapped (then nothing changes): binding is an optimisation, never a requirement.
+    `os.sched_setaffinity(0, ...)` moves the CALLING thread and the threads it creates afterwards; threads that already exist
+    (an imported library's pools) keep their affinity -- call this first thing in the rank program."""
+    try:
+        phys = _visible_device_index(local_rank)
+        gpus = _kfd_gpu_nodes()
+        if phys is None or phys >= len(gpus):
             return None
+        path = os.path.join('/sys/bus/pci/devices', gpus[phys][1], 'local_cpulist')
         cpus = set()
-        for part in open(os.path.join(gpus[local_rank], 'local_cpulist')).read().strip().split(','):
+        for part in open(path).read().strip().split(','):
             if not part:
                 continue
             lo, _, hi = part.partition('-')
@@ -85,17 +117,35 @@ def shard_pairs(num_pairs, rank, world_size):
     return list(range(rank, num_pairs, world_size))
 
 
-def pair_metric_records(res, pair_ids):
-    """Per-pair metric rows [pair_id, n_kp_optical, n_kp_thermal, n_matches] (int32, on the device of `res`) of one
-    PairResults batch whose pair i has global id pair_ids[i]: keypoint counts are clamped to the list capacity like
-    PairResults.to_host().  This is the record the ranks gather."""
+# the per-pair record the ranks gather, one float64 row per pair
+RECORD_FIELDS = ('pair_id', 'n_kp_a', 'n_kp_b', 'n_matches', 't_forward', 't_nms', 't_match', 'desc_err')
+
+
+def pair_metric_records(res, pair_ids, stage_ms=None, desc_err=None):
+    """Per-pair metric rows `RECORD_FIELDS` (float64, on the device of `res`; ids and counts are exact in a double) of one
+    PairResults batch whose pair i has global id pair_ids[i].  n_kp_a / n_kp_b: keypoints of the optical / thermal image,
+    clamped to the list capacity like PairResults.to_host(); t_forward / t_nms / t_match: milliseconds the BATCH this pair was
+    in spent in the forward, in box-NMS + top-k + keypoint lists, and in descriptor sampling + matching (`stage_ms`, e.g.
+    PairResults.stage_ms() of a run with `timings=True`; pairs of one batch share them; NaN: not timed); desc_err: this pair's
+    largest descriptor deviation from the CPU reference path when a parity leg checked it (NaN: not checked)."""
     K = res.kp_yx.shape[1]
     dev = res.kp_count.device
-    ids = torch.as_tensor(list(pair_ids), dtype=torch.int32, device=dev)
-    if ids.numel() != res.match_count.shape[0]:
-        raise ValueError('pair_ids has %d entries for %d pairs' % (ids.numel(), res.match_count.shape[0]))
-    return torch.stack([ids, res.kp_count[0::2].clamp(max=K).to(torch.int32), res.kp_count[1::2].clamp(max=K).to(torch.int32),
-                        res.match_count.to(torch.int32)], dim=1)
+    n = res.match_count.shape[0]
+    ids = torch.as_tensor(list(pair_ids), dtype=torch.float64, device=dev)
+    if ids.numel() != n:
+        raise ValueError('pair_ids has %d entries for %d pairs' % (ids.numel(), n))
+    nan = float('nan')
+    st = [nan, nan, nan] if stage_ms is None else [float(stage_ms[k]) for k in ('forward', 'nms', 'match')]
+    if desc_err is None:
+        de = torch.full((n,), nan, dtype=torch.float64, device=dev)
+    else:
+        de = torch.as_tensor([nan if v is None else float(v) for v in desc_err], dtype=torch.float64, device=dev)
+        if de.numel() != n:
+            raise ValueError('desc_err has %d entries for %d pairs' % (de.numel(), n))
+    cols = [ids, res.kp_count[0::2].clamp(max=K).to(torch.float64), res.kp_count[1::2].clamp(max=K).to(torch.float64),
+            res.match_count.to(torch.float64)]
+    cols += [torch.full((n,), v, dtype=torch.float64, device=dev) for v in st] + [de]
+    return torch.stack(cols, dim=1)
 
 
 def gather_pair_metrics(records):

@@ -22,6 +22,17 @@ class PairResults:
         self.H, self.W = H, W
         self.done = None            # event recorded on the stream that produced these tensors
         self.inputs_consumed = None # event: the forward has read the input images (they may be overwritten after it)
+        self.stage_events = None    # run_interleaved(timings=True): (forward begin, forward end, post begin, keypoints done, matches done)
+
+    def stage_ms(self):
+        """Milliseconds this batch spent per stage (synchronises): {'forward', 'nms' (box-NMS + top-k + keypoint lists),
+        'match' (descriptor sampling + mutual-NN matching)} -- the t_forward / t_nms / t_match of the gathered per-pair record
+        (multipoint_amd.dist.pair_metric_records).  None unless the batch ran with `timings=True`."""
+        if self.stage_events is None:
+            return None
+        f0, f1, p0, p1, p2 = self.stage_events
+        p2.synchronize()
+        return {'forward': f0.elapsed_time(f1), 'nms': p0.elapsed_time(p1), 'match': p1.elapsed_time(p2)}
 
     def wait(self):
         """Make the current stream wait for the post-processing stream that produced the results."""
@@ -94,7 +105,7 @@ class PairPipeline:
         P = optical.shape[0]
         return torch.stack((optical, thermal), dim=1).reshape(2 * P, *optical.shape[1:])
 
-    def run_interleaved(self, images, valid_mask=None, is_optical=None, order_caller=True):
+    def run_interleaved(self, images, valid_mask=None, is_optical=None, order_caller=True, timings=False):
         """One batch: the forward on a high-priority stream of the pipeline's own, then NMS / top-k / sampling / matching
         on a second side stream (`overlap_post=True`): those kernels are small and latency-bound, so they run in the
         shadow of the NEXT batch's convolutions instead of serialising behind this one.  The returned tensors belong to
@@ -105,7 +116,8 @@ class PairPipeline:
         for callers that never touch `images` again (or wait on `inputs_consumed` themselves): the caller's stream then stays
         idle, and the NEXT call need not order the forward stream behind it -- a cross-queue dependency that costs ~40 us of
         idle GPU between two forwards (`rocprofv3 --kernel-trace`: 55 instead of 13 us between the head tail of batch n and the
-        first convolution of batch n+1)."""
+        first convolution of batch n+1).  `timings=True` brackets the stages with timing events (`PairResults.stage_ms()`); off by
+        default -- a timing event is a packet of its own in the queue."""
         dev = images.device
         B, _, H, W = images.shape
         if B % 2:
@@ -113,6 +125,7 @@ class PairPipeline:
         if is_optical is None:
             is_optical = (torch.arange(B) % 2 == 0).reshape(B, 1)
         main = torch.cuda.current_stream(dev)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)] if timings else None
         if self.overlap_post:
             # Two streams of the pipeline's own: the forward on a HIGH-priority one, the post-processing on a normal one.  A
             # convolution workgroup needs a whole CU; when batch n's post-processing and batch n+1's first convolution become
@@ -126,8 +139,10 @@ class PairPipeline:
             if not main.query():                                    # the inputs were produced on the caller's stream: wait for whatever
                 fwd.wait_stream(main)                               # is still pending there (nothing, in a steady pipeline: no packet)
             with torch.cuda.stream(fwd):
+                if timings:
+                    ev[0].record(fwd)
                 out = self.net({'image': images, 'is_optical': is_optical})
-                consumed = torch.cuda.Event()
+                consumed = ev[1] if timings else torch.cuda.Event()
                 consumed.record(fwd)
             if order_caller:
                 main.wait_event(consumed)                           # the caller's stream stays ordered behind the forward
@@ -139,14 +154,20 @@ class PairPipeline:
                 if t is not None:
                     t.record_stream(post)
         else:
+            if timings:
+                ev[0].record(main)
             out = self.net({'image': images, 'is_optical': is_optical})
             post = main
-            consumed = torch.cuda.Event()
+            consumed = ev[1] if timings else torch.cuda.Event()
             consumed.record(main)
         with torch.cuda.stream(post):
-            res = self._post(out, valid_mask, dev, B, H, W)
-            res.done = torch.cuda.Event()
+            if timings:
+                ev[2].record(post)
+            res = self._post(out, valid_mask, dev, B, H, W, mark=(lambda: ev[3].record(post)) if timings else None)
+            res.done = ev[4] if timings else torch.cuda.Event()
             res.done.record(post)
+        if timings:
+            res.stage_events = tuple(ev)
         res.inputs_consumed = consumed
         self._last = res
         return res
@@ -155,7 +176,7 @@ class PairPipeline:
         """A list of K slots holds every keypoint the reference would return iff top-k limits them to <= K."""
         return self.nms > 0 and 0 < self.topk <= K
 
-    def _post(self, out, valid_mask, dev, B, H, W, nms_rounds=None, capacity=None):
+    def _post(self, out, valid_mask, dev, B, H, W, nms_rounds=None, capacity=None, mark=None):
         prob = out['prob']
         if self.nms > 0:
             # `topk: 0` (the shipped configs, like the reference's) = unlimited: 4096 slots is a first guess that
@@ -166,6 +187,8 @@ class PairPipeline:
                                              max_rounds=self.nms_rounds if nms_rounds is None else nms_rounds)
         else:
             kp, sc, cnt = U.extract_keypoints(prob, self.thr, capacity=capacity or self.capacity or 4096, valid_mask=valid_mask)
+        if mark is not None:
+            mark()                  # keypoint lists done (stage timing)
         K = kp.shape[1]
         desc = U.interpolate_descriptors_batched(kp, cnt, out['desc'], H, W)        # [B,K,D]
         D = desc.shape[2]

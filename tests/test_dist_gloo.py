@@ -52,12 +52,17 @@ def _results_for(pair_ids, K=50):
                        match_count, 64, 64)
 
 
+def _stage_ms(rank):
+    return {'forward': 9.0 + rank, 'nms': 0.25 + rank, 'match': 0.125 + rank}
+
+
 def _worker_results(rank, world, port, n_pairs, out_dir):
     os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = str(port)
     dist.init_process_group('gloo', rank=rank, world_size=world)
     from multipoint_amd.dist import shard_pairs, gather_pair_metrics, pair_metric_records
     mine = shard_pairs(n_pairs, rank, world)
-    allrec = gather_pair_metrics(pair_metric_records(_results_for(mine), mine))      # exactly bench.py's gather
+    allrec = gather_pair_metrics(pair_metric_records(_results_for(mine), mine, stage_ms=_stage_ms(rank),
+                                                     desc_err=[1e-6 * p if p % 2 else None for p in mine]))      # exactly bench.py's gather
     torch.save(allrec, os.path.join(out_dir, 'rank%d.pt' % rank))
     dist.barrier()
     dist.destroy_process_group()
@@ -69,11 +74,18 @@ def test_gather_records_of_pair_results_world2(tmp_path):
     n_pairs, world = 9, 2
     mp.spawn(_worker_results, args=(world, _free_port(), n_pairs, str(tmp_path)), nprocs=world, join=True)
     a = torch.load(tmp_path / 'rank0.pt'); b = torch.load(tmp_path / 'rank1.pt')
-    assert torch.equal(a, b) and a.dtype == torch.int32 and a.shape == (n_pairs, 4)
+    from multipoint_amd.dist import RECORD_FIELDS
+    assert RECORD_FIELDS == ('pair_id', 'n_kp_a', 'n_kp_b', 'n_matches', 't_forward', 't_nms', 't_match', 'desc_err')
+    assert torch.equal(a.nan_to_num(-1.0), b.nan_to_num(-1.0)) and a.dtype == torch.float64 and a.shape == (n_pairs, 8)
     single = pair_metric_records(_results_for(list(range(n_pairs))), list(range(n_pairs)))
     order = torch.argsort(a[:, 0])
-    assert torch.equal(a[order], single)                     # same rows as one rank processing every pair
+    assert torch.equal(a[order][:, :4], single[:, :4])       # ids and counts: same rows as one rank processing every pair
+    assert torch.isnan(single[:, 4:]).all()                  # nothing timed, nothing checked: NaN, not zero
     assert int(a[:, 1].max()) <= 50 and int(a[:, 2].max()) <= 50      # counts clamped to the list capacity
+    for row in a.tolist():
+        p = int(row[0]); r = p % world                      # the stage times are those of the rank (batch) that owned the pair
+        assert row[4:7] == [9.0 + r, 0.25 + r, 0.125 + r]
+        assert (row[7] == 1e-6 * p) if p % 2 else (row[7] != row[7])
 
 
 def test_shard_pairs_partition():
@@ -99,7 +111,7 @@ def _worker_rank_program(rank, world, port, n_pairs, out_dir):
     t = torch.tensor([dt], dtype=torch.float64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     rec = gather_pair_metrics(pair_metric_records(_results_for(mine), mine)) if mine else \
-        gather_pair_metrics(torch.zeros((0, 4), dtype=torch.int32))
+        gather_pair_metrics(torch.zeros((0, 8), dtype=torch.float64))
     torch.save({'max': float(t.item()), 'per_rank': gather_scalar(dt, 'cpu'), 'seen': ranks_seen('cpu'), 'rec': rec,
                 'bound': bound}, os.path.join(out_dir, 'rank%d.pt' % rank))
     dist.barrier()
@@ -117,8 +129,9 @@ def test_rank_program_world4_ragged(tmp_path):
     for o in outs:
         assert o['seen'] == world and abs(o['max'] - 0.040) < 1e-12
         assert [round(v, 6) for v in o['per_rank']] == [0.01, 0.02, 0.03, 0.04]
-        assert torch.equal(o['rec'], outs[0]['rec']) and o['rec'].shape == (n_pairs, 4)
-        assert torch.equal(o['rec'][torch.argsort(o['rec'][:, 0])], single)
+        assert torch.equal(o['rec'].nan_to_num(-1.0), outs[0]['rec'].nan_to_num(-1.0)) and o['rec'].shape == (n_pairs, 8)
+        assert o['rec'].dtype == torch.float64
+        assert torch.equal(o['rec'][torch.argsort(o['rec'][:, 0])].nan_to_num(-1.0), single.nan_to_num(-1.0))
         assert o['bound'] is None or len(o['bound']) > 0
 
 
@@ -126,3 +139,22 @@ def test_rank_helpers_without_a_process_group():
     from multipoint_amd.dist import gather_scalar, hw_queues_note, ranks_seen
     assert ranks_seen('cpu') == 1 and gather_scalar(1.5, 'cpu') == [1.5]
     assert hw_queues_note()['GPU_MAX_HW_QUEUES'] is not None      # importing multipoint_amd.dist sets the deployment default
+
+
+def test_numa_binding_resolves_the_visible_device(monkeypatch):
+    """bind_rank_to_numa_node maps the local rank through the *_VISIBLE_DEVICES filters (integer lists) and refuses what it cannot
+    map -- binding to another GPU's node would be worse than not binding (round-4 advisor)."""
+    from multipoint_amd import dist as D
+    for k in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        monkeypatch.delenv(k, raising=False)
+    assert D._visible_device_index(3) == 3
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '4,5,6,7')
+    assert D._visible_device_index(1) == 5 and D._visible_device_index(4) is None
+    monkeypatch.setenv('CUDA_VISIBLE_DEVICES', '4,5,6,7')
+    assert D._visible_device_index(0) == 4                       # the same filter twice: fine
+    monkeypatch.setenv('ROCR_VISIBLE_DEVICES', '1,0')
+    assert D._visible_device_index(0) is None                    # two different filters: composition is not ours to guess
+    monkeypatch.delenv('HIP_VISIBLE_DEVICES'); monkeypatch.delenv('CUDA_VISIBLE_DEVICES')
+    monkeypatch.setenv('ROCR_VISIBLE_DEVICES', 'GPU-deadbeef')
+    assert D._visible_device_index(0) is None                    # UUIDs cannot be mapped without a GPU call
+    assert D.bind_rank_to_numa_node(0) is None                   # and then nothing is bound

@@ -116,6 +116,41 @@ def test_split_input_channels_on_small_launches(oracle, monkeypatch, B, H, W, ge
     assert (a['prob'] - b['prob']).abs().max().item() <= 3e-5 and (a['desc'] - b['desc']).abs().max().item() <= 3e-6
 
 
+def test_reload_restores_auto_algorithm(oracle):
+    """mp_load_weights starts every load from the switches mp_create read (round-4 advisor): a handle that held a `direct` (or
+    `winograd43_general`) model and is reloaded with `auto` must run what a fresh `auto` handle runs, bit for bit."""
+    cfg = dict(oracle.SHIPPED_MODEL_CONFIG)
+    fresh, sd = _net(oracle, cfg, seed=4)
+    img = oracle.make_images(77, 3, 120, 160).cuda()
+    want = fresh({'image': img})
+    for first in ('direct', 'winograd43_general'):
+        net, _ = _net(oracle, dict(cfg, conv_algorithm=first), seed=4)
+        other = net({'image': img})
+        assert not torch.equal(other['desc'], want['desc'])           # the first load really ran another algorithm
+        net.config['conv_algorithm'] = 'auto'
+        net.load_state_dict(sd)                                       # same handle, reloaded
+        got = net({'image': img})
+        assert torch.equal(got['prob'], want['prob']) and torch.equal(got['desc'], want['desc']), first
+
+
+def test_split_launch_gate_is_the_whole_forward(oracle):
+    """The split small launches are gated on the forward's image count, not on one encoder's share of it (round-4 advisor):
+    a multispectral forward of 4 interleaved images (2 per encoder) or of 6 images with ONE thermal image has the bits of the same
+    images inside a larger batch, without `batch_invariant`."""
+    cfg = dict(oracle.SHIPPED_MODEL_CONFIG, multispectral=True)
+    net, _ = _net(oracle, cfg, seed=6)
+    img = oracle.make_images(31, 8, 240, 320).cuda()
+    opt = torch.tensor([[True], [False]] * 4).cuda()
+    big = net({'image': img, 'is_optical': opt})
+    part = net({'image': img[:4], 'is_optical': opt[:4]})
+    assert torch.equal(part['prob'], big['prob'][:4]) and torch.equal(part['desc'], big['desc'][:4])
+    opt1 = torch.tensor([[True]] * 5 + [[False]]).cuda()
+    six = net({'image': img[:6], 'is_optical': opt1})
+    opt2 = torch.tensor([[True]] * 5 + [[False]] + [[False], [True]]).cuda()
+    eight = net({'image': img, 'is_optical': opt2})
+    assert torch.equal(six['prob'], eight['prob'][:6]) and torch.equal(six['desc'], eight['desc'][:6])
+
+
 @pytest.mark.parametrize('H,W', [(480, 640), (240, 320)])
 def test_batch_invariant_setting(oracle, H, W):
     """model.batch_invariant (mp_model_config.batch_invariant): forwards of one or two images leave the split small launches out,
