@@ -224,14 +224,25 @@ def parity_structured(PRED, H, W, device, n_pairs=4):
     prob_cpu = O.forward(sd, img, cfg)['prob'].numpy()
     nms_fn = lambda m: O.box_nms(m, PRED['nms'], PRED['detection_threshold'], keep_top_k=0)
     rec = {'pairs': n_pairs, 'images': 'oracle/trained_like.py structured_images(4, %d, %d, %d), weights trained_like_weights(1, wide)' % (2 * n_pairs, H, W)}
+    from multipoint_amd.pipeline import PairPipeline
     for algo in ('auto', 'direct'):
         c = dict(cfg); c['conv_algorithm'] = algo
         net = models.MultiPoint(c); net.load_state_dict(sd); net.to(device); net.eval()
-        prob_gpu = net({'image': img.to(device)})['prob'].cpu().numpy()
-        s, _ = FA.account_batch(prob_cpu, prob_gpu, nms_fn, PRED['nms'], PRED['detection_threshold'], 0.1, PRED['topk'])
-        rec[algo] = {'keypoints_total': s['keypoints_total'], 'keypoints_differing': s['keypoints_differing'],
-                     'explained': s['keypoints_differing'] - s['unexplained'], 'unexplained': s['unexplained'],
-                     'max_unexplained_margin': s['max_unexplained_margin'], 'max_prob_abs_err': s['max_prob_err']}
+        # `auto` / `direct`: the heat map the product's drivers take keypoints from -- PairPipeline.run_converged, which re-evaluates
+        # images flagged by the top-k tie guard with the tie-exact algorithm; `auto_raw_forward`: the default forward alone (what the
+        # throughput entry keeps; round 4 reported this as `auto`)
+        pipe = PairPipeline(net, PRED, capacity=PRED['topk'], keep_maps=True)
+        res = pipe.run_converged(img.to(device))
+        runs = [(algo, res.prob.cpu().numpy(), pipe.tie_redone)]
+        if algo == 'auto':
+            runs.append(('auto_raw_forward', net({'image': img.to(device)})['prob'].cpu().numpy(), None))
+        for name, prob_gpu, redone in runs:
+            s, _ = FA.account_batch(prob_cpu, prob_gpu, nms_fn, PRED['nms'], PRED['detection_threshold'], 0.1, PRED['topk'])
+            rec[name] = {'keypoints_total': s['keypoints_total'], 'keypoints_differing': s['keypoints_differing'],
+                         'explained': s['keypoints_differing'] - s['unexplained'], 'unexplained': s['unexplained'],
+                         'max_unexplained_margin': s['max_unexplained_margin'], 'max_prob_abs_err': s['max_prob_err']}
+            if redone is not None:
+                rec[name]['images_redone_by_tie_guard'] = redone
     return rec
 
 
@@ -259,7 +270,8 @@ def secondary_block(device):
 
     def build(cfg, pred, pairs, h, w):
         net = models.MultiPoint(cfg); net.load_state_dict(make_weights(0, cfg)); net.to(device); net.eval()
-        pipe = PairPipeline(net, pred, capacity=pred['topk'] or None, nms_rounds=8)
+        # (topk 0 = unlimited: 8192 slots hold the ~5000 keypoints these images have; run_converged would regrow them anyway)
+        pipe = PairPipeline(net, pred, capacity=pred['topk'] or 8192, nms_rounds=8)
         images = make_batch(list(range(pairs)), device, h, w)
         flags = (torch.arange(2 * pairs) % 2 == 0).reshape(-1, 1)
         return net, pipe, images, flags
@@ -332,7 +344,8 @@ def main():
                     help='secondary measurement (never the headline value): every step first uploads its batch from pinned '
                          'host memory on a copy stream, double-buffered, overlapping the previous step (PCIe-inclusive rate)')
     ap.add_argument('--no-secondary', action='store_true',
-                    help='skip the `secondary` object of the N = 1 line (c5 / direct / batchsize-1 rates, ~15 s)')
+                    help='skip the `secondary` object of the plain N = 1 line (c5 / direct / batchsize-1 rates, ~15 s; also skipped with '
+                         '--no-cpu-baseline, --forward-only, --host-input, --workload c5 and under torchrun)')
     ap.add_argument('--workload', choices=['c3', 'c5'], default='c3',
                     help='c3 (default, headline): 480x640 fp32 top-k 1000; c5: 1024x1280 fp16 MFMA path top-k 2000')
     args = ap.parse_args()
@@ -460,8 +473,10 @@ def main():
 
     # per-pair metric records, gathered over RCCL (the only collective of the path)
     metrics = None
+    tie_flagged = None
     if not args.forward_only:
         pipe.check_converged(device)
+        tie_flagged = pipe.tie_flagged      # images of the timed steps whose top-k cut fell inside a plateau of tied scores (reported only)
         # one more step, OUTSIDE the timed region, with the stages bracketed by timing events: t_forward / t_nms / t_match of the
         # record are this rank's batch times with nothing else in flight
         fence()
@@ -608,6 +623,9 @@ def main():
         # direct-convolution roofline, not a utilisation: > 1 with Winograd layers)
         'whole_path_algorithmic_vs_direct_mfma_roofline': round(value / world * gflop_pair / 1e3 / peak, 4),
         'forward_tflops': round(conv_flop / (conv_ms * 1e-3) / 1e12, 2) if conv_ms > 0 else None,
+        # top-k tie guard: the throughput entry (run_interleaved) only REPORTS images whose top-k cut fell inside a plateau of
+        # (near-)tied scores; run_converged re-evaluates them with conv_algorithm direct (parity.structured)
+        'topk_tie_flagged_images_in_timed_steps': tie_flagged,
         'layer_ms': layers,
     }
     if use_dist:
@@ -641,7 +659,7 @@ def main():
                                't_forward_ms': round(float(metrics[:, 4].mean()), 4), 't_nms_ms': round(float(metrics[:, 5].mean()), 4),
                                't_match_ms': round(float(metrics[:, 6].mean()), 4),
                                'desc_err_max': float(checked.max()) if checked.size else None, 'desc_err_pairs_checked': int(checked.size)}
-    if world == 1 and not use_dist and not args.no_secondary and not args.forward_only and not args.host_input and not c5:
+    if world == 1 and not use_dist and not args.no_secondary and not args.no_cpu_baseline and not args.forward_only and not args.host_input and not c5:
         del pipe, net, images
         torch.cuda.empty_cache()
         out['secondary'] = secondary_block(device)

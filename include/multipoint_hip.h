@@ -128,6 +128,20 @@ int mp_detect_keypoints(mp_handle* h, const float* prob, const unsigned char* va
  * the previous mp_nms_unresolved (0 = every result exact); resets the counter.  Synchronises `stream`. */
 int mp_nms_unresolved(mp_handle* h, int* unresolved, void* stream);
 
+/* Top-k tie guard (no reference counterpart; it exists because the reference's list is a function of EXACT score order,
+ * multipoint/utils/utils.py:97-116: score-ordered indices, per-image [:keep_top_k]).  The default convolution algorithm
+ * (Winograd F(4x4,3x3)) equals the fp32 reference within ~1e-5 in prob, which reorders exact ties of the heat map; when the
+ * top-k cut of an image falls inside a plateau of (near-)tied scores, WHICH members of the plateau are kept is then decided by
+ * that noise.  mp_box_nms / mp_detect_keypoints (keep_top_k > 0) therefore count, per image, the NMS survivors whose score lies
+ * within `eps` (default 6e-5: the measured prob noise) of the k-th score -- admitted ones and cut-off ones separately -- and flag
+ * the image when BOTH counts reach `min_each_side` (default 4; 0 switches the guard off).  A flagged image is one whose list the
+ * caller should recompute from a forward with conv_algorithm 3 (direct), which keeps exact ties; the Python mirror does that in
+ * PairPipeline.run_converged / utils.box_nms_tie_robust, the throughput entry only reports the count.
+ *   mp_topk_ambiguous: flags [B] (host ints, 0/1) of the LATEST mp_box_nms / mp_detect_keypoints call; *total = flagged
+ *   images summed over all calls since the previous read (resets).  Synchronises `stream`. */
+int mp_topk_tie_guard(mp_handle* h, float eps, int min_each_side);
+int mp_topk_ambiguous(mp_handle* h, int* flags, int B, int* total, void* stream);
+
 /* replaces torch.nonzero(map > thr) on an arbitrary dense map; with valid_mask (uint8 [B][H][W] or NULL) it is
  * torch.nonzero((map > thr) * valid_mask) (multipoint/utils/evaluation.py:156-157, predict_keypoints.py:176-178). */
 int mp_extract_keypoints(mp_handle* h, const float* map, const unsigned char* valid_mask, int B, int H, int W, float thr,

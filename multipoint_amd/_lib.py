@@ -43,6 +43,8 @@ SIGNATURES = {
     'mp_detect_keypoints': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float,
                                     c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'mp_nms_unresolved': (c_int, [c_void_p, ctypes.POINTER(c_int), c_void_p]),
+    'mp_topk_tie_guard': (c_int, [c_void_p, c_float, c_int]),
+    'mp_topk_ambiguous': (c_int, [c_void_p, ctypes.POINTER(c_int), c_int, ctypes.POINTER(c_int), c_void_p]),
     'mp_extract_keypoints': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p,
                                      c_void_p, c_void_p, c_void_p]),
     'mp_sample_descriptors': (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,

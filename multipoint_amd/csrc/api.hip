@@ -72,6 +72,10 @@ struct mp_handle {
     DevBuf kp_scratch;              // segment counts + list totals of the keypoint compaction
     int* nms_total = nullptr;       // device: undecided candidates summed over all calls since the last read
     int last_nms_rounds = 0;
+    int* tie_state = nullptr;       // device, 1 + MP_TIE_MAX_IMAGES ints: top-k tie guard (mp_topk_ambiguous)
+    float tie_eps = 6e-5f;          // ... a survivor within this of the k-th score counts as 'at the cut' (mp_topk_tie_guard)
+    int tie_min = 4;                // ... an image is flagged when at least this many sit at the cut on EACH side of it; 0: guard off
+    int tie_last_B = 0;
     int head_channels = 256;        // width of each 3x3 head convolution (MultiPoint.py:38-53)
     void* dummy = nullptr;          // scratch line for masked-off store lanes of the fp16 kernels
     bool wino = true;               // Winograd F(4x4,3x3) for the 3x3 layers (MP_NO_WINOGRAD=1 / conv_algorithm 'direct': the direct kernels)
@@ -766,8 +770,19 @@ int nms_common(mp_handle* h, const float* prob, const unsigned char* mask, int B
         MP_HIP(hipMemsetAsync(h->nms_total, 0, 4, s));
     }
     launch_nms_accumulate(remaining, B, H, W, round - 1, h->nms_total, s);
+    int* tie = nullptr;
+    if (topk > 0 && h->tie_min > 0) {
+        if (!h->tie_state) {
+            MP_HIP(hipMalloc(reinterpret_cast<void**>(&h->tie_state), (1 + MP_TIE_MAX_IMAGES) * 4));
+            MP_HIP(hipMemsetAsync(h->tie_state, 0, (1 + MP_TIE_MAX_IMAGES) * 4, s));
+        }
+        tie = h->tie_state;
+        h->tie_last_B = B < MP_TIE_MAX_IMAGES ? B : MP_TIE_MAX_IMAGES;
+    } else {
+        h->tie_last_B = 0;
+    }
     launch_select_keypoints(work, B, H, W, topk, K, list_idx, list_score, H * W, kp_yx, kp_score, kp_count,
-                            prob_nms, static_cast<int*>(h->kp_scratch.p), s);
+                            prob_nms, static_cast<int*>(h->kp_scratch.p), s, h->tie_eps, h->tie_min, tie);
     MP_HIP(hipGetLastError());
     if (max_rounds == 0 && round >= cap) {
         MP_HIP(hipMemcpyAsync(h->pinned, remaining + ((round - 1) & 63), 4, hipMemcpyDeviceToHost, s));
@@ -896,6 +911,7 @@ void mp_destroy(mp_handle* h)
     if (h->nms_state.p) (void)hipFree(h->nms_state.p);
     if (h->kp_scratch.p) (void)hipFree(h->kp_scratch.p);
     if (h->nms_total) (void)hipFree(h->nms_total);
+    if (h->tie_state) (void)hipFree(h->tie_state);
     if (h->dummy) (void)hipFree(h->dummy);
     if (h->pinned) (void)hipHostFree(h->pinned);
     for (auto& e : h->prof_entries) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -1152,6 +1168,31 @@ int mp_nms_unresolved(mp_handle* h, int* unresolved, void* stream)
     MP_HIP(hipMemsetAsync(h->nms_total, 0, 4, s));
     MP_HIP(hipStreamSynchronize(s));
     *unresolved = h->pinned[0];
+    return MP_OK;
+}
+
+int mp_topk_tie_guard(mp_handle* h, float eps, int min_each_side)
+{
+    if (!h) return MP_EINVAL;
+    if (!(eps >= 0.f) || min_each_side < 0) return fail(h, MP_EINVAL, "mp_topk_tie_guard: eps >= 0 and min_each_side >= 0 (0: off)");
+    h->tie_eps = eps; h->tie_min = min_each_side;
+    return MP_OK;
+}
+
+int mp_topk_ambiguous(mp_handle* h, int* flags, int B, int* total, void* stream)
+{
+    if (!h || !total || B < 0 || (B > 0 && !flags)) return MP_EINVAL;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    *total = 0;
+    for (int b = 0; b < B; ++b) flags[b] = 0;
+    if (!h->tie_state) return MP_OK;
+    MP_HIP(hipSetDevice(h->device));
+    const int nb = B < h->tie_last_B ? B : h->tie_last_B;       // flags exist for the images of the latest call only
+    MP_HIP(hipMemcpyAsync(h->pinned, h->tie_state, (size_t)(1 + nb) * 4, hipMemcpyDeviceToHost, s));
+    MP_HIP(hipMemsetAsync(h->tie_state, 0, 4, s));
+    MP_HIP(hipStreamSynchronize(s));
+    *total = h->pinned[0];
+    for (int b = 0; b < nb; ++b) flags[b] = h->pinned[1 + b];
     return MP_OK;
 }
 

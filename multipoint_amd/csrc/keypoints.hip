@@ -137,11 +137,14 @@ __global__ __launch_bounds__(BT) void compact_segments_kernel(const float* __res
 __global__ __launch_bounds__(BTS) void select_keypoints_kernel(
     const float* __restrict__ work, int H, int W, int topk, int K, int* __restrict__ list_idx,
     float* __restrict__ list_score, int list_cap, int* __restrict__ kp_yx, float* __restrict__ kp_score,
-    int* __restrict__ kp_count, float* __restrict__ prob_nms, const int* __restrict__ list_count)
+    int* __restrict__ kp_count, float* __restrict__ prob_nms, const int* __restrict__ list_count,
+    float tie_eps, int tie_min, int* __restrict__ tie_state)
 {
     __shared__ int s_wave[BTS / 64];
     __shared__ unsigned s_hist[256];
     __shared__ unsigned s_sel[2];
+    __shared__ int s_near[2];          // survivors within tie_eps of the k-th score: [0] admitted, [1] cut off
+    if (threadIdx.x < 2) s_near[threadIdx.x] = 0;
     const int b = blockIdx.x, tid = threadIdx.x;
     const int n = H * W;
     const float* img = work + (long long)b * n;
@@ -207,6 +210,9 @@ __global__ __launch_bounds__(BTS) void select_keypoints_kernel(
                 tie_base += tot_eq;
             }
             sel = (i < nk) && ((key > T) || (eq && tie_rank < need));
+            // top-k tie guard: how many survivors sit within the convolution's rounding noise of the cut, on either side of it
+            // (a cut inside a plateau of (near-)tied scores picks members of the plateau by that noise; a few hits per image)
+            if (tie_state && i < nk && fabsf(sc - __uint_as_float(T)) <= tie_eps) atomicAdd(&s_near[sel ? 0 : 1], 1);
         }
         int tot;
         const int pos = out_base + block_excl_scan<BTS>(sel ? 1 : 0, s_wave, &tot);
@@ -221,6 +227,14 @@ __global__ __launch_bounds__(BTS) void select_keypoints_kernel(
         if (sel && prob_nms) prob_nms[(long long)b * n + idx] = sc;        // utils.py:120
     }
     if (tid == 0 && kp_count) kp_count[b] = out_base;      // may exceed K when topk == 0: overflow
+    if (tie_state) {
+        __syncthreads();
+        if (tid == 0) {
+            const int flag = select && s_near[0] >= tie_min && s_near[1] >= tie_min;
+            if (b < MP_TIE_MAX_IMAGES) tie_state[1 + b] = flag;
+            if (flag) atomicAdd(&tie_state[0], 1);
+        }
+    }
 }
 
 }  // namespace
@@ -228,7 +242,8 @@ __global__ __launch_bounds__(BTS) void select_keypoints_kernel(
 // scratch layout behind `seg_scratch`: [B * nseg] segment counts, then [B] list totals
 void launch_select_keypoints(const float* work, int B, int H, int W, int topk, int K, int* list_idx,
                              float* list_score, int list_cap, int* kp_yx, float* kp_score,
-                             int* kp_count, float* prob_nms, int* seg_scratch, hipStream_t s)
+                             int* kp_count, float* prob_nms, int* seg_scratch, hipStream_t s, float tie_eps, int tie_min,
+                             int* tie_state)
 {
     if (B <= 0) return;
     const int n = H * W, nseg = (n + SEG - 1) / SEG;
@@ -240,7 +255,7 @@ void launch_select_keypoints(const float* work, int B, int H, int W, int topk, i
     hipLaunchKernelGGL(compact_segments_kernel<0>, g, dim3(BT), 0, s, work, n, 0.f, W, nseg, seg_count, list_cap,
                        (long long)list_cap, list_idx, list_score, (int*)nullptr, list_count, (const unsigned char*)nullptr);
     hipLaunchKernelGGL(select_keypoints_kernel, dim3(B), dim3(BTS), 0, s, work, H, W, topk, K, list_idx,
-                       list_score, list_cap, kp_yx, kp_score, kp_count, prob_nms, list_count);
+                       list_score, list_cap, kp_yx, kp_score, kp_count, prob_nms, list_count, tie_eps, tie_min, tie_state);
 }
 
 void launch_extract_threshold(const float* map, const unsigned char* mask, int B, int H, int W, float thr, int K, int* kp_yx,

@@ -241,7 +241,10 @@ void launch_nms_accumulate(int* remaining, int B, int H, int W, int round, int* 
 // outputs kp_yx [B][K][2] int32, kp_score [B][K], kp_count [B]; optional dense map prob_nms
 void launch_select_keypoints(const float* work, int B, int H, int W, int topk, int K,
                              int* list_idx, float* list_score, int list_cap, int* kp_yx,
-                             float* kp_score, int* kp_count, float* prob_nms, int* seg_scratch, hipStream_t s);
+                             float* kp_score, int* kp_count, float* prob_nms, int* seg_scratch, hipStream_t s,
+                             float tie_eps = 0.f, int tie_min = 0, int* tie_state = nullptr);
+// top-k tie guard state (device ints): [0] flagged images since the last read, [1 + b] flag of image b of the latest call
+#define MP_TIE_MAX_IMAGES 1000
 // ints of device scratch (segment counts + list totals) launch_select_keypoints / launch_extract_threshold need
 size_t keypoint_scratch_ints(int B, int H, int W);
 // plain threshold extraction: (map > thr) -> row-major list (torch.nonzero semantics)

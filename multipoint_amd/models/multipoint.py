@@ -180,6 +180,25 @@ class MultiPoint:
             self._upload()
         return self
 
+    def direct_twin(self):
+        """A second model over the SAME weights with `conv_algorithm: direct` (created on first use, on this model's device) --
+        the tie-exact algorithm the top-k tie guard re-evaluates flagged images with (utils.tie_robust_redo).  None when this
+        model has no other algorithm to offer: it is `direct` itself, or runs the fp16 path (`mixed_precision`)."""
+        if self.config.get('conv_algorithm', 'auto') == 'direct' or self.config.get('mixed_precision') or self._state is None \
+                or self.device is None:
+            return None
+        twin = getattr(self, '_direct_twin', None)
+        if twin is None or twin._state_of is not self._state or twin.device != self.device:
+            cfg = dict(self.config); cfg['conv_algorithm'] = 'direct'
+            twin = type(self)(cfg)
+            twin._state = self._state                    # shared host tensors (read-only)
+            twin._state_of = self._state
+            twin._uploaded = False
+            twin.to(self.device)
+            twin.eval()
+            self._direct_twin = twin
+        return twin
+
     def cuda(self, device=None):
         return self.to(torch.device('cuda', torch.cuda.current_device() if device is None else device))
 

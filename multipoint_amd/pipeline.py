@@ -66,8 +66,13 @@ class PairPipeline:
     """config: the `prediction:` block of the reference yaml
     (configs/config_image_pair_dataset_prediction.yaml:40-53)."""
 
-    def __init__(self, net, config, capacity=None, nms_rounds=8, overlap_post=True):
+    def __init__(self, net, config, capacity=None, nms_rounds=8, overlap_post=True, tie_robust=True, keep_maps=False):
         self.net = net
+        self.tie_robust = tie_robust    # run_converged re-evaluates images flagged by the top-k tie guard with the tie-exact algorithm
+        self.keep_maps = keep_maps      # run_converged keeps the (possibly redone) heat map / coarse descriptors on its results
+        self.tie_redone = 0             # images the latest run_converged() redid; tie_redone_total: since construction
+        self.tie_redone_total = 0
+        self.tie_flagged = 0            # images flagged since the previous check_converged() (throughput entry: reported only)
         self.overlap_post = overlap_post and os.environ.get('MP_POST_OVERLAP', '1') != '0'     # (developer A/B switch)
         self._post_stream = None
         self._fwd_stream = None
@@ -227,9 +232,22 @@ class PairPipeline:
             raise ValueError('interleaved batch must hold an even number of images')
         if is_optical is None:
             is_optical = (torch.arange(B) % 2 == 0).reshape(B, 1)
-        out = self.net({'image': images, 'is_optical': is_optical})
+        data = {'image': images, 'is_optical': is_optical}
+        out = self.net(data)
         res = self._post(out, valid_mask, dev, B, H, W)
-        for attempt in range(5):
+        tie_checked = not (self.tie_robust and self.nms > 0 and self.topk > 0)
+        for attempt in range(6):
+            if not tie_checked:
+                # top-k tie guard (include/multipoint_hip.h): images whose top-k cut fell inside a plateau of scores tied within the
+                # default convolution algorithm's rounding noise are re-evaluated ONCE with the tie-exact algorithm, so that their
+                # lists follow the reference's exact score order (utils.py:97-116); one small host read per batch
+                tie_checked = True
+                flags, _ = U.topk_ambiguous(dev, B)
+                self.tie_redone = U.tie_robust_redo(self.net, data, out, flags) if any(flags) else 0
+                self.tie_redone_total += self.tie_redone
+                if self.tie_redone:
+                    res = self._post(out, valid_mask, dev, B, H, W)
+                    U.topk_ambiguous(dev, B)                     # (the redone lists flag the same plateaus again: read and drop)
             # both conditions are evaluated after EVERY pass, the last one included (check first, at most four redone passes): the
             # exact NMS of a redone pass can keep more keypoints than the asynchronous rounds left, i.e. overflow lists that fitted
             redo_nms = self.nms > 0 and U.nms_unresolved(dev)
@@ -239,23 +257,29 @@ class PairPipeline:
             overflow = need > K
             if not (redo_nms or overflow):
                 break
-            if attempt == 4:
-                raise RuntimeError('run_converged: keypoint lists / NMS did not settle after 4 redone passes (capacity %d)' % K)
+            if attempt == 5:
+                raise RuntimeError('run_converged: keypoint lists / NMS did not settle after 5 redone passes (capacity %d)' % K)
             # lists that overflowed their capacity (topk == 0: the reference keeps EVERY keypoint, utils.py:109-116) are
             # rebuilt with the exact size -- dropping the row-major tail would silently change nn_map / m_score
             res = self._post(out, valid_mask, dev, B, H, W, nms_rounds=0 if redo_nms else None,
                              capacity=((need + 255) // 256) * 256 if overflow else K)
         self._last = res
+        if self.keep_maps:
+            res.prob, res.desc_map = out['prob'], out['desc']
         return res
 
     def check_converged(self, device=None):
-        """Synchronises; raises if the fixed number of asynchronous NMS rounds was not enough."""
+        """Synchronises; raises if the fixed number of asynchronous NMS rounds was not enough.  Also reads the top-k tie guard:
+        `self.tie_flagged` = images, over all batches since the previous check, whose top-k cut fell inside a plateau of
+        (near-)tied scores -- reported, not raised: the throughput entry does not re-evaluate them (run_converged does)."""
         if self._post_stream is not None:
             self._post_stream.synchronize()
             with torch.cuda.stream(self._post_stream):
                 n = U.nms_unresolved(device)
+                self.tie_flagged = U.topk_ambiguous(device, 0)[1] if (self.nms > 0 and self.topk > 0) else 0
         else:
             n = U.nms_unresolved(device)
+            self.tie_flagged = U.topk_ambiguous(device, 0)[1] if (self.nms > 0 and self.topk > 0) else 0
         if n:
             raise RuntimeError('box_nms: %d candidates undecided after %d rounds; raise nms_rounds'
                                % (n, self.nms_rounds))

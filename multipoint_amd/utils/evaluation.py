@@ -256,7 +256,7 @@ def repeatability_counts(kp_yx, kp_count, h_optical, h_thermal, H, W, distance_t
 def compute_repeatability_multispectral(net, dataloader, device, config, distance_thresh=3, verbose=False):
     """Same signature and return value as the reference (evaluation.py:105-200):
     (mean repeatability, per-sample list, n_kp_optical, n_kp_thermal).  `config` is the whole yaml dict."""
-    from .utils import box_nms, data_to_device, extract_keypoints
+    from .utils import box_nms_tie_robust, data_to_device, extract_keypoints
     pred = config['prediction']
     thr = pred['detection_threshold']
     cap = pred['topk'] if pred.get('topk', 0) > 0 else 4096
@@ -270,9 +270,11 @@ def compute_repeatability_multispectral(net, dataloader, device, config, distanc
         img = torch.stack([data['optical']['image'], data['thermal']['image']], 1).flatten(0, 1)     # interleaved
         mask = torch.stack([data['optical']['valid_mask'], data['thermal']['valid_mask']], 1).flatten(0, 1)
         flags = (torch.arange(2 * B) % 2 == 0).reshape(-1, 1)
-        prob = net({'image': img, 'is_optical': flags})['prob']
-        if pred['nms'] > 0:
-            prob = box_nms(prob, pred['nms'], thr, keep_top_k=pred['topk'], on_cpu=pred.get('cpu_nms', False))
+        fwd_in = {'image': img, 'is_optical': flags}
+        fwd = net(fwd_in)
+        prob = fwd['prob']
+        if pred['nms'] > 0:      # (top-k tie guard: flagged images are re-evaluated with the tie-exact algorithm)
+            prob = box_nms_tie_robust(net, fwd_in, fwd, pred['nms'], thr, keep_top_k=pred['topk'], on_cpu=pred.get('cpu_nms', False))
         # keypoints: nonzero((prob > thr) * mask)  (:156-157) -- the mask is applied AFTER the NMS here
         kp, _, cnt = extract_keypoints(prob, thr, cap, valid_mask=mask)
         H, W = prob.shape[2:]

@@ -10,7 +10,8 @@ from .. import _lib
 
 __all__ = ['dict_update', 'data_to_device', 'data_unsqueeze', 'fix_model_weigth_keys', 'depth_to_space',
            'space_to_depth', 'box_nms', 'detect_keypoints', 'extract_keypoints', 'nms_unresolved',
-           'interpolate_descriptors', 'interpolate_descriptors_batched']
+           'interpolate_descriptors', 'interpolate_descriptors_batched', 'topk_ambiguous', 'topk_tie_guard',
+           'tie_robust_redo', 'box_nms_tie_robust']
 
 
 def dict_update(d, u):
@@ -129,6 +130,61 @@ def nms_unresolved(device=None):
     n = ctypes.c_int(0)
     h.check(h.lib.mp_nms_unresolved(h.ptr, ctypes.byref(n), _lib.stream_ptr(dev)))
     return n.value
+
+
+def topk_ambiguous(device=None, B=0):
+    """Top-k tie guard (include/multipoint_hip.h: mp_topk_ambiguous): (flags, total) -- flags[b] is True when the top-k cut of
+    image b of the LATEST box_nms / detect_keypoints call (keep_top_k > 0) fell inside a plateau of scores tied within the
+    convolution's rounding noise; total counts the flagged images of all calls since the previous read.  Synchronises."""
+    dev = _lib.require_cuda(device)
+    h = _lib.get_handle(dev)
+    flags = (ctypes.c_int * max(B, 1))()
+    n = ctypes.c_int(0)
+    h.check(h.lib.mp_topk_ambiguous(h.ptr, flags, int(B), ctypes.byref(n), _lib.stream_ptr(dev)))
+    return [bool(flags[b]) for b in range(B)], n.value
+
+
+def topk_tie_guard(device=None, eps=6e-5, min_each_side=4):
+    """Parameters of the top-k tie guard of this device's handle (min_each_side=0 switches it off)."""
+    dev = _lib.require_cuda(device)
+    h = _lib.get_handle(dev)
+    h.check(h.lib.mp_topk_tie_guard(h.ptr, float(eps), int(min_each_side)))
+
+
+def tie_robust_redo(net, data, out, flags):
+    """Re-evaluate the flagged images of a forward with the tie-exact algorithm: `out['prob']` / `out['desc']` rows of the
+    images with flags[b] set are replaced IN PLACE by the forward of `net.direct_twin()` (model.conv_algorithm: direct -- a
+    k-ordered multiply-add chain per output like the reference's convolution, so exact ties of the heat map stay ties).
+    Returns the number of images redone (0 when the model has no other algorithm: already direct, or mixed_precision)."""
+    idx = [b for b, f in enumerate(flags) if f]
+    twin = net.direct_twin() if idx else None
+    if twin is None:
+        return 0
+    sel = torch.as_tensor(idx, dtype=torch.long, device=out['prob'].device)
+    sub = {'image': data['image'].index_select(0, sel)}
+    if data.get('is_optical') is not None:
+        sub['is_optical'] = data['is_optical'].to(sel.device).index_select(0, sel) if data['is_optical'].is_cuda \
+            else data['is_optical'][torch.as_tensor(idx)]
+    redo = twin(sub)
+    for k in ('prob', 'logits', 'desc'):
+        if out.get(k) is not None and redo.get(k) is not None:
+            out[k].index_copy_(0, sel, redo[k])
+    return len(idx)
+
+
+def box_nms_tie_robust(net, data, out, size, min_prob, iou=0.1, keep_top_k=0, on_cpu=False, valid_mask=None):
+    """box_nms(out['prob'], ...) for the output `out = net(data)` with the top-k tie guard applied: images whose top-k cut fell
+    inside a plateau of (near-)tied scores are re-evaluated with the tie-exact convolution algorithm (`out` is updated in place
+    for them) and suppressed again, so the kept indices follow the reference's exact score order (utils.py:97-116) where the
+    default algorithm's rounding noise would have picked other members of the plateau.  What the predict_* CLIs call."""
+    res = box_nms(out['prob'], size, min_prob, iou, keep_top_k, on_cpu, valid_mask)
+    if keep_top_k > 0:
+        B = out['prob'].shape[0] if out['prob'].dim() == 4 else 1
+        flags, _ = topk_ambiguous(out['prob'].device, B)
+        if any(flags) and tie_robust_redo(net, data, out, flags):
+            res = box_nms(out['prob'], size, min_prob, iou, keep_top_k, on_cpu, valid_mask)
+            topk_ambiguous(out['prob'].device, B)            # the redone call flags the same plateaus again: read and drop
+    return res
 
 
 def extract_keypoints(prob, thr, capacity=None, valid_mask=None):

@@ -197,7 +197,18 @@ def gpu_outputs(cfg, sd, img, env):
         cfg_l = dict(cfg); cfg_l['force_return_logits'] = True
         net_l = M.MultiPoint(cfg_l); net_l.load_state_dict(sd); net_l.to('cuda'); net_l.eval()
         lg = net_l({'image': img.cuda()})['logits']
-        return {'prob': out['prob'].cpu(), 'desc': out['desc'].cpu(), 'logits': lg.cpu()}
+        got = {'prob': out['prob'].cpu(), 'desc': out['desc'].cpu(), 'logits': lg.cpu()}
+        if img.shape[0] % 2 == 0:
+            # the heat map the PRODUCT's drivers extract keypoints from: PairPipeline.run_converged re-evaluates images whose top-k
+            # cut fell inside a plateau of tied scores with the tie-exact algorithm (top-k tie guard, include/multipoint_hip.h)
+            from multipoint_amd.pipeline import PairPipeline
+            pred = {'nms': 4, 'detection_threshold': 0.015, 'topk': 1000,
+                    'matching': {'method': 'bfmatcher', 'method_kwargs': {'crossCheck': True}, 'knn_matches': False}}
+            pipe = PairPipeline(net, pred, capacity=1000, keep_maps=True)
+            res = pipe.run_converged(img.cuda())
+            got['prob_tie_robust'] = res.prob.cpu()
+            got['tie_redone'] = pipe.tie_redone
+        return got
     finally:
         for k, v in old.items():
             os.environ.pop(k, None)

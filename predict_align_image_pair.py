@@ -118,12 +118,14 @@ def main(argv=None):
         t_2 = time.time()
 
         if pred['nms'] > 0:
-            out_optical['prob'] = utils.box_nms(out_optical['prob'], pred['nms'], pred['detection_threshold'],
-                                                keep_top_k=pred['topk'], on_cpu=pred['cpu_nms'],
-                                                valid_mask=data['optical']['valid_mask'])
-            out_thermal['prob'] = utils.box_nms(out_thermal['prob'], pred['nms'], pred['detection_threshold'],
-                                                keep_top_k=pred['topk'], on_cpu=pred['cpu_nms'],
-                                                valid_mask=data['thermal']['valid_mask'])
+            # (box_nms with the top-k tie guard: an image whose top-k cut falls inside a plateau of tied scores is re-evaluated
+            # with the tie-exact convolution algorithm, so the kept indices follow the reference's exact score order)
+            out_optical['prob'] = utils.box_nms_tie_robust(net, data['optical'], out_optical, pred['nms'], pred['detection_threshold'],
+                                                           keep_top_k=pred['topk'], on_cpu=pred['cpu_nms'],
+                                                           valid_mask=data['optical']['valid_mask'])
+            out_thermal['prob'] = utils.box_nms_tie_robust(net, data['thermal'], out_thermal, pred['nms'], pred['detection_threshold'],
+                                                           keep_top_k=pred['topk'], on_cpu=pred['cpu_nms'],
+                                                           valid_mask=data['thermal']['valid_mask'])
         else:
             out_optical['prob'] = out_optical['prob'] * data['optical']['valid_mask']
             out_thermal['prob'] = out_thermal['prob'] * data['thermal']['valid_mask']

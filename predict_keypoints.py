@@ -81,21 +81,21 @@ def main(argv=None):
         if not args.batch:
             data = utils.data_unsqueeze(data, 0)
 
-        def nms(prob):
-            if pred['nms'] > 0:
-                return utils.box_nms(prob, pred['nms'], pred['detection_threshold'], keep_top_k=pred['topk'],
-                                     on_cpu=pred['cpu_nms'])
-            return prob
+        def nms(out, data):
+            if pred['nms'] > 0:      # (with the top-k tie guard: utils.box_nms_tie_robust)
+                return utils.box_nms_tie_robust(net, data, out, pred['nms'], pred['detection_threshold'], keep_top_k=pred['topk'],
+                                                on_cpu=pred['cpu_nms'])
+            return out['prob']
 
         outs = {}
         if dataset.returns_pair():
             for side in ('optical', 'thermal'):
                 out = net(data[side])
-                out['prob'] = nms(out['prob'])
+                out['prob'] = nms(out, data[side])
                 outs[side] = out
         else:
             out = net(data)
-            out['prob'] = nms(out['prob'])
+            out['prob'] = nms(out, data)
             outs['image'] = out
         torch.cuda.synchronize()
         print('Prediction took: {} s'.format(time.time() - t_start))

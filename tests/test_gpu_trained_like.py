@@ -46,9 +46,14 @@ def test_conv_families_on_trained_like_statistics(oracle, sev, variant):
     got = T.gpu_outputs(cfg, sd, img, T.VARIANT_ENV[variant])
     e = T.errors(got, r32, r64)
     nms = lambda m: oracle.box_nms(m, 4, 0.015, keep_top_k=0)
-    s, _ = FA.account_batch(r32['prob'].numpy(), got['prob'].numpy(), nms, 4, 0.015, 0.1, 1000)
-    print('\n[trained-like %s %s] %s | ATen fp32 vs fp64: %s | keypoints %d differing %d unexplained %d'
-          % (sev, variant, json.dumps(e), json.dumps(aten), s['keypoints_total'], s['keypoints_differing'], s['unexplained']))
+    # keypoints: from the heat map the product's drivers use (PairPipeline.run_converged: images flagged by the top-k tie guard are
+    # re-evaluated with the tie-exact algorithm); the raw forward's own accounting is printed beside it
+    s_raw, _ = FA.account_batch(r32['prob'].numpy(), got['prob'].numpy(), nms, 4, 0.015, 0.1, 1000)
+    s, _ = FA.account_batch(r32['prob'].numpy(), got['prob_tie_robust'].numpy(), nms, 4, 0.015, 0.1, 1000)
+    print('\n[trained-like %s %s] %s | ATen fp32 vs fp64: %s | keypoints %d differing %d (raw forward: %d; %d images redone) unexplained %d'
+          % (sev, variant, json.dumps(e), json.dumps(aten), s['keypoints_total'], s['keypoints_differing'],
+             s_raw['keypoints_differing'], got['tie_redone'], s['unexplained']))
+    assert s_raw['unexplained'] == 0 and s_raw['max_unexplained_margin'] == 0.0, s_raw
     assert e['desc_vs_cpu32'] <= 1e-4, e
     # 'wide+hot' is ill-conditioned on purpose (filters 10x outside their BatchNorm statistics): the max-norm there moves by 2x with
     # the summation order of ONE layer (F(4x4,3x3): 1.6e-3 with the first block's bias added last, 3.2e-3 with the bias as the
@@ -58,11 +63,13 @@ def test_conv_families_on_trained_like_statistics(oracle, sev, variant):
     assert e['logits_vs_f64'] <= max(1e-3, (k + 1.0) * aten['logits']), (e, aten)
     assert s['unexplained'] == 0 and s['max_unexplained_margin'] == 0.0, s
     assert s['roots_within_measured_noise']
+    # the direct kernel evaluates equal patches equally: the exact ties of piecewise-constant images survive; the F(4x4,3x3) kernels
+    # reorder them by rounding noise (round 4: 110-120 of 2 060 keypoints on 'wide', all at a top-k cut inside a plateau of tied
+    # scores) -- the top-k tie guard flags exactly those images and the pipeline redoes them with `direct`: 0 of 2 000 on 'mild' /
+    # 'wide', 4 of 2 002 on the ill-conditioned 'wide+hot' (where `direct` itself is 5.8e-4 from the oracle's map)
+    assert s['keypoints_differing'] <= 0.01 * s['keypoints_total'], s
     if variant == 'direct':
-        # the direct kernel evaluates equal patches equally: the exact ties of piecewise-constant images survive
-        assert s['keypoints_differing'] <= 0.01 * s['keypoints_total'], s
-    else:
-        assert s['keypoints_differing'] <= 0.08 * s['keypoints_total'], s
+        assert got['tie_redone'] == 0
 
 
 def test_f16_path_on_trained_like_statistics(oracle):
