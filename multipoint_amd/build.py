@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ_DIR = os.path.join(CSRC, '_build')
 LIB_PATH = os.path.join(HERE, 'libmultipoint_hip.so')
-SOURCES = ['conv_mfma.hip', 'conv_wino43.hip', 'conv_wino43b.hip', 'conv_split.hip', 'conv_f16.hip', 'conv_f16_res.hip', 'conv_first.hip', 'heads_post.hip', 'head_tail.hip', 'nms.hip', 'keypoints.hip',
+SOURCES = ['conv_mfma.hip', 'conv_wino43.hip', 'conv_wino43b.hip', 'conv_split.hip', 'conv_f16.hip', 'conv_f16_res.hip', 'conv_first.hip', 'heads_post.hip', 'head_tail.hip', 'head_tail_f16.hip', 'nms.hip', 'keypoints.hip',
            'sample_match.hip', 'match_extra.hip', 'pair_metrics.hip', 'detector_metrics.hip', 'homography.hip', 'homog_adapt.hip', 'api.hip']
 HEADERS = [os.path.join(CSRC, 'mp_common.h'),
            os.path.join(HERE, '..', 'include', 'multipoint_hip.h')]
@@ -32,7 +32,7 @@ def _stale(target, deps):
 
 # sources whose inline-asm LDS-DMA statements read SGPR base pointers: hipcc pads no hazards inside an asm string, so the
 # generated code is checked instead of padding every statement with s_nop (which costs 1 % of a launch)
-DMA_SOURCES = ('conv_wino43.hip', 'conv_wino43b.hip', 'head_tail.hip')
+DMA_SOURCES = ('conv_wino43.hip', 'conv_wino43b.hip', 'head_tail.hip', 'head_tail_f16.hip')
 
 
 def check_dma_hazards(asm_path, wait_states=5):

@@ -680,6 +680,23 @@ int forward_f16(mp_handle* h, const float* images, int B, int H, int W, int nset
         }
     }
     if ((rc = run_conv_h(h, h->heads3, X, encc, 0, P, headc, 0, B, Hc, Wc, nullptr, s))) return rc;
+    if (h->head_fuse) {
+        // both 1x1 convolutions + BN + softmax / shuffle + normalisation in ONE launch that reads P once (head_tail_f16.hip)
+        HeadTailParamsH t{};
+        t.x = P; t.xstride = headc; t.K = hc;
+        t.wdet = h->det1.wpack_h; t.bdet = h->det1.bias_h; t.sdet = h->det1.scale; t.tdet = h->det1.shift;
+        t.wdesc = h->desc1.wpack_h; t.bdesc = h->desc1.bias_h; t.sdesc = h->desc1.scale; t.tdesc = h->desc1.shift;
+        t.D = D; t.npx = npx; t.B = B; t.Hc = Hc; t.Wc = Wc;
+        t.prob = prob; t.logits_nchw = logits; t.desc = h->cfg.descriptor_head ? desc : nullptr;
+        t.softmax_mode = h->cfg.softmax_mode; t.normalize = h->cfg.normalize_descriptors ? 1 : 0; t.ncu = h->ncu;
+        if (t.wdet && (!t.desc || t.wdesc) && (prob || logits || t.desc)) {
+            prof_begin(h, "heads.tail", 2.0 * hc * (65.0 + (t.desc ? D : 0)) * (double)npx, s);
+            const int miss = launch_head_tail_f16(t, s);
+            prof_end(h, s);
+            if (!miss) { MP_HIP(hipGetLastError()); return MP_OK; }
+            if (h->prof && h->prof_used) --h->prof_used;      // not covered: the separate launches below are profiled instead
+        }
+    }
     if ((rc = run_conv_h(h, h->det1, P, headc, 0, Lg, 128, 0, B, Hc, Wc, nullptr, s))) return rc;
     if (prob || logits) {
         prof_begin(h, "det.softmax_shuffle", 0.0, s);

@@ -210,6 +210,20 @@ struct HeadTailParams {
     int ncu;                    // compute units of the device: one persistent workgroup each
 };
 int launch_head_tail(const HeadTailParams& p, hipStream_t s);      // 0: launched, 1: shape not covered (use the separate kernels)
+// the same for the fp16 path (head_tail_f16.hip): x and the weight fragments are fp16 (conv_f16.hip's packing, taps = 1), the
+// biases are the fp16-rounded ones, outputs stay fp32
+struct HeadTailParamsH {
+    const _Float16* x;          // [npx][xstride] fp16 output of the 3x3 head convolution: detector channels [0,K), descriptor [K,2K)
+    int xstride, K;             // K = head channels (multiple of 128: two 64-channel chunks per pass of the double buffer)
+    const _Float16 *wdet, *wdesc;
+    const float *bdet, *sdet, *tdet, *bdesc, *sdesc, *tdesc;      // padded like HeadTailParams' (>= 96 / D entries)
+    int D;
+    long long npx;
+    int B, Hc, Wc;
+    float* prob; float* logits_nchw; float* desc;
+    int softmax_mode, normalize, ncu;
+};
+int launch_head_tail_f16(const HeadTailParamsH& p, hipStream_t s); // 0: launched, 1: shape not covered
 void launch_det_post(const float* logits, int lstride, int B, int Hc, int Wc, float* prob,
                      float* logits_nchw, int mode, hipStream_t s);
 void launch_det_post_f16(const _Float16* logits, int lstride, int B, int Hc, int Wc, float* prob,

@@ -245,3 +245,30 @@ def test_f16_kernel_variants_agree(oracle, monkeypatch, env, upd, B, H, W):
     ds = S.desc_stats(a['desc'].cpu().numpy(), b['desc'].cpu().numpy(), channel_axis=1)
     assert ds['median'] <= 0.5 and ds['p999'] <= 4.0 and ds['max'] <= 8.0, ds
     assert (a['prob'] - b['prob']).abs().max().item() <= PROB_TOL_F16
+
+
+@pytest.mark.parametrize('upd', [{}, {'descriptor_size': 128}, {'descriptor_size': 256}, {'final_batchnorm': False},
+                                 {'descriptor_head': False}, {'normalize_descriptors': False}])
+@pytest.mark.parametrize('B,H,W', [(3, 72, 104), (1, 240, 320), (2, 480, 640), (1, 8, 8)])
+def test_f16_fused_head_tail_equals_separate_launches(oracle, monkeypatch, upd, B, H, W):
+    """head_tail_f16.hip (both 1x1 head convolutions + BatchNorm + softmax / shuffle + L2 normalisation in ONE launch, operands
+    by LDS-DMA) against the four launches it replaces (MP_NO_HEAD_FUSE=1: conv_f16.hip 1x1 x 2, det_post, desc_l2norm).  Same
+    rounding points and the SAME accumulation order over K (one MFMA chain per output, k ascending): the fp16 logits are
+    bit-identical; prob / desc differ only by exp / reciprocal rounding in fp32 (MultiPoint.py:66-75,82-86,150-166 under autocast)."""
+    img = oracle.make_images(17 + W, B, H, W).cuda()
+    net, sd, cfg = _net(oracle, upd, seed=3)
+    a = net({'image': img})
+    net.set_force_return_logits(True)
+    al = net({'image': img})['logits']
+    monkeypatch.setenv('MP_NO_HEAD_FUSE', '1')
+    net2, _, _ = _net(oracle, upd, seed=3)
+    b = net2({'image': img})
+    net2.set_force_return_logits(True)
+    bl = net2({'image': img})['logits']
+    assert torch.equal(al, bl)
+    assert (a['prob'] - b['prob']).abs().max().item() <= 2e-6
+    if a['desc'] is not None:
+        assert a['desc'].shape == b['desc'].shape
+        assert (a['desc'] - b['desc']).abs().max().item() <= 2e-6 * max(1.0, b['desc'].abs().max().item())
+    else:
+        assert b['desc'] is None
