@@ -343,6 +343,7 @@ def main():
     ap.add_argument('--host-input', action='store_true',
                     help='secondary measurement (never the headline value): every step first uploads its batch from pinned '
                          'host memory on a copy stream, double-buffered, overlapping the previous step (PCIe-inclusive rate)')
+    ap.add_argument('--nms-rounds', type=int, default=8, help='fixed asynchronous NMS rounds of the throughput entry (developer A/B)')
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip the `secondary` object of the plain N = 1 line (c5 / direct / batchsize-1 rates, ~15 s; also skipped with '
                          '--no-cpu-baseline, --forward-only, --host-input, --workload c5 and under torchrun)')
@@ -389,7 +390,7 @@ def main():
         cfg['mixed_precision'] = True
     sd = make_weights(0, cfg)
     net = models.MultiPoint(cfg); net.load_state_dict(sd); net.to(device); net.eval()
-    pipe = PairPipeline(net, PRED, capacity=PRED['topk'], nms_rounds=int(os.environ.get('MP_BENCH_NMS_ROUNDS', '8')))   # (developer A/B only)
+    pipe = PairPipeline(net, PRED, capacity=PRED['topk'], nms_rounds=args.nms_rounds)
     P = args.pairs_per_gpu
     pair_ids = shard_pairs(P * world, rank, world)              # pair p -> rank p mod world
     images = make_batch(pair_ids, device, H, W)
@@ -511,10 +512,11 @@ def main():
     for name, ms, flop in prof:
         by_name.setdefault(name, []).append((ms, flop))
     roof = None
-    wino = os.environ.get('MP_NO_WINOGRAD') != '1' and not c5
+    from multipoint_amd._lib import debug_switch
+    wino = debug_switch('no_winograd') is None and not c5
     # the library's choice for conv2 (api.hip uses_wino43): F(4x4,3x3) unless switched off, fused, or the frame is no multiple of 4
-    f43 = wino and os.environ.get('MP_WINO43', '2') != '0'
-    gen2 = f43 and (os.environ.get('MP_WINO43_GEN') == '2' or H % 4 != 0 or W % 4 != 0)      # conv_wino43b.hip: never fused
+    f43 = wino and debug_switch('wino43', '2') != '0'
+    gen2 = f43 and (debug_switch('wino43_gen') == '2' or H % 4 != 0 or W % 4 != 0)      # conv_wino43b.hip: never fused
     dom = by_name.get('enc.conv1+2') or by_name.get('enc.conv2')
     n_launch = 1
     if dom:
@@ -529,7 +531,7 @@ def main():
         conv2_flop = 2.0 * 9 * 64 * 64 * H * W * 2 * P          # the conv2 part of a fused conv1+conv2 launch
         peak = PEAK_FP16_MFMA_TFLOPS if c5 else PEAK_FP32_MFMA_TFLOPS
         if c5:
-            res_kernel = os.environ.get('MP_F16_NO_RES') != '1'
+            res_kernel = debug_switch('f16_no_res') is None
             if fused:
                 # first block inside the launch: per 8 x 32-pixel item 11 blocks of 32 tile pixels x 2 chunks of 32 channels, one
                 # v_mfma_f32_32x32x16_f16 (32768 FLOP, K = 9 taps + bias padded to 16) each
@@ -563,7 +565,7 @@ def main():
                       'F(4x4,3x3) on v_mfma_f32_16x16x4_f32, weights staged by LDS-DMA, + bias/ReLU/BN + 2x2 max-pool)') if fused else \
                      ('conv_wino43_kernel<true,false,8,false,false> (enc.conv2 64->64 @480x640 by Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32, '
                       'weights and channel-quad-planar input patches staged by LDS-DMA, + bias/ReLU/BN + 2x2 max-pool)')
-        else:                                                   # MP_WINO43=0: no Winograd kernel, as MP_NO_WINOGRAD=1
+        else:                                                   # MP_DEBUG=wino43=0: no Winograd kernel, as MP_DEBUG=no_winograd
             issued = conv2_flop if fused else flop
             inst = 'conv_mfma_kernel<9,32,true,true,false>' if fused else 'conv_mfma_persist_kernel<9,32,true,false>'
             kernel = inst + ' (direct convolution)'

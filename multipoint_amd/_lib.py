@@ -13,6 +13,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # MP_LIB selects another build of the library (developer tools: the -DMP_TIMING instrumented variant)
 LIB_PATH = os.environ.get('MP_LIB') or os.path.join(_HERE, 'libmultipoint_hip.so')
 
+
+
+def debug_switch(key, default=None):
+    """Developer switch `key` of the MP_DEBUG environment variable (a comma-separated list of `key` / `key=value`; the library
+    reads the kernel-selection keys in mp_create, see csrc/api.hip): the value behind '=', '1' for a bare key, `default` if absent."""
+    for tok in os.environ.get('MP_DEBUG', '').split(','):
+        k, eq, v = tok.strip().partition('=')
+        if k == key:
+            return v if eq else '1'
+    return default
+
+
 MP_OK = 0
 c_void_p, c_int, c_float, c_ll = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_longlong
 

@@ -53,7 +53,7 @@ struct ProfEntry {
 
 struct mp_handle {
     int device = 0;
-    int ncu = 256, xcd_shift = 3;   // machine shape derived in mp_create: compute units, log2(XCDs) (MP_NCU / MP_NXCD override)
+    int ncu = 256, xcd_shift = 3;   // machine shape derived in mp_create: compute units, log2(XCDs) (MP_DEBUG=ncu / MP_DEBUG=nxcd override)
     std::string err;
     bool loaded = false;
     mp_model_config cfg{};
@@ -65,7 +65,9 @@ struct mp_handle {
     DevBuf ws3;                     // matching arg-min arrays
     DevBuf ws4;                     // pair metrics: warped keypoints + inverse match map
     DevBuf split_ws;                // F(4x4,3x3) split launches: the ranges' pre-bias output tiles
-    int splitk_max = 8;             // most ranges the input channels of a small launch are cut into (MP_SPLITK_MAX; 1: never)
+    DevBuf vin_ws;                  // F(4x4,3x3) layers with >= 4 output slices: the pre-transformed input (ConvParams::vglobal)
+    int vin_min_slices = 4;         // ... from this many slices on (MP_DEBUG=no_vin: never)
+    int splitk_max = 8;             // most ranges the input channels of a small launch are cut into (MP_DEBUG=splitk_max; 1: never)
     int fwd_batch = 0;              // images of the forward in flight: the split launches are gated on THIS, not on an encoder's share of it
     int splitk_env = 8;             // ... as mp_create set it (model.batch_invariant overrides it per loaded model)
     DevBuf nms_state;               // 64 round counters + tile flags
@@ -78,21 +80,21 @@ struct mp_handle {
     int tie_last_B = 0;
     int head_channels = 256;        // width of each 3x3 head convolution (MultiPoint.py:38-53)
     void* dummy = nullptr;          // scratch line for masked-off store lanes of the fp16 kernels
-    bool wino = true;               // Winograd F(4x4,3x3) for the 3x3 layers (MP_NO_WINOGRAD=1 / conv_algorithm 'direct': the direct kernels)
+    bool wino = true;               // Winograd F(4x4,3x3) for the 3x3 layers (MP_DEBUG=no_winograd / conv_algorithm 'direct': the direct kernels)
     int persist = 8;                // persistent conv workgroups for launches with >= this many items per CU
-                                    // (MP_NO_PERSIST=1: never; MP_PERSIST_MIN_ITEMS=n overrides the threshold)
-    bool fuse_first = true;         // fuse the Cin=1 block into the second convolution (MP_NO_FUSE=1 disables)
-    int planar = 1;                 // 0 (MP_NO_PLANAR=1): NHWC everywhere; 1: channel-quad-planar tensors where they pay; 2 (MP_PLANAR=2): between every two F(4x4,3x3) layers
-    int wino43 = 2;                 // MP_WINO43: 0 off (direct kernels), 1 F(4x4,3x3) for the 3x3 layers with 64 input channels only, 2 (default) every 3x3 layer
-    bool head_fuse = true;          // MP_NO_HEAD_FUSE=1: separate 1x1 convolution / softmax / normalisation launches
-    bool fuse43 = true;             // first block evaluated inside the F(4x4,3x3) conv2 kernel (MP_NO_FUSE43=1: its own launch)
-    int wino43_gen = 0;             // MP_WINO43_GEN: 0 conv_wino43.hip where it applies, conv_wino43b.hip for every other shape; 1 / 2: only that kernel
+                                    // (MP_DEBUG=no_persist: never; MP_DEBUG=persist_min_items=n overrides the threshold)
+    bool fuse_first = true;         // fuse the Cin=1 block into the second convolution (MP_DEBUG=no_fuse disables)
+    int planar = 1;                 // 0 (MP_DEBUG=no_planar): NHWC everywhere; 1: channel-quad-planar tensors where they pay; 2 (MP_DEBUG=planar=2): between every two F(4x4,3x3) layers
+    int wino43 = 2;                 // MP_DEBUG=wino43: 0 off (direct kernels), 1 F(4x4,3x3) for the 3x3 layers with 64 input channels only, 2 (default) every 3x3 layer
+    bool head_fuse = true;          // MP_DEBUG=no_head_fuse: separate 1x1 convolution / softmax / normalisation launches
+    bool fuse43 = true;             // first block evaluated inside the F(4x4,3x3) conv2 kernel (MP_DEBUG=no_fuse43: its own launch)
+    int wino43_gen = 0;             // MP_DEBUG=wino43_gen: 0 conv_wino43.hip where it applies, conv_wino43b.hip for every other shape; 1 / 2: only that kernel
     bool wino_env = true;           // wino / wino43 / wino43_gen as mp_create read them: mp_load_weights starts from these and
     int wino43_env = 2, wino43_gen_env = 0;   // applies the model's conv_algorithm on top (a reload never inherits the previous model's)
     int* pinned = nullptr;          // small pinned host scratch (img lists, counters)
-    bool f16_res = true;            // MP_F16_NO_RES=1: the streaming kernel (conv_f16.hip) also for the 64 -> 64 layers
-    bool f16_fuse1 = true;          // MP_F16_NO_FUSE1=1: the first block of the fp16 path as its own launch
-    int f16_res_groups = 3;         // MP_F16_RES_GROUPS=2: two instead of three wave groups per CU in conv_f16_res.hip
+    bool f16_res = true;            // MP_DEBUG=f16_no_res: the streaming kernel (conv_f16.hip) also for the 64 -> 64 layers
+    bool f16_fuse1 = true;          // MP_DEBUG=f16_no_fuse1: the first block of the fp16 path as its own launch
+    int f16_res_groups = 3;         // MP_DEBUG=f16_res_groups=2: two instead of three wave groups per CU in conv_f16_res.hip
     bool prof = false;
     bool head_fallback_noted = false;
     std::vector<ProfEntry> prof_entries;
@@ -508,7 +510,7 @@ int launch_failed(mp_handle* h, int code, const char* name, int B, int H, int W)
 
 // which F(4x4,3x3) kernel run_conv() sends this 3x3 layer at H x W to: 0 none, 1 conv_wino43.hip (two waves per SIMD; reflection
 // padding and frames that are multiples of the 4x4 tile; the only one that evaluates the first block inside the launch), 2
-// conv_wino43b.hip (one wave per SIMD; any frame size, reflection or zero padding).  MP_WINO43_GEN: 0 (default) the first where
+// conv_wino43b.hip (one wave per SIMD; any frame size, reflection or zero padding).  MP_DEBUG=wino43_gen: 0 (default) the first where
 // it applies and the second otherwise, 1 / 2 only that one.
 int wino43_kind(const mp_handle* h, const ConvLayer& L, int H, int W, bool fuse, int in_cstride = 0, int in_coff = 0,
                 int out_cstride = 0, int out_coff = 0)
@@ -575,6 +577,13 @@ int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, 
                 if (rc) return rc;
                 p.ks_shift = ks; p.split_scratch = static_cast<float*>(h->split_ws.p);
             }
+        }
+        if (f43 == 1 && !fuse && !L.pool && p.ks_shift == 0 && !in_planar && L.cin % 16 == 0 && h->vin_min_slices > 0 &&
+            L.nslices >= h->vin_min_slices) {
+            // many output slices over one input (heads: 512 couts = 8 slices): transform the input ONCE (conv_wino43.hip VIN)
+            int rc = ensure(h, h->vin_ws, (size_t)conv_wino43_vglobal_floats(p) * 4);
+            if (rc) return rc;
+            p.vglobal = static_cast<float*>(h->vin_ws.p);
         }
         big = f43 == 2 ? launch_conv_wino43b(p, L.pool, s) : launch_conv_wino43(p, L.pool, s, fuse != nullptr);
     } else {
@@ -815,6 +824,40 @@ int nms_common(mp_handle* h, const float* prob, const unsigned char* mask, int B
 namespace {
 // XCC (= XCD) count of the KFD topology node whose PCI location matches `bus_id` ("dddd:bb:dd.f"); 0 if the topology is not
 // readable (containers without /sys/class/kfd): the caller then falls back to compute units / 32
+// MP_DEBUG: the ONE environment variable the library reads (in mp_create), a comma-separated list of developer switches
+// `key` or `key=value` -- kernel selection for A/B runs and for the parity tests, which hold every kernel variant to the CPU reference path.
+// They are not configuration: a model's algorithm is `model.conv_algorithm` / `model.batch_invariant` (mp_model_config).
+//   no_winograd          the direct implicit-GEMM kernels for every 3x3 layer (what conv_algorithm 3 selects per model)
+//   wino43=0|1|2         F(4x4,3x3) for no layer / the 64-input-channel layers only / every 3x3 layer (default 2)
+//   wino43_gen=0|1|2     0 conv_wino43.hip where it applies and conv_wino43b.hip elsewhere; 1 / 2: only that kernel
+//   no_fuse              the fp32 first block as its own launch in front of the direct conv2 kernel
+//   no_fuse43            ... in front of the F(4x4,3x3) conv2 kernel
+//   no_head_fuse         separate 1x1 convolution / softmax / normalisation launches instead of the fused head tail (fp32 and fp16)
+//   no_vin               the head convolutions transform their input per output slice (no pre-transformed V pass)
+//   no_planar, planar=0|1|2   channel-quad-planar tensors: never / behind conv1 and pooled producers (default) / everywhere
+//   no_persist, persist_min_items=N   direct kernels: per-tile launches / persistent from N items per CU
+//   splitk_max=1..8      most ranges the input channels of a small launch are cut into
+//   f16_no_res, f16_no_fuse1, f16_res_groups=2   fp16 path: streaming kernel everywhere / first block as its own launch / two groups
+//   ncu=N, nxcd=N        emulate a partitioned device (fewer persistent workgroups, same results)
+// Returns true when `key` is present; *value receives the integer behind '=' (or `dflt` for a bare key).
+bool debug_switch(const char* key, int* value = nullptr, int dflt = 1)
+{
+    const char* e = getenv("MP_DEBUG");
+    if (!e) return false;
+    const size_t kl = std::strlen(key);
+    for (const char* q = e; *q;) {
+        while (*q == ',' || *q == ' ') ++q;
+        const char* end = q;
+        while (*end && *end != ',') ++end;
+        if ((size_t)(end - q) >= kl && std::strncmp(q, key, kl) == 0 && (q[kl] == '=' || q + kl == end || q[kl] == ' ')) {
+            if (value) *value = q[kl] == '=' ? atoi(q + kl + 1) : dflt;
+            return true;
+        }
+        q = end;
+    }
+    return false;
+}
+
 int kfd_num_xcc(const char* bus_id)
 {
     unsigned dom = 0, bus = 0, dev = 0, fn = 0;
@@ -873,15 +916,16 @@ int mp_create(mp_handle** out, int device)
     // Machine shape: every persistent kernel launches one (fp16: two) workgroup(s) per compute unit and walks, per XCD, a
     // contiguous share of the work items (workgroup b is dispatched to XCD b mod nxcd; each XCD has its own L2).  Both numbers
     // come from the device: multiProcessorCount, and the XCC count of the KFD topology node at the device's PCI address
-    // (a partitioned MI355X -- DPX / QPX / CPX -- reports 4 / 2 / 1 XCDs with 128 / 64 / 32 CUs).  MP_NCU / MP_NXCD override
+    // (a partitioned MI355X -- DPX / QPX / CPX -- reports 4 / 2 / 1 XCDs with 128 / 64 / 32 CUs).  MP_DEBUG=ncu / MP_DEBUG=nxcd override
     // (tests emulate smaller partitions on the full device: fewer workgroups, same results).
     int ncu = prop.multiProcessorCount, nxcd = 0;
     {
         char bus[64] = {0};
         if (hipDeviceGetPCIBusId(bus, sizeof bus, device) == hipSuccess) nxcd = kfd_num_xcc(bus);
         if (nxcd <= 0) nxcd = ncu >= 32 ? ncu / 32 : 1;           // gfx950: 32 active CUs per XCD
-        if (const char* e = getenv("MP_NCU")) { const int v = atoi(e); if (v > 0 && v <= ncu) ncu = v; }
-        if (const char* e = getenv("MP_NXCD")) { const int v = atoi(e); if (v > 0) nxcd = v; }
+        int v = 0;
+        if (debug_switch("ncu", &v) && v > 0 && v <= ncu) ncu = v;
+        if (debug_switch("nxcd", &v) && v > 0) nxcd = v;
     }
     if (ncu < 1 || nxcd < 1 || (nxcd & (nxcd - 1)) != 0 || nxcd > ncu)
         return fail(h, MP_EINVAL, "mp_create: unsupported machine shape: " + std::to_string(ncu) + " compute units in " +
@@ -891,20 +935,24 @@ int mp_create(mp_handle** out, int device)
     hh->ncu = ncu;
     hh->xcd_shift = 0;
     while ((1 << hh->xcd_shift) < nxcd) ++hh->xcd_shift;
-    { const char* e = getenv("MP_NO_FUSE"); hh->fuse_first = !(e && e[0] == '1'); }
-    { const char* e = getenv("MP_NO_WINOGRAD"); hh->wino = !(e && e[0] == '1'); }
-    { const char* e = getenv("MP_NO_FUSE43"); hh->fuse43 = !(e && e[0] == '1'); }
-    { const char* e = getenv("MP_NO_HEAD_FUSE"); hh->head_fuse = !(e && e[0] == '1'); }
-    { const char* e = getenv("MP_F16_NO_RES"); hh->f16_res = !(e && e[0] == '1'); }
-    { const char* e = getenv("MP_F16_NO_FUSE1"); hh->f16_fuse1 = !(e && e[0] == '1'); }
-    { const char* e = getenv("MP_F16_RES_GROUPS"); if (e && e[0] == '2') hh->f16_res_groups = 2; }
-    { const char* e = getenv("MP_NO_PLANAR"); if (e && e[0] == '1') hh->planar = 0; }
-    { const char* e = getenv("MP_PLANAR"); if (e && e[0] >= '0' && e[0] <= '2') hh->planar = e[0] - '0'; }
-    { const char* e = getenv("MP_WINO43"); if (e && e[0] >= '0' && e[0] <= '2') hh->wino43 = e[0] - '0'; }
-    { const char* e = getenv("MP_WINO43_GEN"); if (e && e[0] >= '0' && e[0] <= '2') hh->wino43_gen = e[0] - '0'; }
-    { const char* e = getenv("MP_PERSIST_MIN_ITEMS"); if (e && atoi(e) > 0) hh->persist = atoi(e); }
-    { const char* e = getenv("MP_NO_PERSIST"); if (e && e[0] == '1') hh->persist = 0; }
-    { const char* e = getenv("MP_SPLITK_MAX"); if (e && atoi(e) >= 1 && atoi(e) <= 8) hh->splitk_max = atoi(e); }
+    {
+        int v = 0;
+        hh->fuse_first = !debug_switch("no_fuse");
+        hh->wino = !debug_switch("no_winograd");
+        hh->fuse43 = !debug_switch("no_fuse43");
+        hh->head_fuse = !debug_switch("no_head_fuse");
+        hh->f16_res = !debug_switch("f16_no_res");
+        hh->f16_fuse1 = !debug_switch("f16_no_fuse1");
+        if (debug_switch("f16_res_groups", &v) && v == 2) hh->f16_res_groups = 2;
+        if (debug_switch("no_planar")) hh->planar = 0;
+        if (debug_switch("planar", &v) && v >= 0 && v <= 2) hh->planar = v;
+        if (debug_switch("wino43", &v) && v >= 0 && v <= 2) hh->wino43 = v;
+        if (debug_switch("wino43_gen", &v) && v >= 0 && v <= 2) hh->wino43_gen = v;
+        if (debug_switch("persist_min_items", &v) && v > 0) hh->persist = v;
+        if (debug_switch("no_persist")) hh->persist = 0;
+        if (debug_switch("splitk_max", &v) && v >= 1 && v <= 8) hh->splitk_max = v;
+        if (debug_switch("no_vin")) hh->vin_min_slices = 0;
+    }
     hh->splitk_env = hh->splitk_max;
     hh->wino_env = hh->wino; hh->wino43_env = hh->wino43; hh->wino43_gen_env = hh->wino43_gen;
     if (hipHostMalloc(reinterpret_cast<void**>(&hh->pinned), 4096) != hipSuccess) {
@@ -953,7 +1001,7 @@ int mp_load_weights(mp_handle* h, const mp_model_config* cfg, const mp_tensor* t
     MP_HIP(hipSetDevice(h->device));
     free_weights(h);
     h->cfg = *cfg;
-    // the convolution algorithm of the 3x3 layers is a MODEL setting (yaml model.conv_algorithm); the MP_* environment switches of
+    // the convolution algorithm of the 3x3 layers is a MODEL setting (yaml model.conv_algorithm); the MP_DEBUG developer switches of
     // mp_create only apply to 'auto'
     h->wino = h->wino_env; h->wino43 = h->wino43_env; h->wino43_gen = h->wino43_gen_env;     // 0 auto: what mp_create chose
     if (cfg->conv_algorithm == 1) { h->wino = true; h->wino43 = 2; h->wino43_gen = 0; }

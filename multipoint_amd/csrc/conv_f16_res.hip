@@ -577,7 +577,7 @@ bool conv_f16_res_supports(const ConvParamsH& p, int taps)
 int launch_conv_f16_res(const ConvParamsH& p, int mbw, bool pool, hipStream_t s)
 {
     // three groups per CU for the pooled layers, two for the un-pooled ones (their epilogue writes 4x the bytes: enc.conv3
-    // 0.45 vs 0.48 ms, enc.conv5's slices 0.24 vs 0.25 ms with two); MP_F16_RES_GROUPS=2 (read per handle in mp_create): two everywhere
+    // 0.45 vs 0.48 ms, enc.conv5's slices 0.24 vs 0.25 ms with two); MP_DEBUG=f16_res_groups=2 (read per handle in mp_create): two everywhere
     const int ng = (p.res_groups == 2 || !pool) ? 2 : 3;
     if (p.img) {           // first encoder block fused in: the pooled 64 -> 64 layer (enc.conv2), reflection padding
         if (!pool || p.pad_zero) return 2;

@@ -161,18 +161,26 @@ __device__ __forceinline__ void bt6(const f32x2 d[6], f32x2 r[6])
 // already reflected) and the weight of channel lane & 3, and receives the 4 channels of its own pixel -- exactly one raw
 // granule, written after ReLU / BatchNorm with one ds_write_b128.  Nothing of the block ever leaves the CU; the image patch of
 // item k + 2 arrives by 4-byte LDS-DMA during the epilogue of item k.
-template <bool POOL, bool BNF, int TC4, bool F1, bool SPLIT = false>
+// VIN (round 5: layers with MANY output slices -- the 3x3 head convolutions, 512 couts = 8 slices): the input arrives already
+// TRANSFORMED.  Every 64-cout slice of a tile block needs the same V = B^T d B, and the in-kernel transform is what the matrix pipe
+// waits for (Appendix B: 2470 cycles per unit without it, 3300-3650 with); wino43_vprod_kernel below writes V once per (tile block,
+// unit) into p.vglobal in exactly the LDS order [unit][ch 4][tile 32][pos 36] (18 KiB, the same bits the in-kernel transform
+// produces), and this instantiation DMAs it straight into a ring of FOUR V buffers three units ahead: no raw patches, no
+// scratch, no vector work in the unit body at all.  The 8 slices of a tile block are consecutive items = 8 workgroups of one XCD at
+// the same time: one of them misses to HBM, the others hit the XCD's L2.
+template <bool POOL, bool BNF, int TC4, bool F1, bool SPLIT = false, bool VIN = false>
 __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
 {
     static_assert(!(F1 && SPLIT), "the fused first block is never split");
+    static_assert(!(VIN && (F1 || SPLIT)), "pre-transformed input: plain launches only");
     constexpr int TR4 = 32 / TC4;                      // tile rows x tile columns of an item
     constexpr int OY = 4 * TR4, OX = 4 * TC4;          // output pixels of an item
     constexpr int PY = OY + 2, PX = OX + 2;            // raw patch
     static_assert(PY * PX == NPIX, "item shape");
-    __shared__ __attribute__((aligned(16))) float Vs[2 * VB4];
+    __shared__ __attribute__((aligned(16))) float Vs[(VIN ? 4 : 2) * VB4];
     __shared__ __attribute__((aligned(16))) float Us[2 * UB4];
-    __shared__ __attribute__((aligned(16))) float raw[3 * RB4 + 256];
-    __shared__ __attribute__((aligned(16))) float scr[8 * SW4];
+    __shared__ __attribute__((aligned(16))) float raw[VIN ? 256 : 3 * RB4 + 256];        // VIN: only the dummy DMA block
+    __shared__ __attribute__((aligned(16))) float scr[VIN ? 4 : 8 * SW4];
     __shared__ __attribute__((aligned(16))) float prm[3 * 64];
 
     const int tid = threadIdx.x;
@@ -190,11 +198,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     if (item >= item_end) return;
 
     auto udiv = [](unsigned n, unsigned magic, unsigned d) -> unsigned { return d == 1 ? n : __umulhi(n, magic); };
-    struct Where { int slice, img, y0, x0; const float* in_base; };
+    struct Where { int slice, img, y0, x0, tile; const float* in_base; };
     auto decode = [&](int it) __attribute__((always_inline)) -> Where {
         Where w{};
         const int tile = (int)udiv((unsigned)it, p.magic_slices, (unsigned)p.nslices);
         w.slice = it - tile * p.nslices;
+        w.tile = tile;
         const int trow = (int)udiv((unsigned)tile, p.magic_tx, (unsigned)p.tiles_x);
         const int tx = tile - trow * p.tiles_x;
         const int bi = (int)udiv((unsigned)trow, p.magic_ty, (unsigned)p.tiles_y);
@@ -489,6 +498,30 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
         }
     };
 
+    // ---- VIN: the pre-transformed input of unit n + 3 by DMA into V ring slot (n + 3) & 3 ----
+    // 18 blocks of 1 KiB per unit: wave w issues blocks w, w + 8, w + 16; waves 2..7 have no third block -- theirs re-reads block 17
+    // into the dummy block (every wave issues three, so that one s_waitcnt vmcnt(3) leaves exactly a unit's V DMAs in flight)
+    const unsigned vs_lds = lds_addr(Vs);
+    auto v_dma = [&](const float* vsrc, int slot, int i) __attribute__((always_inline)) {
+        const int b = wave + 8 * i;
+        const unsigned dst = b < 18 ? vs_lds + (unsigned)(slot * VB4 + b * 256) * 4u : lds_addr(raw);
+        dma16(vsrc + (b < 18 ? b : 17) * 256, (unsigned)lane * 16u, dst);
+    };
+    const float* vcur = nullptr;              // V of the cursor's unit in p.vglobal
+    int v_chunk = 0, v_next_item = item + stride;
+    auto v_advance = [&]() __attribute__((always_inline)) {
+        vcur += VB4;
+        if (++v_chunk == NC) {
+            v_chunk = 0;
+            if (v_next_item < item_end) {
+                vcur = p.vglobal + (long long)decode(v_next_item).tile * NC * VB4;
+                v_next_item += stride;
+            } else {
+                vcur -= (long long)NC * VB4;      // no next item: dummy re-reads of this one
+            }
+        }
+    };
+
     // ---- prologue ----
     Where cur = decode(item);
     if constexpr (F1) {
@@ -511,7 +544,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
         produce(RB4 * 4u, 0); if (wave + 8 < NRB) produce(RB4 * 4u, 1);       // raw(1) -> buffer 1
         prod_advance();
     }
-    const float* rbase = F1 ? p.in : raw_offsets(cur);
+    const float* rbase = (F1 || VIN) ? p.in : raw_offsets(cur);
     const float* rsrc = rbase;               // the cursor's unit: rbase + ld_chunk * unit_stride
     Where ld_item = cur;
     int ld_chunk = 0;
@@ -530,7 +563,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     };
     const float* up = u_ptr(cur.slice);
     // raw(k) lives in raw buffer k % 3: unit n transforms raw(n+1) and sends raw(n+3) over raw(n)
-    if constexpr (!F1) {
+    if constexpr (VIN) {
+        vcur = p.vglobal + (long long)cur.tile * NC * VB4;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {                                                                   // V(0), V(1), V(2)
+            v_dma(vcur, u, 0); v_dma(vcur, u, 1); v_dma(vcur, u, 2);
+            v_advance();
+        }
+    } else if constexpr (!F1) {
         raw_dma(rsrc, 0u, 0); raw_dma(rsrc, 0u, 1); ld_advance();                                       // raw(0)
         raw_dma(rsrc, RB4 * 4u, 0); raw_dma(rsrc, RB4 * 4u, 1); ld_advance();                           // raw(1)
         raw_dma(rsrc, 2u * RB4 * 4u, 0); raw_dma(rsrc, 2u * RB4 * 4u, 1); ld_advance();                 // raw(2)
@@ -543,10 +583,12 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     load_prm(cur.slice);
     dma_wait();
     __syncthreads();
-    tf_pass1(); tf_pass1b(RB4 * 4u); tf_pass1w(0); tf_pass1w(1); tf_pass1w(2); tf_pass2(); tf_pass2b();
-    tf_pass2w(0, 0); tf_pass2w(0, 1); tf_pass2w(0, 2);                                // V(0); unit 0 transforms raw(1)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the V stores are asm statements: hipcc does not count them
-    __syncthreads();
+    if constexpr (!VIN) {
+        tf_pass1(); tf_pass1b(RB4 * 4u); tf_pass1w(0); tf_pass1w(1); tf_pass1w(2); tf_pass2(); tf_pass2b();
+        tf_pass2w(0, 0); tf_pass2w(0, 1); tf_pass2w(0, 2);                            // V(0); unit 0 transforms raw(1)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the V stores are asm statements: hipcc does not count them
+        __syncthreads();
+    }
     af[0] = *reinterpret_cast<const f32x4*>(&Us[a_base]);
     bf[0] = *reinterpret_cast<const f32x4*>(&Vs[b_base]);
     af[1] = *reinterpret_cast<const f32x4*>(&Us[a_base + 4]);
@@ -590,13 +632,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                 if (g == slot_g[k] && e == slot_e[k]) prod_step(k, wbuf, 0, px_);
         };
         // the 36 MFMAs of a unit and everything that rides in their shadow: one basic block
-        auto unit_body = [&](const int c, auto first_tag, auto vb_tag) __attribute__((always_inline)) {
+        auto unit_body = [&](const int c, auto first_tag, auto vb_tag, auto vs_tag) __attribute__((always_inline)) {
             constexpr bool FIRST = decltype(first_tag)::value;
             constexpr int vb = decltype(vb_tag)::value;
+            constexpr int vs = VIN ? decltype(vs_tag)::value : vb;        // V buffer of this unit (VIN: ring of four)
+            constexpr int vsn = VIN ? (vs + 1) & 3 : vb ^ 1;             // ... of the next one
             const float* const ur = Us + vb * UB4 + a_base;
-            const float* const vr = Vs + vb * VB4 + b_base;
+            const float* const vr = Vs + vs * VB4 + b_base;
             const float* const urn = Us + (vb ^ 1) * UB4 + a_base;
-            const float* const vrn = Vs + (vb ^ 1) * VB4 + b_base;
+            const float* const vrn = Vs + vsn * VB4 + b_base;
             const float* const un2 = c + 2 < NC ? up + (long long)(c + 2) * UB4 : unext + (long long)(c + 2 - NC) * UB4;
             MPQ_T(t_u0);
 #ifdef MP_TIMING
@@ -610,7 +654,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                     // weights as the A operand: D[cout][tile] -- lane = tile, register quad = 4 consecutive output channels
                     acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[g % 3][e], bf[g % 3][e], FIRST ? zero4 : acc[s], 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (e != 2) tf_at(g, e, vb);
+                    if constexpr (!VIN) { if (e != 2) tf_at(g, e, vb); }
                     if constexpr (F1) prod_at(g, e, vb);
                     if (e == 0 && !(MPQX & 4)) {
                         // fragments two groups ahead; groups 7, 8 fetch groups 0, 1 of the NEXT unit (behind the unit barrier)
@@ -625,13 +669,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                         // but the two patch DMAs, which have until the NEXT barrier.
                         if (g == 7) { u_dma(un2, vb, 0); u_dma(un2, vb, 1); u_dma(un2, vb, 2); }
                         else if (g == 8) { u_dma(un2, vb, 3); u_dma(un2, vb, 4); }
-                        else if (g == 0) { if constexpr (!F1) raw_dma(rsrc, rd_byte, 0); }
-                        else if (g == 1) { if constexpr (!F1) raw_dma(rsrc, rd_byte, 1); }
+                        else if (g == 0) { if constexpr (VIN) v_dma(vcur, (vs + 3) & 3, 0); else if constexpr (!F1) raw_dma(rsrc, rd_byte, 0); }
+                        else if (g == 1) { if constexpr (VIN) v_dma(vcur, (vs + 3) & 3, 1); else if constexpr (!F1) raw_dma(rsrc, rd_byte, 1); }
+                        else if (g == 2) { if constexpr (VIN) v_dma(vcur, (vs + 3) & 3, 2); }
                     } else if (e == 2) {
                         // input transform of unit n+1: raw[vb^1] -> V[vb^1]
                         // input transform of unit n+1, raw -> V[vb^1]: reads, arithmetic and stores of the two passes spread
                         // over groups 0-6 (the schedule table is tf_at())
-                        tf_at(g, 2, vb);
+                        if constexpr (!VIN) tf_at(g, 2, vb);
                     } else {
                         if (g == 6) {
                             // unit barrier: every fragment of the unit has been fetched (two groups ahead), V(n+1) is
@@ -642,6 +687,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                             // U(n+1), raw(n+2) (and an item's output stores) have landed; raw(n+3) stays in flight
                             // (lgkmcnt: the V stores are asm statements hipcc does not count)
                             if constexpr (F1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");     // (no raw DMA in flight: raw(n+2) was produced above)
+                            else if constexpr (VIN) asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");   // U(n+1), V(n+2) landed; V(n+3) stays in flight
                             else asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
                             if (MPQX & 65536) {
 #pragma unroll
@@ -663,9 +709,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
             MPQ_ADD(0, t_u0, t_u1);                                   // a unit incl. its barrier
             MPQ_ADD(1, t_b0, t_b1);                                   // the DMA wait alone (slot 4: the barrier behind it)
         };
-        auto unit = [&](const int c, auto first_tag, auto vb_tag) __attribute__((always_inline)) {
-            unit_body(c, first_tag, vb_tag);
-            if constexpr (F1) {
+        auto unit = [&](const int c, auto first_tag, auto vb_tag, auto vs_tag) __attribute__((always_inline)) {
+            unit_body(c, first_tag, vb_tag, vs_tag);
+            if constexpr (VIN) {
+                v_advance();
+            } else if constexpr (F1) {
                 prod_advance();
             } else {
                 ld_advance();
@@ -675,12 +723,27 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
         };
         using VB0 = std::integral_constant<int, 0>;
         using VB1 = std::integral_constant<int, 1>;
-        unit(0, std::true_type{}, VB0{});
+        using VS2 = std::integral_constant<int, 2>;
+        using VS3 = std::integral_constant<int, 3>;
+        if constexpr (VIN) {          // units per item a multiple of 4 (cin % 16 == 0): unit c lives in U[c & 1], V[c & 3]
+            unit(0, std::true_type{}, VB0{}, VB0{});
+            for (int c = 1; c + 3 < NC; c += 4) {
+                unit(c, std::false_type{}, VB1{}, VB1{});
+                unit(c + 1, std::false_type{}, VB0{}, VS2{});
+                unit(c + 2, std::false_type{}, VB1{}, VS3{});
+                unit(c + 3, std::false_type{}, VB0{}, VB0{});
+            }
+            unit(NC - 3, std::false_type{}, VB1{}, VB1{});
+            unit(NC - 2, std::false_type{}, VB0{}, VS2{});
+            unit(NC - 1, std::false_type{}, VB1{}, VS3{});
+        } else {
+        unit(0, std::true_type{}, VB0{}, VB0{});
         for (int c = 1; c + 1 < NC; c += 2) {
-            unit(c, std::false_type{}, VB1{});
-            unit(c + 1, std::false_type{}, VB0{});
+            unit(c, std::false_type{}, VB1{}, VB1{});
+            unit(c + 1, std::false_type{}, VB0{}, VB0{});
         }
-        unit(NC - 1, std::false_type{}, VB1{});
+        unit(NC - 1, std::false_type{}, VB1{}, VB1{});
+        }
 
         MPQ_T(t_e0);
         MPQ_ADD(3, t_item, t_e0);                                      // whole unit loop of the item
@@ -829,6 +892,59 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     }
 }
 
+// The input transform as a pass of its own (VIN launches): V = B^T d B of every 6x6 window of the layer's NHWC input, written to
+// p.vglobal as [tile block][unit = cin / 4][channel of the unit 4][tile 32][pos 36] -- per (tile block, unit) exactly the 18 KiB the
+// VIN kernel DMAs into a V buffer.  One thread per (tile, channel pair): the column pass and the row pass are the SAME bt6() chains
+// the in-kernel transform runs (column pass first), so V has the same bits.  HBM/L2 streaming: reads 2.25x the input (the windows
+// of adjacent tiles overlap) coalesced over the channel pairs of a pixel, writes 2.25x the input as 144-byte runs.
+template <int TC4>
+__global__ __launch_bounds__(256) void wino43_vprod_kernel(const ConvParams p, long long ntb)
+{
+    constexpr int TR4 = 32 / TC4, OY = 4 * TR4, OX = 4 * TC4;
+    const int ncp = p.cin >> 1, NC = p.cin / UC4;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int cp = (int)(gid % ncp);
+    const long long tl = gid / ncp;
+    const int t = (int)(tl & 31);
+    const long long tb = tl >> 5;
+    if (tb >= ntb) return;
+    const int tx = (int)(tb % p.tiles_x);
+    const long long trow = tb / p.tiles_x;
+    const int ty = (int)(trow % p.tiles_y);
+    const int bi = (int)(trow / p.tiles_y);
+    const int img = p.img_list ? p.img_list[bi] : bi;
+    const int wy = ty * OY + 4 * (t / TC4) - 1, wx = tx * OX + 4 * (t % TC4) - 1;      // frame position of the window's corner
+    const float* const base = p.in + (long long)img * p.H * p.W * p.in_cstride + p.in_coff + 2 * cp;
+    int gx[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) gx[j] = reflect_clamp_q(wx + j, p.W);
+    f32x2 r[6][6];                                       // r[i'][j] = (B^T d)[i'][column j]
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        f32x2 d[6], o[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+            d[i] = *reinterpret_cast<const f32x2*>(base + ((long long)reflect_clamp_q(wy + i, p.H) * p.W + gx[j]) * p.in_cstride);
+        bt6(d, o);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[i][j] = o[i];
+    }
+    float* const dst0 = p.vglobal + (((tb * NC + (cp >> 1)) * 4 + 2 * (cp & 1)) * 32 + t) * 36;      // channel 2 cp of the unit
+    float* const dst1 = dst0 + 32 * 36;
+#pragma unroll
+    for (int i = 0; i < 6; i += 2) {                     // two rows = 12 positions = three 16-byte stores per channel
+        f32x2 a[6], b[6];
+        bt6(r[i], a);
+        bt6(r[i + 1], b);
+        *reinterpret_cast<f32x4*>(dst0 + 6 * i) = f32x4{a[0][0], a[1][0], a[2][0], a[3][0]};
+        *reinterpret_cast<f32x4*>(dst0 + 6 * i + 4) = f32x4{a[4][0], a[5][0], b[0][0], b[1][0]};
+        *reinterpret_cast<f32x4*>(dst0 + 6 * i + 8) = f32x4{b[2][0], b[3][0], b[4][0], b[5][0]};
+        *reinterpret_cast<f32x4*>(dst1 + 6 * i) = f32x4{a[0][1], a[1][1], a[2][1], a[3][1]};
+        *reinterpret_cast<f32x4*>(dst1 + 6 * i + 4) = f32x4{a[4][1], a[5][1], b[0][1], b[1][1]};
+        *reinterpret_cast<f32x4*>(dst1 + 6 * i + 8) = f32x4{b[2][1], b[3][1], b[4][1], b[5][1]};
+    }
+}
+
 template <bool POOL, int TC4, bool F1 = false, bool SPLIT = false>
 int launch_q(const ConvParams& p, hipStream_t s)
 {
@@ -847,6 +963,29 @@ int launch_q(const ConvParams& p, hipStream_t s)
     const ConvParams& pp = q;
     if (p.bn_first) hipLaunchKernelGGL((conv_wino43_kernel<POOL, true, TC4, F1, SPLIT>), dim3(grid), dim3(512), 0, s, pp);
     else hipLaunchKernelGGL((conv_wino43_kernel<POOL, false, TC4, F1, SPLIT>), dim3(grid), dim3(512), 0, s, pp);
+    return 0;
+}
+
+// two passes: the input transform into p.vglobal, then the GEMMs + output transform per (tile block, slice) with V by DMA
+template <int TC4>
+int launch_vin(const ConvParams& p, hipStream_t s)
+{
+    constexpr int OY = 4 * (32 / TC4), OX = 4 * TC4;
+    ConvParams q = p;
+    q.tiles_x = (p.W + OX - 1) / OX; q.tiles_y = (p.H + OY - 1) / OY;
+    const long long ntb = (long long)p.B * q.tiles_x * q.tiles_y, nitems = ntb * q.nslices;
+    if (nitems <= 0) return 0;
+    auto magic = [](int d) -> unsigned { return d <= 1 ? 0u : (unsigned)((0x100000000ull / (unsigned)d) + 1ull); };
+    q.magic_slices = magic(q.nslices); q.magic_tx = magic(q.tiles_x); q.magic_ty = magic(q.tiles_y);
+    const long long dmax = std::max(std::max(q.nslices, q.tiles_x), q.tiles_y);
+    if (nitems * dmax >= 0x100000000ll) return 1;
+    q.nitems = (int)nitems;
+    const ConvParams& pp = q;
+    const long long threads = ntb * 32 * (p.cin / 2);
+    hipLaunchKernelGGL((wino43_vprod_kernel<TC4>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, pp, ntb);
+    const unsigned grid = persistent_grid(nitems, p.ncu, p.xcd_shift);
+    if (p.bn_first) hipLaunchKernelGGL((conv_wino43_kernel<false, true, TC4, false, false, true>), dim3(grid), dim3(512), 0, s, pp);
+    else hipLaunchKernelGGL((conv_wino43_kernel<false, false, TC4, false, false, true>), dim3(grid), dim3(512), 0, s, pp);
     return 0;
 }
 
@@ -870,6 +1009,13 @@ bool conv_wino43_supports(const ConvParams& p)
 }
 
 // work items of a launch (the larger of the two item shapes' counts is never chosen): what api.hip sizes the split by
+// floats of p.vglobal a pre-transformed launch of this layer needs: tile blocks x (cin / 4) units x 18 KiB
+long long conv_wino43_vglobal_floats(const ConvParams& p)
+{
+    const long long wide = (long long)((p.W + 31) / 32) * ((p.H + 15) / 16), tall = (long long)((p.W + 15) / 16) * ((p.H + 31) / 32);
+    return (long long)p.B * std::min(wide, tall) * (p.cin / UC4) * VB4;
+}
+
 long long conv_wino43_items(const ConvParams& p)
 {
     const long long wide = (long long)((p.W + 31) / 32) * ((p.H + 15) / 16), tall = (long long)((p.W + 15) / 16) * ((p.H + 31) / 32);
@@ -883,6 +1029,11 @@ long long conv_wino43_items(const ConvParams& p)
 int launch_conv_wino43(const ConvParams& p, bool pool, hipStream_t s, bool fuse_first)
 {
     if (fuse_first) return pool && p.cin == 64 ? launch_q<true, 8, true>(p, s) : 2;          // 2: shape not covered
+    if (p.vglobal) {       // pre-transformed input (api.hip: un-pooled layers with >= 4 output slices; cin a multiple of 16, NHWC)
+        if (pool || p.ks_shift > 0 || p.cin % 16 != 0 || p.in_planar) return 2;
+        const long long wide = (long long)((p.W + 31) / 32) * ((p.H + 15) / 16), tall = (long long)((p.W + 15) / 16) * ((p.H + 31) / 32);
+        return tall < wide ? launch_vin<4>(p, s) : launch_vin<8>(p, s);
+    }
     if (p.ks_shift > 0) {
         const int ncs = (p.cin / 4) >> p.ks_shift;
         if (ncs < 4 || (ncs & 1) || (ncs << p.ks_shift) * 4 != p.cin || !p.split_scratch) return 2;

@@ -35,12 +35,21 @@ __device__ __forceinline__ void dma16h(const _Float16* sbase, unsigned voff_byte
 }
 __device__ __forceinline__ void dma_wait_h() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// conv output (fp32 accumulator) -> what autocast leaves: fp16(acc + bias), then the BatchNorm affine in fp32, rounded to fp16
-// (conv_f16.hip's act_h2 without the ReLU: the 1x1 head convolutions have none, MultiPoint.py:66-72,82-86)
-__device__ __forceinline__ float head_act(float a, float bias, float scale, float shift)
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// conv output pair (fp32 accumulators) -> what autocast leaves: fp16(acc + bias), then the BatchNorm affine in fp32, rounded to
+// fp16.  Written on a PAIR exactly like conv_f16.hip's act_h2 (without the ReLU: the 1x1 head convolutions have none,
+// MultiPoint.py:66-72,82-86) so that hipcc emits v_pk_add_f32 / v_cvt_pk_f16_f32 / v_pk_fma_f32: the scalar form becomes
+// v_fma_mixlo_f16 -- ONE rounding from the exact product-sum to fp16 where autocast rounds to fp32 first and to fp16 second,
+// which flips output bits.
+__device__ __forceinline__ f32x2 head_act2(float a0, float a1, f32x2 bias, f32x2 scale, f32x2 shift)
 {
-    const _Float16 h = (_Float16)(a + bias);
-    return (float)(_Float16)((float)h * scale + shift);
+    const f32x2 x = f32x2{a0, a1} + bias;
+    const h2 h = __builtin_convertvector(x, h2);
+    f32x2 y = __builtin_convertvector(h, f32x2) * scale + shift;
+    asm volatile("" : "+v"(y));      // y exists as an fp32 pair: no fused multiply-add-and-round-to-fp16 even where one half is unused
+    const h2 o = __builtin_convertvector(y, h2);
+    return __builtin_convertvector(o, f32x2);
 }
 
 // ND = D / 32 descriptor blocks (0: no descriptor head)
@@ -51,8 +60,10 @@ __global__ __launch_bounds__(256) void head_tail_f16_kernel(const HeadTailParams
     constexpr int NP = 96 + 32 * ND;
     constexpr int WCH = 4 * NT * 512;                             // halfs of one chunk's weights: [kgroup4][tile NT][lane][8]
     constexpr int XCH = 2 * 4 * 512;                              // halfs of one wave's X chunk: [det|desc][kgroup4][lane][8]
-    __shared__ __attribute__((aligned(16))) _Float16 wl[2 * WCH];
-    __shared__ __attribute__((aligned(16))) _Float16 xl[2 * 4 * XCH];
+    constexpr int NBUF = ND <= 2 ? 3 : 2, PD = NBUF - 1;          // chunk buffers / chunks in flight (LDS: 3 x 52 KiB for D = 64)
+    constexpr int NDMA = NT + (ND ? 8 : 4);                       // DMAs a wave issues per chunk
+    __shared__ __attribute__((aligned(16))) _Float16 wl[NBUF * WCH];
+    __shared__ __attribute__((aligned(16))) _Float16 xl[NBUF * 4 * XCH];
     __shared__ __attribute__((aligned(16))) float prm[3 * NP];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -98,9 +109,17 @@ __global__ __launch_bounds__(256) void head_tail_f16_kernel(const HeadTailParams
         }
     };
 
+    // ring of NBUF chunk buffers, PD = NBUF - 1 chunks in flight: the kernel is a stream with 20 MFMAs (640 cycles) per chunk, so a
+    // chunk's DMAs must be issued well over an HBM round trip (~3-4 k cycles under load) ahead -- with ONE chunk ahead (the
+    // fp32 kernel's double buffer, whose chunk is 5 k cycles of MFMAs) every chunk waited for its own latency: 0.130 ms for 16
+    // frames 1024x1280; three buffers fit the LDS up to D = 64 (3 x 52 KiB)
+    int bufi = 0;                                                 // ring slot of the chunk being multiplied
 #pragma unroll
-    for (int j = 0; j < NT + 8; ++j) chunk_dma(0, 0, j, false);
-    dma_wait_h();
+    for (int d = 0; d < PD; ++d) {
+#pragma unroll
+        for (int j = 0; j < NT + 8; ++j) chunk_dma(d, d, j, false);
+    }
+    if (PD == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory"); else dma_wait_h();
     __syncthreads();                                              // chunk 0 and prm visible
 
     for (;;) {
@@ -114,12 +133,16 @@ __global__ __launch_bounds__(256) void head_tail_f16_kernel(const HeadTailParams
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    // the 4 * NT MFMAs of a chunk; the NT + 8 DMAs of the next chunk ride one per MFMA behind the first ones; fragments are
-    // fetched one k-group ahead
-    auto chunk = [&](int c, auto buf_tag, bool prefetch, bool next_tile) __attribute__((always_inline)) {
-        constexpr int buf = decltype(buf_tag)::value;
-        const _Float16* const wb = wl + buf * WCH + lane * 8;
-        const _Float16* const xb = xl + wave * XCH + buf * 4 * XCH + lane * 8;
+    // the 4 * NT MFMAs of chunk c (ring slot bufi); the NT + 8 DMAs of the chunk PD ahead -- of this tile, or of the next one --
+    // ride one per MFMA behind the first ones into the slot that was read last; fragments are fetched one k-group ahead
+    for (int c = 0; c < nchunks; ++c) {
+        const int ct = c + PD;                                    // the chunk to fetch
+        const bool next_tile = ct >= nchunks;
+        const bool prefetch = !next_tile || has_next;
+        const int cf = next_tile ? ct - nchunks : ct;
+        int bt = bufi + PD; bt = bt >= NBUF ? bt - NBUF : bt;
+        const _Float16* const wb = wl + bufi * WCH + lane * 8;
+        const _Float16* const xb = xl + wave * XCH + bufi * 4 * XCH + lane * 8;
         h8 wf[2][NT], xd[2], xs[2];
         auto frags = [&](int slot, int g) __attribute__((always_inline)) {
 #pragma unroll
@@ -136,20 +159,16 @@ __global__ __launch_bounds__(256) void head_tail_f16_kernel(const HeadTailParams
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[g & 1][t], t < 3 ? xd[g & 1] : xs[g & 1], acc[t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 const int m = g * NT + t;
-                if (prefetch && m < NT + 8) chunk_dma(next_tile ? 0 : c + 1, buf ^ 1, m, next_tile);
+                if (m < NT + 8) { if (prefetch) chunk_dma(cf, bt, m, next_tile); }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        dma_wait_h();
+        // chunk c + 1 must have landed; with PD = 2 the NDMA operations this chunk issued may stay in flight (the vector memory
+        // counter retires loads in order, so "at most NDMA outstanding" means everything older than them -- the previous chunk's
+        // DMAs and the epilogue's stores, which count in vmcnt too -- has completed)
+        if (PD == 2 && prefetch) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NDMA) : "memory"); else dma_wait_h();
         __syncthreads();                                          // next chunk landed, this one consumed
-    };
-    using B0 = std::integral_constant<int, 0>;
-    using B1 = std::integral_constant<int, 1>;
-    // (the number of chunks is even: launch_head_tail_f16 checks K % 128 == 0)
-    for (int c = 0; c < nchunks; c += 2) {
-        chunk(c, B0{}, true, false);
-        const bool lastc = c + 2 >= nchunks;
-        chunk(c + 1, B1{}, !lastc || has_next, lastc);
+        bufi = bufi + 1 == NBUF ? 0 : bufi + 1;
     }
 
     // ---- detector: bias -> fp16 -> BN -> fp16, softmax over 65 channels in fp32 -> shuffle ----
@@ -161,12 +180,15 @@ __global__ __launch_bounds__(256) void head_tail_f16_kernel(const HeadTailParams
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int c = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hf;
-                v[16 * t + r] = head_act(acc[t][r], prm[c], prm[NP + c], prm[2 * NP + c]);
+            for (int r = 0; r < 16; r += 2) {
+                const int c = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * hf;              // registers r, r + 1 = channels c, c + 1
+                const f32x2 o = head_act2(acc[t][r], acc[t][r + 1], f32x2{prm[c], prm[c + 1]}, f32x2{prm[NP + c], prm[NP + c + 1]},
+                                          f32x2{prm[2 * NP + c], prm[2 * NP + c + 1]});
+                v[16 * t + r] = o[0]; v[16 * t + r + 1] = o[1];
             }
         // the dustbin (channel 64) is row 0 of block 2: register 0 of the lower half-wave; both halves need it
-        float d = head_act(acc[2][0], prm[64], prm[NP + 64], prm[2 * NP + 64]);
+        float d = head_act2(acc[2][0], acc[2][1], f32x2{prm[64], prm[65]}, f32x2{prm[NP + 64], prm[NP + 65]},
+                            f32x2{prm[2 * NP + 64], prm[2 * NP + 65]})[0];
         d = __shfl(d, pl);                                            // from lane pl (hf = 0)
         if (p.logits_nchw && valid) {
             const long long plane = (long long)p.Hc * p.Wc;
@@ -218,11 +240,13 @@ __global__ __launch_bounds__(256) void head_tail_f16_kernel(const HeadTailParams
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int c = 32 * t + 8 * q + 4 * hf + e;
-                        const float x = head_act(acc[3 + t][4 * q + e], prm[96 + c], prm[NP + 96 + c], prm[2 * NP + 96 + c]);
-                        dv[4 * t + q][e] = x;
-                        ss += x * x;
+                    for (int e = 0; e < 4; e += 2) {
+                        const int c = 96 + 32 * t + 8 * q + 4 * hf + e;
+                        const f32x2 x = head_act2(acc[3 + t][4 * q + e], acc[3 + t][4 * q + e + 1], f32x2{prm[c], prm[c + 1]},
+                                                  f32x2{prm[NP + c], prm[NP + c + 1]}, f32x2{prm[2 * NP + c], prm[2 * NP + c + 1]});
+                        dv[4 * t + q][e] = x[0]; dv[4 * t + q][e + 1] = x[1];
+                        ss += x[0] * x[0];
+                        ss += x[1] * x[1];
                     }
             if (p.normalize) {
                 ss += __shfl_xor(ss, 32);

@@ -51,6 +51,10 @@ struct ConvParams {
     // launch on the stream) sums them in range order and runs the rest of the epilogue.  ks_shift = 0: off.
     int ks_shift;
     float* split_scratch;     // [virtual item][32 or 64 values][512 or 256 threads] f32x2 (128 KiB per virtual item)
+    // conv_wino43.hip, layers with many output slices (the 3x3 head convolutions): the input transform runs as a pass of its own
+    // into vglobal [tile block][cin / 4][4][32][36] (conv_wino43_vglobal_floats()) and every slice's launch items DMA V from there
+    // instead of transforming the same windows again.  nullptr: the transform runs inside the kernel, per slice.
+    float* vglobal;
 };
 
 // persistent schedule shared by the persistent kernels: the items are cut into one contiguous range per XCD, and the
@@ -136,6 +140,7 @@ __device__ __forceinline__ mp_f32x2 w43_add_bias(mp_f32x2 z, int r, int c, mp_f3
 }
 bool conv_wino43_supports(const ConvParams& p);
 long long conv_wino43_items(const ConvParams& p);      // work items the launch would have (B x tile blocks x slices)
+long long conv_wino43_vglobal_floats(const ConvParams& p);      // size of ConvParams::vglobal for this layer
 int launch_conv_wino43(const ConvParams& p, bool pool, hipStream_t s, bool fuse_first = false);
 // second generation (conv_wino43b.hip): one wave per SIMD, whole-window input transform; any frame size
 bool conv_wino43b_supports(const ConvParams& p);
@@ -163,7 +168,7 @@ struct ConvParamsH {
     int nitems;           // work items (tile, slice) of the launch (filled in by the launcher)
     _Float16* dummy;      // >= 1 KiB scratch line that masked-off store lanes write to
     int ncu, xcd_shift;   // machine shape, as in ConvParams
-    int res_groups;       // conv_f16_res.hip: independent four-wave groups per CU (3; 2 = MP_F16_RES_GROUPS=2; the fused-first-block launch always runs 2)
+    int res_groups;       // conv_f16_res.hip: independent four-wave groups per CU (3; 2 = MP_DEBUG=f16_res_groups=2; the fused-first-block launch always runs 2)
     // conv_f16_res.hip with the first encoder block fused in: the fp32 image [B][H][W] and the Cin = 1 layer's parameters
     // ([9][64] tap-major fp16-representable weights, bias, BN scale / shift); img == nullptr: p.in is read
     const float* img;

@@ -73,7 +73,7 @@ class PairPipeline:
         self.tie_redone = 0             # images the latest run_converged() redid; tie_redone_total: since construction
         self.tie_redone_total = 0
         self.tie_flagged = 0            # images flagged since the previous check_converged() (throughput entry: reported only)
-        self.overlap_post = overlap_post and os.environ.get('MP_POST_OVERLAP', '1') != '0'     # (developer A/B switch)
+        self.overlap_post = overlap_post and _lib.debug_switch('post_overlap', '1') != '0'     # (developer A/B switch: MP_DEBUG=post_overlap=0)
         self._post_stream = None
         self._fwd_stream = None
         self._last = None           # results of the latest run_interleaved() (check_converged inspects their counts)
@@ -138,8 +138,8 @@ class PairPipeline:
             # dependent post-processing kernels keeps landing on freed CUs and the convolution's last workgroups start up to
             # 0.4 ms late (measured: enc.conv1+2 4.35 instead of 4.05 ms).
             if self._post_stream is None or self._post_stream.device != dev:
-                self._post_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("MP_POST_PRIORITY", "0")))
-                self._fwd_stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("MP_FWD_PRIORITY", "-1")))
+                self._post_stream = torch.cuda.Stream(device=dev, priority=int(_lib.debug_switch("post_priority", "0")))
+                self._fwd_stream = torch.cuda.Stream(device=dev, priority=int(_lib.debug_switch("fwd_priority", "-1")))
             post, fwd = self._post_stream, self._fwd_stream
             if not main.query():                                    # the inputs were produced on the caller's stream: wait for whatever
                 fwd.wait_stream(main)                               # is still pending there (nothing, in a steady pipeline: no packet)

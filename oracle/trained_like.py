@@ -162,7 +162,7 @@ SEVERITIES = {
 
 # kernel families of the 3x3 layers: the default (conv_wino43.hip where it applies, first block fused), the any-frame-size
 # F(4x4,3x3) kernel on every layer (conv_wino43b.hip), the direct implicit-GEMM kernels
-VARIANT_ENV = {'F(4x4,3x3)': {}, 'F(4x4,3x3) general': {'MP_WINO43_GEN': '2'}, 'direct': {'MP_NO_WINOGRAD': '1'}}
+VARIANT_ENV = {'F(4x4,3x3)': {}, 'F(4x4,3x3) general': {'MP_DEBUG': 'wino43_gen=2'}, 'direct': {'MP_DEBUG': 'no_winograd'}}
 
 
 def case(severity, seed, B, H, W, cfg=None):
@@ -187,7 +187,7 @@ def gpu_outputs(cfg, sd, img, env):
     """prob / desc / logits of the HIP path with the given kernel-selection environment (a new handle reads it)."""
     import os
     import multipoint_amd.models as M
-    old = {k: os.environ.get(k) for k in ('MP_WINO43', 'MP_NO_WINOGRAD', 'MP_WINO43_GEN')}
+    old = {k: os.environ.get(k) for k in ('MP_DEBUG',)}
     try:
         for k in old:
             os.environ.pop(k, None)

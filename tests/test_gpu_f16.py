@@ -220,13 +220,13 @@ def test_f16_forward_against_reference_autocast_fixture(oracle, golden_dir, f16,
     assert np.abs(v['prob'][0] - v['prob'][1]).max() <= PROB_TOL_F16
 
 
-@pytest.mark.parametrize('env', [{'MP_F16_NO_FUSE1': '1'}, {'MP_F16_NO_RES': '1'}, {'MP_F16_RES_GROUPS': '2'}])
+@pytest.mark.parametrize('env', [{'MP_DEBUG': 'f16_no_fuse1'}, {'MP_DEBUG': 'f16_no_res'}, {'MP_DEBUG': 'f16_res_groups=2'}])
 @pytest.mark.parametrize('upd', [{}, {'bn_first': True}, {'multispectral': True}])
 @pytest.mark.parametrize('B,H,W', [(3, 72, 104), (2, 16, 16), (1, 240, 320), (2, 480, 640), (5, 40, 264)])
 def test_f16_kernel_variants_agree(oracle, monkeypatch, env, upd, B, H, W):
     """The default fp16 path (64 -> 64 layers on the LDS-resident-weights kernel, three groups per CU, the first encoder block
-    evaluated inside the conv2 launch on the matrix pipe) against: the first block as its own launch (MP_F16_NO_FUSE1), the
-    streaming kernel on every layer (MP_F16_NO_RES), two groups per CU -- same rounding points, fp32 accumulation in another
+    evaluated inside the conv2 launch on the matrix pipe) against: the first block as its own launch (MP_DEBUG=f16_no_fuse1), the
+    streaming kernel on every layer (MP_DEBUG=f16_no_res), two groups per CU -- same rounding points, fp32 accumulation in another
     order, so the outputs agree to rounding flips: borders (two nested reflections), partial tiles (all three tile shapes),
     bn_first, two encoders.  Both sides also match the fp16 oracle."""
     from oracle import f16_stats as S
@@ -252,7 +252,7 @@ def test_f16_kernel_variants_agree(oracle, monkeypatch, env, upd, B, H, W):
 @pytest.mark.parametrize('B,H,W', [(3, 72, 104), (1, 240, 320), (2, 480, 640), (1, 8, 8)])
 def test_f16_fused_head_tail_equals_separate_launches(oracle, monkeypatch, upd, B, H, W):
     """head_tail_f16.hip (both 1x1 head convolutions + BatchNorm + softmax / shuffle + L2 normalisation in ONE launch, operands
-    by LDS-DMA) against the four launches it replaces (MP_NO_HEAD_FUSE=1: conv_f16.hip 1x1 x 2, det_post, desc_l2norm).  Same
+    by LDS-DMA) against the four launches it replaces (MP_DEBUG=no_head_fuse: conv_f16.hip 1x1 x 2, det_post, desc_l2norm).  Same
     rounding points and the SAME accumulation order over K (one MFMA chain per output, k ascending): the fp16 logits are
     bit-identical; prob / desc differ only by exp / reciprocal rounding in fp32 (MultiPoint.py:66-75,82-86,150-166 under autocast)."""
     img = oracle.make_images(17 + W, B, H, W).cuda()
@@ -260,7 +260,7 @@ def test_f16_fused_head_tail_equals_separate_launches(oracle, monkeypatch, upd, 
     a = net({'image': img})
     net.set_force_return_logits(True)
     al = net({'image': img})['logits']
-    monkeypatch.setenv('MP_NO_HEAD_FUSE', '1')
+    monkeypatch.setenv('MP_DEBUG', 'no_head_fuse')
     net2, _, _ = _net(oracle, upd, seed=3)
     b = net2({'image': img})
     net2.set_force_return_logits(True)

@@ -50,20 +50,18 @@ def test_forward_matches_oracle(oracle, shipped, B, H, W):
     assert (out['desc'].cpu() - ref['desc']).abs().max().item() <= DESC_TOL
 
 
-@pytest.mark.parametrize('env', [{'MP_PERSIST_MIN_ITEMS': '1'}, {'MP_NO_PERSIST': '1'}, {'MP_NO_FUSE': '1'},
-                                 {'MP_NO_WINOGRAD': '1'}, {'MP_NO_WINOGRAD': '1', 'MP_NO_FUSE': '1'},
-                                 {'MP_NO_HEAD_FUSE': '1'}, {'MP_WINO43': '0'}, {'MP_WINO43': '1'}, {'MP_NO_PLANAR': '1'},
-                                 {'MP_PLANAR': '2'}, {'MP_WINO43': '1', 'MP_PLANAR': '2'}, {'MP_NO_FUSE43': '1'},
-                                 {'MP_WINO43_GEN': '2'}, {'MP_WINO43_GEN': '2', 'MP_PLANAR': '2'}, {'MP_WINO43_GEN': '1'}])
+@pytest.mark.parametrize('env', [{'MP_DEBUG': v} for v in (
+    'persist_min_items=1', 'no_persist', 'no_fuse', 'no_winograd', 'no_winograd,no_fuse', 'no_head_fuse', 'wino43=0', 'wino43=1',
+    'no_planar', 'planar=2', 'wino43=1,planar=2', 'no_fuse43', 'wino43_gen=2', 'wino43_gen=2,planar=2', 'wino43_gen=1', 'no_vin')])
 @pytest.mark.parametrize('B,H,W', [(6, 120, 160), (3, 200, 328), (3, 240, 320), (4, 64, 96)])
 def test_forward_kernel_variants(oracle, monkeypatch, env, B, H, W):
     """Every convolution kernel variant against the oracle on the same inputs: the persistent one-workgroup-per-CU
     kernel forced onto small launches (all tile shapes, partial tiles at the right/bottom edge), the per-tile kernel
     only, the unfused first block in front of the direct second convolution, the first block fused into the direct kernel, the four separate head-tail launches instead of the fused
-    head_tail kernel, no Winograd kernel at all (MP_WINO43=0), F(4x4,3x3) on the 64-input-channel layers only
-    (MP_WINO43=1), the any-frame-size F(4x4,3x3) kernel on EVERY 3x3 layer (MP_WINO43_GEN=2: conv_wino43b.hip) or on none (=1: the direct
-    kernels take the frames conv_wino43.hip does not), NHWC everywhere (MP_NO_PLANAR=1) or channel-quad-planar tensors between EVERY two F(4x4,3x3) layers
-    (MP_PLANAR=2) instead of behind conv1 and the pooled layers only.  The default -- standalone first block writing
+    head_tail kernel, no Winograd kernel at all (MP_DEBUG=wino43=0), F(4x4,3x3) on the 64-input-channel layers only
+    (MP_DEBUG=wino43=1), the any-frame-size F(4x4,3x3) kernel on EVERY 3x3 layer (MP_DEBUG=wino43_gen=2: conv_wino43b.hip) or on none (=1: the direct
+    kernels take the frames conv_wino43.hip does not), NHWC everywhere (MP_DEBUG=no_planar) or channel-quad-planar tensors between EVERY two F(4x4,3x3) layers
+    (MP_DEBUG=planar=2) instead of behind conv1 and the pooled layers only.  The default -- standalone first block writing
     planar, conv_wino43.hip on every 3x3 layer whose frame is a multiple of 4 (conv_wino43b.hip otherwise), LDS-DMA staging -- is
     what every other test of this file runs.  (240x320: conv1-5 are multiples of 4 and run F(4x4,3x3), conv6-8 and the heads
     at 60x80 too, ... 30x40 is not: the deep layers take the any-frame-size kernel inside the SAME forward -- the mixed case the frame-size rule
@@ -84,10 +82,10 @@ def test_split_input_channels_on_small_launches(oracle, monkeypatch, B, H, W, ge
     """Single-pair latency path (forwards of one or two images): an F(4x4,3x3) launch with fewer items than half the CUs runs the input channels of an item as
     2 / 4 / 8 separate items whose pre-bias output tiles split_reduce_kernel (conv_split.hip) sums in range order (conv_wino43.hip and -- gen '2':
     every layer; default routing: the layers whose frame is no multiple of 4 -- conv_wino43b.hip, SPLIT).
-    Against the oracle, against the unsplit launch (MP_SPLITK_MAX=1: another summation order, same tolerance class as any two
+    Against the oracle, against the unsplit launch (MP_DEBUG=splitk_max=1: another summation order, same tolerance class as any two
     kernel variants), and bit-identical from run to run."""
     if gen:
-        monkeypatch.setenv('MP_WINO43_GEN', gen)
+        monkeypatch.setenv('MP_DEBUG', 'wino43_gen=' + gen)
     img = oracle.make_images(77 + W, B, H, W)
     net, sd = _net(oracle, oracle.SHIPPED_MODEL_CONFIG, seed=9)
     a = net({'image': img.cuda()})
@@ -96,13 +94,13 @@ def test_split_input_channels_on_small_launches(oracle, monkeypatch, B, H, W, ge
         a3 = net({'image': img.cuda()})
         assert torch.equal(a['prob'], a3['prob']) and torch.equal(a['desc'], a3['desc'])
     assert torch.equal(a['prob'], a2['prob']) and torch.equal(a['desc'], a2['desc'])
-    monkeypatch.setenv('MP_SPLITK_MAX', '1')
+    monkeypatch.setenv('MP_DEBUG', ('wino43_gen=' + gen + ',' if gen else '') + 'splitk_max=1')
     net1, _ = _net(oracle, oracle.SHIPPED_MODEL_CONFIG, seed=9)
     b = net1({'image': img.cuda()})
-    monkeypatch.setenv('MP_SPLITK_MAX', '2')
+    monkeypatch.setenv('MP_DEBUG', ('wino43_gen=' + gen + ',' if gen else '') + 'splitk_max=2')
     net2, _ = _net(oracle, oracle.SHIPPED_MODEL_CONFIG, seed=9)
     c = net2({'image': img.cuda()})
-    monkeypatch.setenv('MP_SPLITK_MAX', '4')
+    monkeypatch.setenv('MP_DEBUG', ('wino43_gen=' + gen + ',' if gen else '') + 'splitk_max=4')
     net4, _ = _net(oracle, oracle.SHIPPED_MODEL_CONFIG, seed=9)
     d = net4({'image': img.cuda()})
     ref = oracle.forward(sd, img, oracle.SHIPPED_MODEL_CONFIG)
@@ -174,7 +172,7 @@ def test_batch_invariant_setting(oracle, H, W):
     assert (part['prob'] - big['prob'][0:2]).abs().max().item() <= 3e-5 and (part['desc'] - big['desc'][0:2]).abs().max().item() <= 3e-6
 
 
-@pytest.mark.parametrize('env', [{}, {'MP_WINO43': '0'}, {'MP_NO_WINOGRAD': '1'}])
+@pytest.mark.parametrize('env', [{}, {'MP_DEBUG': 'wino43=0'}, {'MP_DEBUG': 'no_winograd'}])
 @pytest.mark.parametrize('upd', [{}, {'multispectral': True, 'bn_first': True}, {'reflection_pad': False},
                                  {'channel_version': 1, 'descriptor_size': 128}])
 @pytest.mark.parametrize('B,H,W', [(3, 72, 104), (2, 240, 320), (1, 16, 16)])
@@ -201,7 +199,7 @@ def test_single_convolution_per_stage(oracle, monkeypatch, env, upd, B, H, W):
 def test_first_block_inside_f43_equals_standalone(oracle, monkeypatch, upd, B, H, W):
     """The first encoder block evaluated inside the F(4x4,3x3) conv2 kernel (default; round 3: per unit, straight into the raw LDS
     ring, nine rank-1 v_mfma_f32_4x4x1 updates per pixel with the bias as the accumulator's initial value) against the standalone
-    first-block launch (MP_NO_FUSE43=1: a k-ordered multiply-add chain, bias added last): the same nine products and the bias summed
+    first-block launch (MP_DEBUG=no_fuse43: a k-ordered multiply-add chain, bias added last): the same nine products and the bias summed
     in another order, so the block's outputs differ by an ulp here and there and the network outputs by what that becomes
     downstream (measured: prob <= 1.0e-5, desc <= 6e-7 between the two; each of them 6.5e-6 .. 9.9e-6 from an fp64 evaluation,
     the fp32 CPU oracle 7e-6 .. 1.2e-5) -- borders (two nested reflections), partial items, two encoders, bn_first."""
@@ -210,7 +208,7 @@ def test_first_block_inside_f43_equals_standalone(oracle, monkeypatch, upd, B, H
     flags = torch.tensor([[i % 2 == 0] for i in range(B)])
     net, sd = _net(oracle, cfg, seed=6)
     a = net({'image': img.cuda(), 'is_optical': flags})
-    monkeypatch.setenv('MP_NO_FUSE43', '1')
+    monkeypatch.setenv('MP_DEBUG', 'no_fuse43')
     net2, _ = _net(oracle, cfg, seed=6)
     b = net2({'image': img.cuda(), 'is_optical': flags})
     ref = oracle.forward(sd, img, cfg, is_optical=flags)
@@ -219,23 +217,43 @@ def test_first_block_inside_f43_equals_standalone(oracle, monkeypatch, upd, B, H
     assert (a['prob'] - b['prob']).abs().max().item() <= 3e-5 and (a['desc'] - b['desc']).abs().max().item() <= 3e-6
 
 
+@pytest.mark.parametrize('upd', [{}, {'multispectral': True}, {'bn_first': True}, {'descriptor_size': 128}, {'descriptor_head': False}])
+@pytest.mark.parametrize('B,H,W', [(3, 72, 104), (2, 16, 16), (1, 240, 320), (5, 120, 160), (2, 480, 640)])
+def test_pretransformed_head_input_is_bit_identical(oracle, monkeypatch, upd, B, H, W):
+    """The 3x3 head convolutions (512 couts = 8 output slices over ONE input, MultiPoint.py:62-65,78-81) run with their input
+    transform V = B^T d B as a pass of its own (conv_wino43.hip: wino43_vprod_kernel + the VIN instantiation that DMAs V) instead of
+    transforming the same windows once per slice (MP_DEBUG=no_vin).  The producer runs the same column-pass / row-pass chains, so the
+    outputs are EQUAL -- reflected borders, phantom tiles of partial tile blocks, both item shapes (60x80: 8x4 tiles; 9x13: 4x8)."""
+    cfg = dict(oracle.SHIPPED_MODEL_CONFIG); cfg.update(upd)
+    img = oracle.make_images(13 + W, B, H, W)
+    flags = torch.tensor([[i % 2 == 0] for i in range(B)])
+    net, sd = _net(oracle, cfg, seed=8)
+    a = net({'image': img.cuda(), 'is_optical': flags})
+    monkeypatch.setenv('MP_DEBUG', 'no_vin')
+    net2, _ = _net(oracle, cfg, seed=8)
+    b = net2({'image': img.cuda(), 'is_optical': flags})
+    assert torch.equal(a['prob'], b['prob'])
+    assert (a['desc'] is None and b['desc'] is None) or torch.equal(a['desc'], b['desc'])
+    ref = oracle.forward(sd, img, cfg, is_optical=flags)
+    assert (a['prob'].cpu() - ref['prob']).abs().max().item() <= PROB_TOL
+
+
 @pytest.mark.parametrize('upd', [{}, {'multispectral': True}, {'bn_first': True}])
 @pytest.mark.parametrize('B,H,W', [(3, 72, 104), (2, 16, 16), (1, 240, 320), (2, 88, 48)])
 def test_planar_layout_is_bit_identical(oracle, monkeypatch, upd, B, H, W):
     """Channel-quad-planar tensors [B][C/4][H][W][4] between conv1 and the F(4x4,3x3) layers (default) against NHWC everywhere
-    (MP_NO_PLANAR=1): the layout changes which bytes a DMA fetches, not one multiply-add, so the outputs are EQUAL -- partial
+    (MP_DEBUG=no_planar): the layout changes which bytes a DMA fetches, not one multiply-add, so the outputs are EQUAL -- partial
     items, reflected borders, two encoders with image lists."""
     cfg = dict(oracle.SHIPPED_MODEL_CONFIG); cfg.update(upd)
     img = oracle.make_images(23 + W, B, H, W)
     flags = torch.tensor([[i % 2 == 0] for i in range(B)])
     net, sd = _net(oracle, cfg, seed=5)
     a = net({'image': img.cuda(), 'is_optical': flags})
-    monkeypatch.setenv('MP_NO_PLANAR', '1')
+    monkeypatch.setenv('MP_DEBUG', 'no_planar')
     net2, _ = _net(oracle, cfg, seed=5)
     b = net2({'image': img.cuda(), 'is_optical': flags})
     assert torch.equal(a['prob'], b['prob']) and torch.equal(a['desc'], b['desc'])
-    monkeypatch.delenv('MP_NO_PLANAR')
-    monkeypatch.setenv('MP_PLANAR', '2')                # planar between EVERY two F(4x4,3x3) layers (un-pooled producers too)
+    monkeypatch.setenv('MP_DEBUG', 'planar=2')                # planar between EVERY two F(4x4,3x3) layers (un-pooled producers too)
     net3, _ = _net(oracle, cfg, seed=5)
     c = net3({'image': img.cuda(), 'is_optical': flags})
     assert torch.equal(c['prob'], b['prob']) and torch.equal(c['desc'], b['desc'])
@@ -762,7 +780,7 @@ def test_machine_shape_is_derived_from_the_device():
 @pytest.mark.parametrize('shape', [('64', '2'), ('32', '1'), ('200', '8'), ('128', '4')])
 @pytest.mark.parametrize('upd', [{}, {'mixed_precision': True}])
 def test_smaller_machine_shapes_give_the_same_results(oracle, monkeypatch, shape, upd):
-    """A partitioned or CU-masked device (MP_NCU / MP_NXCD emulate one on the full chip): fewer persistent workgroups and
+    """A partitioned or CU-masked device (MP_DEBUG=ncu= / nxcd= emulate one on the full chip): fewer persistent workgroups and
     another XCD split of the work items, bit-identical outputs -- every persistent kernel family (F(4x4,3x3) with the fused
     first block, the any-frame-size kernel on the deep 240x320 layers, the fused head tail, the fp16 kernels)."""
     from multipoint_amd import _lib
@@ -770,7 +788,7 @@ def test_smaller_machine_shapes_give_the_same_results(oracle, monkeypatch, shape
     img = oracle.make_images(77, 6, 240, 320).cuda()
     net, sd = _net(oracle, cfg, seed=3)
     full = net({'image': img})
-    monkeypatch.setenv('MP_NCU', shape[0]); monkeypatch.setenv('MP_NXCD', shape[1])
+    monkeypatch.setenv('MP_DEBUG', 'ncu=%s,nxcd=%s' % shape)
     assert _lib.Handle(0).device_shape()[:2] == (int(shape[0]), int(shape[1]))
     net2, _ = _net(oracle, cfg, seed=3)
     part = net2({'image': img})
@@ -779,6 +797,6 @@ def test_smaller_machine_shapes_give_the_same_results(oracle, monkeypatch, shape
 
 def test_unsupported_machine_shape_is_refused(monkeypatch):
     from multipoint_amd import _lib
-    monkeypatch.setenv('MP_NXCD', '3')
+    monkeypatch.setenv('MP_DEBUG', 'nxcd=3')
     with pytest.raises(_lib.MultiPointHipError, match='unsupported machine shape'):
         _lib.Handle(0)

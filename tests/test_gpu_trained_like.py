@@ -68,7 +68,7 @@ def test_conv_families_on_trained_like_statistics(oracle, sev, variant):
     # scores) -- the top-k tie guard flags exactly those images and the pipeline redoes them with `direct`: 0 of 2 000 on 'mild' /
     # 'wide', 4 of 2 002 on the ill-conditioned 'wide+hot' (where `direct` itself is 5.8e-4 from the oracle's map)
     assert s['keypoints_differing'] <= 0.01 * s['keypoints_total'], s
-    # (the 'direct' variant here is selected by the developer switch MP_NO_WINOGRAD, which the model config does not see: its flagged
+    # (the 'direct' variant here is selected by the developer switch MP_DEBUG=no_winograd, which the model config does not see: its flagged
     # images are redone too -- by the same kernels, to the same bits)
 
 

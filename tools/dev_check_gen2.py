@@ -1,5 +1,5 @@
-"""Developer check (GPU box): conv_wino43b.hip (MP_WINO43_GEN=2) against the CPU oracle on a few shapes, incl. frames that are
-no multiple of the 4x4 tile.  Run as: MP_WINO43_GEN=2 python tools/dev_check_gen2.py"""
+"""Developer check (GPU box): conv_wino43b.hip (MP_DEBUG=wino43_gen=2) against the CPU oracle on a few shapes, incl. frames that are
+no multiple of the 4x4 tile.  Run as: MP_DEBUG=wino43_gen=2 python tools/dev_check_gen2.py"""
 import sys, os
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,6 +18,6 @@ for (B, H, W) in [(2, 64, 64), (1, 240, 320), (3, 72, 104), (2, 480, 640), (1, 8
     p = out['prob'].cpu(); d = out['desc'].cpu()
     ep = (p - ref['prob']).abs().max().item(); ed = (d - ref['desc']).abs().max().item()
     worst = max(worst, ep, ed)
-    print('gen', os.environ.get('MP_WINO43_GEN', '1'), 'fwd', (B, H, W), 'prob maxabs %.3g' % ep, 'desc maxabs %.3g' % ed,
+    print('gen', os.environ.get('MP_DEBUG', ''), 'fwd', (B, H, W), 'prob maxabs %.3g' % ep, 'desc maxabs %.3g' % ed,
           'nan', torch.isnan(p).any().item(), torch.isnan(d).any().item(), flush=True)
 print('WORST', worst, 'OK' if worst < 1e-4 else 'FAIL')

@@ -1,7 +1,7 @@
 """Developer tool (GPU box): random frame sizes / batch sizes / model variants -- the default routing (conv_wino43.hip with the
 fused first block where it applies, conv_wino43b.hip elsewhere; split launches for B <= 2) against the any-frame kernel alone
-(MP_WINO43_GEN=2) and the direct kernels (MP_NO_WINOGRAD=1) on the same inputs; `f16` as the first
-argument: the mixed_precision path (resident weights + fused first block) against the streaming kernels (MP_F16_NO_RES=1) and
+(MP_DEBUG=wino43_gen=2) and the direct kernels (MP_DEBUG=no_winograd) on the same inputs; `f16` as the first
+argument: the mixed_precision path (resident weights + fused first block) against the streaming kernels (MP_DEBUG=f16_no_res) and
 the fp16 oracle.     python tools/fuzz_shapes.py [f16] [trials] [seed]"""
 import os, sys, random, torch
 sys.path.insert(0, os.getcwd())
@@ -24,21 +24,21 @@ for trial in range(NTR):
     H = 8 * random.randint(2, 40); W = 8 * random.randint(2, 60); B = random.choice([1, 1, 2, 2, 3, 4, 5])
     img = O.make_images(trial, B, H, W).cuda()
     flags = torch.tensor([[i % 2 == 0] for i in range(B)])
-    os.environ.pop('MP_WINO43_GEN', None); os.environ.pop('MP_NO_FUSE43', None)
+    os.environ.pop('MP_DEBUG', None)
     a = net(cfg, trial)({'image': img, 'is_optical': flags})
     if F16:
-        os.environ['MP_F16_NO_RES'] = '1'
+        os.environ['MP_DEBUG'] = 'f16_no_res'
         b = net(cfg, trial)({'image': img, 'is_optical': flags})
-        os.environ.pop('MP_F16_NO_RES')
+        os.environ.pop('MP_DEBUG')
         ref = O.forward(O.make_weights(trial, cfg), img.cpu(), cfg, is_optical=flags)
         c = {'prob': ref['prob'].cuda(), 'desc': ref['desc'].cuda()}
     else:
-        os.environ['MP_WINO43_GEN'] = '2'
+        os.environ['MP_DEBUG'] = 'wino43_gen=2'
         b = net(cfg, trial)({'image': img, 'is_optical': flags})
-        os.environ.pop('MP_WINO43_GEN')
-        os.environ['MP_NO_WINOGRAD'] = '1'
+        os.environ.pop('MP_DEBUG')
+        os.environ['MP_DEBUG'] = 'no_winograd'
         c = net(cfg, trial)({'image': img, 'is_optical': flags})
-        os.environ.pop('MP_NO_WINOGRAD')
+        os.environ.pop('MP_DEBUG')
     dp = max((a['prob'] - b['prob']).abs().max().item(), (a['prob'] - c['prob']).abs().max().item())
     dd = max((a['desc'] - b['desc']).abs().max().item(), (a['desc'] - c['desc']).abs().max().item())
     worst = max(worst, dp, dd)
