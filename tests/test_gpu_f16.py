@@ -267,8 +267,8 @@ def test_f16_fused_head_tail_equals_separate_launches(oracle, monkeypatch, upd, 
     bl = net2({'image': img})['logits']
     assert torch.equal(al, bl)
     assert (a['prob'] - b['prob']).abs().max().item() <= 2e-6
-    if a['desc'] is not None:
+    if a.get('desc') is not None:
         assert a['desc'].shape == b['desc'].shape
         assert (a['desc'] - b['desc']).abs().max().item() <= 2e-6 * max(1.0, b['desc'].abs().max().item())
     else:
-        assert b['desc'] is None
+        assert b.get('desc') is None
