@@ -18,6 +18,23 @@
 #include <algorithm>
 #include <type_traits>
 
+#ifdef MP_TIMING
+// developer instrumentation (tools/conv_timing_f16_res.py): per-workgroup cycle sums per phase of the fused conv1+conv2 launch,
+// wave 0 of groups 0 and 1
+__device__ unsigned long long g_timing_r[512 * 8];
+extern "C" int mp_debug_read_timing_f16_res(unsigned long long* host, int n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_timing_r), sizeof(unsigned long long) * n);
+}
+#define MPR_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define MPR_ADD(slot, a, b) do { tsum[slot] += (b) - (a); } while (0)
+#else
+#define MPR_T(var) do { } while (0)
+#define MPR_ADD(slot, a, b) do { } while (0)
+#endif
+#ifndef MPRX
+#define MPRX 0     // developer elimination switches (timing only, results WRONG): 1 no dependence on the staging loads, 2 no epilogue,
+#endif             // 4 no first-block production (F1), 8 no group barriers, 16 one MFMA step per chunk instead of 18
 namespace {
 
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
@@ -71,6 +88,7 @@ __device__ __forceinline__ h2 act_r2(float a0, float a1, f32x2 bias, f32x2 scale
 typedef __attribute__((address_space(3))) unsigned lds_u32;
 __device__ __forceinline__ void group_barrier(lds_u32* ctr, unsigned& target, int lane)
 {
+    if (MPRX & 8) return;
     target += 4;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -264,6 +282,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
         return o;
     };
     auto build_tile = [&](const int par) __attribute__((always_inline)) {
+        if (MPRX & 4) return;
         const _Float16* const ip = ipg + par * NIPB;
         const f32x16 z16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         h8 x[NJ];
@@ -300,6 +319,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
         }
     };
     auto tile_chunk1 = [&]() __attribute__((always_inline)) {
+        if (MPRX & 4) return;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             if ((wave + 4 * j) * 32 >= G::NPIX) continue;
@@ -367,7 +387,11 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
     group_barrier(ctr, bar_target, lane);
 
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#ifdef MP_TIMING
+    unsigned long long tsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (;;) {
+        MPR_T(t_item);
         f32x16 acc[2][2];
         const int item_next = item + stride;
         const bool has_next = item_next < item_end;
@@ -394,6 +418,8 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
             }
             // weight fragments of step s of this chunk: resident block (tap*4 + 2*C + g) -- the packed order of a 64-channel chunk
             auto w_off = [](int s) -> int { return (((s >> 1) * 4 + 2 * C + (s & 1)) * 2) * 512; };
+            MPR_T(t_s0);
+            if (C == 0) MPR_ADD(0, t_item, t_s0);                  // item start -> first step
 #pragma unroll
             for (int s = 0; s < RA - 1; ++s) {
                 af[s][0] = *reinterpret_cast<const h8*>(&lds[a_base + a_off(s)]);
@@ -402,7 +428,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
                 bf[s][1] = *reinterpret_cast<const h8*>(&wl[w_off(s) + 512 + lane * 8]);
             }
 #pragma unroll
-            for (int s = 0; s < G::STEPS; ++s) {
+            for (int s = 0; s < ((MPRX & 16) ? 1 : G::STEPS); ++s) {
                 constexpr bool Z = (C == 0);
                 acc[0][0] = mma(af[s % RA][0], bf[s % RA][0], (Z && s == 0) ? zero16 : acc[0][0]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -436,7 +462,11 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            MPR_T(t_s1);
+            MPR_ADD(1, t_s0, t_s1);                                // the MFMA steps of a chunk
             group_barrier(ctr, bar_target, lane);              // this chunk's tile fully consumed by the group
+            MPR_T(t_b0);
+            MPR_ADD(2, t_s1, t_b0);                                // barrier behind the steps
             if constexpr (F1) {
                 if (!LAST) {
                     tile_chunk1();
@@ -448,14 +478,24 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
                 if (LAST) cur_pad = nxt_pad;
                 if (!LAST || has_next) lds_write();            // staged registers are free again before the epilogue
             }
+            MPR_T(t_w);
+            MPR_ADD(3, t_b0, t_w);                                 // tile production / LDS write
             if (!LAST) group_barrier(ctr, bar_target, lane);
+            MPR_T(t_b1);
+            MPR_ADD(4, t_w, t_b1);                                 // barrier in front of chunk 1
         };
         chunk_body(std::integral_constant<int, 0>{});
         chunk_body(std::integral_constant<int, 1>{});
 
         // ---------------- epilogue of item `cur` (conv_f16.hip's, one 64-channel slice) ----------------
+        MPR_T(t_e0);
         const int img = cur.img, y0 = cur.y0, x0 = cur.x0;
-        if constexpr (POOL) {
+        if (MPRX & 2) {
+            float sink = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sink += acc[0][0][r] + acc[0][1][r] + acc[1][0][r] + acc[1][1][r];
+            if (sink == 123.456f) p.out[tid] = (_Float16)sink;
+        } else if constexpr (POOL) {
             // lane = channel (li), register r = pixel (r&3) + 8*(r>>2) + 4*half of the M-block; registers r, r+1 are
             // horizontally adjacent pixels -> one packed pair
             f32x2 bia[2], scl[2], sft[2];
@@ -539,8 +579,17 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
             };
             if (full) store_all(std::true_type{}); else store_all(std::false_type{});
         }
+        MPR_T(t_e1);
+        MPR_ADD(5, t_e0, t_e1);                                    // epilogue
+#ifdef MP_TIMING
+        tsum[7] += 1;
+        if (F1 && !has_next && wave == 0 && lane == 0 && grp < 2 && blockIdx.x < 256)
+            for (int i = 0; i < 8; ++i) g_timing_r[(blockIdx.x * 2 + grp) * 8 + i] = tsum[i];
+#endif
         if (!has_next) return;
         group_barrier(ctr, bar_target, lane);                  // next item's tile complete
+        MPR_T(t_b2);
+        MPR_ADD(6, t_e1, t_b2);                                    // barrier before the next item
         item = item_next;
         cur = nxt;
         par ^= 1;

@@ -3,7 +3,7 @@
 # (default conv_wino.hip); every other object comes from the regular build.   tools/build_variant.sh <name> "<flags>" [src]
 set -e
 cd "$(dirname "$0")/.."
-NAME=$1; FLAGS=$2; SRC=${3:-conv_wino.hip}
+NAME=$1; FLAGS=$2; SRC=${3:-conv_wino43.hip}
 B=multipoint_amd/csrc/_build
 mkdir -p $B/exp
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function $FLAGS -c multipoint_amd/csrc/$SRC -o $B/exp/${SRC%.hip}_$NAME.o
