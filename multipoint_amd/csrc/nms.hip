@@ -48,7 +48,11 @@ __global__ __launch_bounds__(256) void nms_init_kernel(const float* __restrict__
 // RT > 0: footprint radius known at compile time (fully unrolled scan, row masks in SGPRs).
 // INIT (round 0 only): the tile is read from the probability map itself -- prob * valid_mask, thresholded (utils.py:97;
 // what nms_init_kernel writes) -- instead of from a work map a separate launch would have to write and this one re-read.
-template <int RT, bool INIT>
+// LOOP (rounds >= 2, which on detector maps find little or nothing to do): a grid of at most 1024 workgroups walks the tiles instead
+// of one workgroup per tile -- a round whose flags are all zero then costs 1024 workgroups x 19 flag reads instead of the dispatch
+// of 19 200 workgroups that each need 13.5 KiB of LDS on a CU before they can read their flag and leave (8 us per such round, five of
+// them per batch, each taking a launch-boundary slot away from the next batch's convolutions).
+template <int RT, bool INIT, bool LOOP = false>
 __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work, int H, int W,
                                                        int tiles_x, int tiles_y, NmsFootprint fp,
                                                        int* __restrict__ flags, int ntiles_total,
@@ -62,12 +66,12 @@ __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work
     const int R = RT > 0 ? RT : fp.R;
     const int LW = NT + 2 * R;
     const int tid = threadIdx.x;
-    const int tile_id = blockIdx.x;
     const int* fin = flags + (round & 1) * ntiles_total;
     int* fout = flags + ((round + 1) & 1) * ntiles_total;
+    for (int tile_id = blockIdx.x; tile_id < ntiles_total; tile_id += LOOP ? (int)gridDim.x : ntiles_total) {
     if (!INIT && round > 0 && fin[tile_id] == 0) {
         if (tid == 0) fout[tile_id] = 0;
-        return;
+        continue;
     }
     int tt = tile_id;
     const int tx = tt % tiles_x; tt /= tiles_x;
@@ -265,6 +269,8 @@ __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work
         const int und = cnt[cur];
         fout[tile_id] = und;
     }
+    if (LOOP) __syncthreads();                               // t[], list[], cnt[] are reused by the next tile
+    }
 }
 
 // undecided pixels after a round = sum of the tiles' counts -> *slot (what the host reads), and added to *total (optional)
@@ -317,6 +323,12 @@ void launch_nms_round(float* work, int B, int H, int W, const NmsFootprint& fp, 
     int* flags = remaining + 64;
     const float* np = nullptr;
     const uint8_t* nm = nullptr;
+#ifndef MP_NMS_NO_LOOP       // (developer A/B: tools/build_variant.sh nl "-DMP_NMS_NO_LOOP" nms.hip)
+    if (fp.R == 3 && round >= 2)       // the usual footprint (size 4): later rounds on a small grid that walks the tiles
+        hipLaunchKernelGGL((nms_round_kernel<3, false, true>), dim3((unsigned)(ntiles < 1024 ? ntiles : 1024)), dim3(256), 0, s, work, H, W,
+                           tiles_x, tiles_y, fp, flags, ntiles, round, np, nm, 0.f);
+    else
+#endif
     if (fp.R == 3)
         hipLaunchKernelGGL((nms_round_kernel<3, false>), dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
                            tiles_y, fp, flags, ntiles, round, np, nm, 0.f);

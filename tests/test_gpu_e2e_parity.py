@@ -137,6 +137,44 @@ def test_structured_images_at_the_headline_shape(oracle):
             assert (kp[:, 0] * W + kp[:, 1]).tolist() == sorted(per[b]['final_gpu']), (algo, b)
 
 
+def test_box_nms_tie_robust_is_what_the_clis_call(oracle):
+    """utils.box_nms_tie_robust (predict_align_image_pair.py / predict_keypoints.py / compute_repeatability_multispectral call it
+    in place of box_nms): on the structured set the image whose top-k cut falls inside a plateau of tied scores is flagged by the
+    guard, re-evaluated with the tie-exact algorithm IN PLACE (`out['prob']` / `out['desc']` rows of that image only) and
+    suppressed again -- the kept pixels then equal the ones a `direct` model keeps, image by image; mp_topk_tie_guard's
+    parameters switch the guard off; a second call on the redone output flags the same image and changes nothing."""
+    import multipoint_amd.models as M
+    import multipoint_amd.utils as U
+    from oracle import trained_like as T
+    H, W = 480, 640
+    cfg = dict(oracle.SHIPPED_MODEL_CONFIG)
+    sd = T.trained_like_weights(1, cfg, **T.SEVERITIES['wide'])
+    img = T.structured_images(4, 8, H, W).cuda()
+    net = M.MultiPoint(dict(cfg)); net.load_state_dict(sd); net.to('cuda'); net.eval()
+    direct = M.MultiPoint(dict(cfg, conv_algorithm='direct')); direct.load_state_dict(sd); direct.to('cuda'); direct.eval()
+    want = U.box_nms(direct({'image': img})['prob'], PRED['nms'], PRED['detection_threshold'], keep_top_k=PRED['topk'])
+    data = {'image': img}
+    out = net(data)
+    raw = out['prob'].clone()
+    plain = U.box_nms(out['prob'], PRED['nms'], PRED['detection_threshold'], keep_top_k=PRED['topk'])
+    flags, total = U.topk_ambiguous('cuda', 8)
+    assert sum(flags) >= 1 and total >= sum(flags)
+    got = U.box_nms_tie_robust(net, data, out, PRED['nms'], PRED['detection_threshold'], keep_top_k=PRED['topk'])
+    changed = [b for b in range(8) if not torch.equal(out['prob'][b], raw[b])]
+    assert changed == [b for b, f in enumerate(flags) if f]                # only the flagged images were re-evaluated
+    for b in range(8):
+        assert torch.equal(got[b] > 0, want[b] > 0), 'image %d: kept pixels differ from the direct model' % b
+    assert any(not torch.equal(plain[b] > 0, want[b] > 0) for b in changed)   # ... and without the guard they did differ
+    again = U.box_nms_tie_robust(net, data, out, PRED['nms'], PRED['detection_threshold'], keep_top_k=PRED['topk'])
+    assert torch.equal(again, got)
+    U.topk_tie_guard('cuda', 6e-5, 0)                                      # off
+    try:
+        U.box_nms(raw, PRED['nms'], PRED['detection_threshold'], keep_top_k=PRED['topk'])
+        assert U.topk_ambiguous('cuda', 8) == ([False] * 8, 0)
+    finally:
+        U.topk_tie_guard('cuda', 6e-5, 4)
+
+
 def test_unlimited_topk_lists_grow_instead_of_truncating(oracle):
     """`topk: 0` (the shipped prediction configs, like the reference's) keeps EVERY keypoint (utils.py:109-116).  The device
     lists have a fixed capacity: run_converged() must regrow them on overflow (same keypoints as the oracle, none dropped
