@@ -48,10 +48,13 @@ __global__ __launch_bounds__(256) void nms_init_kernel(const float* __restrict__
 // RT > 0: footprint radius known at compile time (fully unrolled scan, row masks in SGPRs).
 // INIT (round 0 only): the tile is read from the probability map itself -- prob * valid_mask, thresholded (utils.py:97;
 // what nms_init_kernel writes) -- instead of from a work map a separate launch would have to write and this one re-read.
-// LOOP (rounds >= 2, which on detector maps find little or nothing to do): a grid of at most 1024 workgroups walks the tiles instead
-// of one workgroup per tile -- a round whose flags are all zero then costs 1024 workgroups x 19 flag reads instead of the dispatch
-// of 19 200 workgroups that each need 13.5 KiB of LDS on a CU before they can read their flag and leave (8 us per such round, five of
-// them per batch, each taking a launch-boundary slot away from the next batch's convolutions).
+// LOOP (rounds >= 1: on detector maps round 1 still has work in a third of the tiles, rounds 3-7 find nothing to do): a grid of at
+// most 2048 workgroups walks the tiles instead of one workgroup per tile -- a round whose flags are all zero then costs 2048
+// workgroups x 10 flag reads instead of the dispatch of 19 200 workgroups that each need 13.5 KiB of LDS on a CU before they can
+// read their flag and leave (8 us per such round, five of them per batch, each taking a launch-boundary slot away from the next
+// batch's convolutions).  Measured in the pipeline (same box, 3 alternating runs of 40 steps): 9.65 / 9.65 / 9.69 ms per step
+// against 9.77 / 9.76 / 9.86 with one workgroup per tile in every round; grids of 256 / 1024 / 2048 / 4096 from round 1 or 2:
+// 9.79-9.86 / 9.65-9.68 / 9.63 / 9.66-9.68; forward-only on that box 9.60 -- the post-processing that remains visible is 0.03 ms.
 template <int RT, bool INIT, bool LOOP = false>
 __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work, int H, int W,
                                                        int tiles_x, int tiles_y, NmsFootprint fp,
@@ -323,9 +326,15 @@ void launch_nms_round(float* work, int B, int H, int W, const NmsFootprint& fp, 
     int* flags = remaining + 64;
     const float* np = nullptr;
     const uint8_t* nm = nullptr;
+#ifndef MP_NMS_LOOP_FROM
+#define MP_NMS_LOOP_FROM 1
+#endif
+#ifndef MP_NMS_LOOP_GRID
+#define MP_NMS_LOOP_GRID 2048
+#endif
 #ifndef MP_NMS_NO_LOOP       // (developer A/B: tools/build_variant.sh nl "-DMP_NMS_NO_LOOP" nms.hip)
-    if (fp.R == 3 && round >= 2)       // the usual footprint (size 4): later rounds on a small grid that walks the tiles
-        hipLaunchKernelGGL((nms_round_kernel<3, false, true>), dim3((unsigned)(ntiles < 1024 ? ntiles : 1024)), dim3(256), 0, s, work, H, W,
+    if (fp.R == 3 && round >= MP_NMS_LOOP_FROM)       // the usual footprint (size 4): later rounds on a small grid that walks the tiles
+        hipLaunchKernelGGL((nms_round_kernel<3, false, true>), dim3((unsigned)(ntiles < MP_NMS_LOOP_GRID ? ntiles : MP_NMS_LOOP_GRID)), dim3(256), 0, s, work, H, W,
                            tiles_x, tiles_y, fp, flags, ntiles, round, np, nm, 0.f);
     else
 #endif
