@@ -559,11 +559,11 @@ def main():
             # v_mfma_f32_4x4x1_16b_f32 (512 FLOP) each -> 16 x 10 x 9 = 1440 per item
             items = 2 * P * ((H + 15) // 16) * ((W + 31) // 32)
             issued = (conv2_flop / 4.0 + items * 1440 * 512.0) if fused else flop / 4.0
-            inst = 'conv_wino43_kernel<true,false,8,true,false>' if fused else ('conv_wino43b_kernel<true,false,8,false>' if gen2 else 'conv_wino43_kernel<true,false,8,false,false>')
-            kernel = ('conv_wino43_kernel<true,false,8,true,false> (encoder conv1 -- Cin = 1, produced per unit of 4 channels on the matrix pipe '
+            inst = 'conv_wino43_kernel<true,false,8,true,false,false>' if fused else ('conv_wino43b_kernel<true,false,8,false>' if gen2 else 'conv_wino43_kernel<true,false,8,false,false,false>')
+            kernel = ('conv_wino43_kernel<true,false,8,true,false,false> (encoder conv1 -- Cin = 1, produced per unit of 4 channels on the matrix pipe '
                       '(v_mfma_f32_4x4x1_16b_f32) straight into the LDS patch ring -- fused into enc.conv2 64->64 @480x640 by Winograd '
                       'F(4x4,3x3) on v_mfma_f32_16x16x4_f32, weights staged by LDS-DMA, + bias/ReLU/BN + 2x2 max-pool)') if fused else \
-                     ('conv_wino43_kernel<true,false,8,false,false> (enc.conv2 64->64 @480x640 by Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32, '
+                     ('conv_wino43_kernel<true,false,8,false,false,false> (enc.conv2 64->64 @480x640 by Winograd F(4x4,3x3) on v_mfma_f32_16x16x4_f32, '
                       'weights and channel-quad-planar input patches staged by LDS-DMA, + bias/ReLU/BN + 2x2 max-pool)')
         else:                                                   # MP_DEBUG=wino43=0: no Winograd kernel, as MP_DEBUG=no_winograd
             issued = conv2_flop if fused else flop

@@ -106,7 +106,7 @@ def summarize(prefix, suffix, dominant, nper, bench_cmd, layers_cmd):
 
 
 # enc.conv1+2 (the first block fused into the pooled 64 -> 64 layer) is the only launch of this instantiation
-summarize('', '', 'conv_wino43_kernel<true, false, 8, true, false>', 1,
+summarize('', '', 'conv_wino43_kernel<true, false, 8, true, false, false>', 1,
           'python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline', 'python3 tools/bench_layers.py 64')
 # fp16 workload: enc.conv1 evaluated inside enc.conv2 on the LDS-resident-weights kernel, one launch of this instantiation per forward
 summarize('c5_', '_c5', 'conv_f16_res_kernel<32, true, false, 2, true>', 1,
