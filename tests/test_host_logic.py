@@ -411,3 +411,25 @@ def test_conv_algorithm_is_a_model_setting():
     assert M.SuperPointMagicLeap({'batch_invariant': True}).config['batch_invariant'] is True
     from multipoint_amd import _lib
     assert [n for n, _ in _lib.ModelConfig._fields_][-2:] == ['conv_algorithm', 'batch_invariant']
+
+
+def test_mp_debug_switch_parser(monkeypatch):
+    """MP_DEBUG is ONE comma-separated list of `key` / `key=value` developer switches (csrc/api.hip::debug_switch reads the kernel
+    selection keys in mp_create; the Python side reads its own -- pipeline stream priorities, post_overlap -- with the same grammar)."""
+    from multipoint_amd import _lib
+    monkeypatch.delenv('MP_DEBUG', raising=False)
+    assert _lib.debug_switch('no_winograd') is None and _lib.debug_switch('wino43', '2') == '2'
+    monkeypatch.setenv('MP_DEBUG', 'no_winograd, wino43_gen=2,post_overlap=0 ,ncu=64')
+    assert _lib.debug_switch('no_winograd') == '1'
+    assert _lib.debug_switch('wino43_gen') == '2' and _lib.debug_switch('wino43') is None      # a key is a whole token, not a prefix
+    assert _lib.debug_switch('post_overlap', '1') == '0' and _lib.debug_switch('ncu') == '64'
+    assert _lib.debug_switch('fwd_priority', '-1') == '-1'
+    # every switch the C side documents is spelled the same way in its parser and in INTEGRATION.md
+    api = open(os.path.join(ROOT, 'multipoint_amd', 'csrc', 'api.hip')).read()
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    import re
+    keys = set(re.findall(r'debug_switch\("([a-z0-9_]+)"', api))
+    assert {'no_winograd', 'wino43', 'wino43_gen', 'no_fuse', 'no_fuse43', 'no_head_fuse', 'vin', 'no_planar', 'planar', 'no_persist',
+            'persist_min_items', 'splitk_max', 'f16_no_res', 'f16_no_fuse1', 'f16_res_groups', 'ncu', 'nxcd'} <= keys
+    for k in keys:
+        assert k in doc, 'MP_DEBUG key %s is not documented in INTEGRATION.md' % k
