@@ -369,7 +369,8 @@ def main():
     import torch.distributed as dist
     from multipoint_amd.dist import bind_rank_to_numa_node
     orig_affinity = os.sched_getaffinity(0) if hasattr(os, 'sched_getaffinity') else None
-    cpu_set = bind_rank_to_numa_node(local_rank) if world > 1 else None      # before the first GPU call; silent when not exposed
+    # (every rank of a torchrun job binds to its GPU's NUMA node, also a job of ONE rank: the line then shows that the binding works)
+    cpu_set = bind_rank_to_numa_node(local_rank) if (world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ) else None      # before the first GPU call; silent when not exposed
     if not torch.cuda.is_available():
         sys.exit('bench.py needs an MI355X; torch.cuda.is_available() is False')
     torch.cuda.set_device(local_rank)

@@ -99,3 +99,26 @@ def test_emulated_world2_equals_single_rank(oracle):
         for k in ('kp_optical', 'kp_thermal', 'match_query', 'match_train'):
             assert np.array_equal(a[k], b[k]), (p, k)
         assert np.array_equal(a['desc_optical'], b['desc_optical']) and np.array_equal(a['match_dist'], b['match_dist'])
+
+
+def test_numa_binding_resolves_the_gpu_on_this_box():
+    """dist.bind_rank_to_numa_node on real hardware: the KFD topology lists this box's GPU(s) with a PCI id that exists under
+    /sys/bus/pci/devices, and binding rank 0 either takes effect (a non-empty subset of the CPUs the process may run on) or reports
+    None because the container does not expose the topology -- never a wrong or empty set.  The affinity is restored afterwards."""
+    from multipoint_amd import dist as D
+    before = os.sched_getaffinity(0)
+    try:
+        nodes = D._kfd_gpu_nodes()
+        if os.path.isdir('/sys/class/kfd/kfd/topology/nodes'):
+            assert len(nodes) >= 1, 'KFD topology is exposed but lists no GPU node'
+            for _, bdf in nodes:
+                assert len(bdf.split(':')) == 3 and '.' in bdf
+        got = D.bind_rank_to_numa_node(0)
+        print('\n[numa] kfd gpu nodes %s -> rank 0 bound to %s' % (nodes, None if got is None else '%d CPUs %d-%d' % (len(got), got[0], got[-1])))
+        if got is not None:
+            assert len(got) > 0 and set(got) <= before and set(got) == os.sched_getaffinity(0)
+            assert nodes and os.path.exists(os.path.join('/sys/bus/pci/devices', nodes[0][1], 'local_cpulist'))
+        else:
+            assert os.sched_getaffinity(0) == before
+    finally:
+        os.sched_setaffinity(0, before)
