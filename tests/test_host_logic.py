@@ -433,3 +433,36 @@ def test_mp_debug_switch_parser(monkeypatch):
             'persist_min_items', 'splitk_max', 'f16_no_res', 'f16_no_fuse1', 'f16_res_groups', 'ncu', 'nxcd'} <= keys
     for k in keys:
         assert k in doc, 'MP_DEBUG key %s is not documented in INTEGRATION.md' % k
+
+
+def test_tie_robust_redo_replaces_only_the_flagged_rows():
+    """utils.tie_robust_redo (host logic of the top-k tie guard, CPU tensors + a stand-in model): the rows of prob / desc of the
+    flagged images -- and only those -- are replaced in place by the twin model's forward of exactly those images (with their
+    is_optical flags); models without a second algorithm (direct_twin() -> None) are left alone."""
+    import torch
+    from multipoint_amd.utils import utils as U
+    calls = []
+
+    class Twin:
+        def __call__(self, data):
+            calls.append({k: v.clone() for k, v in data.items()})
+            n = data['image'].shape[0]
+            return {'prob': data['image'] * 0 + 7.0, 'logits': None, 'desc': torch.full((n, 4, 2, 2), 9.0)}
+
+    class Net:
+        def __init__(self, twin): self._t = twin
+        def direct_twin(self): return self._t
+
+    img = torch.arange(5 * 16, dtype=torch.float32).reshape(5, 1, 4, 4)
+    flags_in = torch.tensor([[True], [False], [True], [False], [True]])
+    out = {'prob': img.clone(), 'logits': None, 'desc': torch.zeros(5, 4, 2, 2)}
+    n = U.tie_robust_redo(Net(Twin()), {'image': img, 'is_optical': flags_in}, out, [False, True, False, True, False])
+    assert n == 2 and len(calls) == 1
+    assert torch.equal(calls[0]['image'], img[[1, 3]]) and torch.equal(calls[0]['is_optical'], flags_in[[1, 3]])
+    for b in range(5):
+        if b in (1, 3):
+            assert bool((out['prob'][b] == 7.0).all()) and bool((out['desc'][b] == 9.0).all())
+        else:
+            assert torch.equal(out['prob'][b], img[b]) and bool((out['desc'][b] == 0).all())
+    assert U.tie_robust_redo(Net(Twin()), {'image': img}, out, [False] * 5) == 0 and len(calls) == 1      # nothing flagged: no forward
+    assert U.tie_robust_redo(Net(None), {'image': img}, out, [True] * 5) == 0                               # no second algorithm
