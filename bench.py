@@ -642,7 +642,7 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         if orig_affinity is not None:
             os.sched_setaffinity(0, orig_affinity)                # the CPU figure is the host's, not one NUMA node's
-        cb, cres, prob_cpu, desc_cpu = cpu_baseline(sd, cfg, min(P, 2 if c5 else 16), H, W, PRED)
+        cb, cres, prob_cpu, desc_cpu = cpu_baseline(sd, cfg, min(P, 4 if c5 else 16), H, W, PRED)
         out['cpu_baseline'] = cb
         if not args.forward_only:
             out['parity'] = parity_block(res, net, images, flags, cres, prob_cpu, desc_cpu, PRED, H, W)
