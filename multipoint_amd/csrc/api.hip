@@ -66,9 +66,8 @@ struct mp_handle {
     DevBuf ws4;                     // pair metrics: warped keypoints + inverse match map
     DevBuf split_ws;                // F(4x4,3x3) split launches: the ranges' pre-bias output tiles
     DevBuf vin_ws;                  // F(4x4,3x3) layers with >= 4 output slices: the pre-transformed input (ConvParams::vglobal)
-    int vin_min_slices = 0;         // ... from this many slices on; 0 (default): never -- measured: the GEMM-only pass is 15 % faster (0.876 vs
-                                    // 1.03 ms, 74 % of the matrix pipe) and the V round trip through memory costs what it saves (producer 0.18 ms);
-                                    // MP_DEBUG=vin switches it on for layers with >= 4 slices
+    int vin_min_slices = 4;         // ... from this many slices on (the 3x3 head convolutions: 8): GEMM pass 0.865 ms at 75 % of the matrix pipe +
+                                    // 0.106 ms for the producer against 1.03 ms with the in-kernel transform per slice; MP_DEBUG=no_vin: never
     int splitk_max = 8;             // most ranges the input channels of a small launch are cut into (MP_DEBUG=splitk_max; 1: never)
     int fwd_batch = 0;              // images of the forward in flight: the split launches are gated on THIS, not on an encoder's share of it
     int splitk_env = 8;             // ... as mp_create set it (model.batch_invariant overrides it per loaded model)
@@ -580,7 +579,8 @@ int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, 
                 p.ks_shift = ks; p.split_scratch = static_cast<float*>(h->split_ws.p);
             }
         }
-        if (f43 == 1 && !fuse && !L.pool && p.ks_shift == 0 && !in_planar && L.cin % 16 == 0 && h->vin_min_slices > 0 &&
+        if (f43 == 1 && !fuse && !L.pool && p.ks_shift == 0 && !in_planar && L.cin % 16 == 0 && L.cin <= 256 && 256 % (L.cin / 2) == 0 &&
+            L.cin >= 16 && h->vin_min_slices > 0 &&
             L.nslices >= h->vin_min_slices) {
             // many output slices over one input (heads: 512 couts = 8 slices): transform the input ONCE (conv_wino43.hip VIN)
             int rc = ensure(h, h->vin_ws, (size_t)conv_wino43_vglobal_floats(p) * 4);
@@ -835,8 +835,8 @@ namespace {
 //   no_fuse              the fp32 first block as its own launch in front of the direct conv2 kernel
 //   no_fuse43            ... in front of the F(4x4,3x3) conv2 kernel
 //   no_head_fuse         separate 1x1 convolution / softmax / normalisation launches instead of the fused head tail (fp32 and fp16)
-//   vin                  the 3x3 head convolutions (>= 4 output slices) take their input pre-transformed by a pass of its own
-//                        (conv_wino43.hip VIN; bit-identical; measured +-0: off by default)
+//   no_vin               the 3x3 head convolutions (>= 4 output slices) transform their input per slice inside the kernel instead of
+//                        taking it pre-transformed from a pass of its own (conv_wino43.hip VIN; bit-identical either way)
 //   no_planar, planar=0|1|2   channel-quad-planar tensors: never / behind conv1 and pooled producers (default) / everywhere
 //   no_persist, persist_min_items=N   direct kernels: per-tile launches / persistent from N items per CU
 //   splitk_max=1..8      most ranges the input channels of a small launch are cut into
@@ -954,7 +954,7 @@ int mp_create(mp_handle** out, int device)
         if (debug_switch("persist_min_items", &v) && v > 0) hh->persist = v;
         if (debug_switch("no_persist")) hh->persist = 0;
         if (debug_switch("splitk_max", &v) && v >= 1 && v <= 8) hh->splitk_max = v;
-        if (debug_switch("vin")) hh->vin_min_slices = 4;
+        if (debug_switch("no_vin")) hh->vin_min_slices = 0;
     }
     hh->splitk_env = hh->splitk_max;
     hh->wino_env = hh->wino; hh->wino43_env = hh->wino43; hh->wino43_gen_env = hh->wino43_gen;

@@ -900,14 +900,20 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
 template <int TC4>
 __global__ __launch_bounds__(256) void wino43_vprod_kernel(const ConvParams p, long long ntb)
 {
+    // A block = TL consecutive tiles of a tile block x every channel pair (256 threads = TL x cin / 2).  The reads stay coalesced over
+    // the channel pairs of a pixel; the results are transposed through LDS so that they leave as 16-byte pieces of TL x 144-byte runs
+    // (the first version stored each lane's 144-byte run directly: 64 pieces 9 KiB apart per store instruction, 0.18 ms).
     constexpr int TR4 = 32 / TC4, OY = 4 * TR4, OX = 4 * TC4;
+    __shared__ __attribute__((aligned(16))) float st[19456];      // cin x (TL x 36 + 4) floats: 18432 + 4 cin, cin <= 256
     const int ncp = p.cin >> 1, NC = p.cin / UC4;
-    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
-    const int cp = (int)(gid % ncp);
-    const long long tl = gid / ncp;
-    const int t = (int)(tl & 31);
-    const long long tb = tl >> 5;
-    if (tb >= ntb) return;
+    const int TL = 256 / ncp;                            // tiles per block (4 for cin = 128)
+    const int RS = TL * 36 + 4;                          // floats per (unit, channel) row: padded, lanes 2 rows apart hit 4 bank quads
+    const int groups = 32 / TL;
+    const int tid = threadIdx.x;
+    const int cp = tid % ncp, tlc = tid / ncp;
+    const long long tb = (long long)blockIdx.x / groups;
+    const int t0 = ((int)((long long)blockIdx.x % groups)) * TL, t = t0 + tlc;
+    (void)ntb;
     const int tx = (int)(tb % p.tiles_x);
     const long long trow = tb / p.tiles_x;
     const int ty = (int)(trow % p.tiles_y);
@@ -929,8 +935,8 @@ __global__ __launch_bounds__(256) void wino43_vprod_kernel(const ConvParams p, l
 #pragma unroll
         for (int i = 0; i < 6; ++i) r[i][j] = o[i];
     }
-    float* const dst0 = p.vglobal + (((tb * NC + (cp >> 1)) * 4 + 2 * (cp & 1)) * 32 + t) * 36;      // channel 2 cp of the unit
-    float* const dst1 = dst0 + 32 * 36;
+    float* const dst0 = st + (2 * cp) * RS + tlc * 36;   // row = unit * 4 + channel of the unit = 2 cp (+ 1)
+    float* const dst1 = dst0 + RS;
 #pragma unroll
     for (int i = 0; i < 6; i += 2) {                     // two rows = 12 positions = three 16-byte stores per channel
         f32x2 a[6], b[6];
@@ -942,6 +948,14 @@ __global__ __launch_bounds__(256) void wino43_vprod_kernel(const ConvParams p, l
         *reinterpret_cast<f32x4*>(dst1 + 6 * i) = f32x4{a[0][1], a[1][1], a[2][1], a[3][1]};
         *reinterpret_cast<f32x4*>(dst1 + 6 * i + 4) = f32x4{a[4][1], a[5][1], b[0][1], b[1][1]};
         *reinterpret_cast<f32x4*>(dst1 + 6 * i + 8) = f32x4{b[2][1], b[3][1], b[4][1], b[5][1]};
+    }
+    __syncthreads();
+    // [unit][ch 4][tile 32][pos 36] in p.vglobal: row `row` = (unit, ch) holds this block's TL tiles as one run of TL x 144 bytes
+    const int q4 = TL * 9, total4 = p.cin * q4;
+    float* const gbase = p.vglobal + (tb * NC * 4 * 32 + t0) * 36;
+    for (int i = tid; i < total4; i += 256) {
+        const int row = i / q4, w = i - row * q4;
+        *reinterpret_cast<f32x4*>(gbase + (long long)row * (32 * 36) + w * 4) = *reinterpret_cast<const f32x4*>(st + row * RS + w * 4);
     }
 }
 
@@ -981,8 +995,8 @@ int launch_vin(const ConvParams& p, hipStream_t s)
     if (nitems * dmax >= 0x100000000ll) return 1;
     q.nitems = (int)nitems;
     const ConvParams& pp = q;
-    const long long threads = ntb * 32 * (p.cin / 2);
-    hipLaunchKernelGGL((wino43_vprod_kernel<TC4>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, pp, ntb);
+    const int tl = 256 / (p.cin / 2);                    // tiles per producer block (launch_conv_wino43 checked the divisibility)
+    hipLaunchKernelGGL((wino43_vprod_kernel<TC4>), dim3((unsigned)(ntb * (32 / tl))), dim3(256), 0, s, pp, ntb);
     const unsigned grid = persistent_grid(nitems, p.ncu, p.xcd_shift);
     if (p.bn_first) hipLaunchKernelGGL((conv_wino43_kernel<false, true, TC4, false, false, true>), dim3(grid), dim3(512), 0, s, pp);
     else hipLaunchKernelGGL((conv_wino43_kernel<false, false, TC4, false, false, true>), dim3(grid), dim3(512), 0, s, pp);
@@ -1030,7 +1044,7 @@ int launch_conv_wino43(const ConvParams& p, bool pool, hipStream_t s, bool fuse_
 {
     if (fuse_first) return pool && p.cin == 64 ? launch_q<true, 8, true>(p, s) : 2;          // 2: shape not covered
     if (p.vglobal) {       // pre-transformed input (api.hip: un-pooled layers with >= 4 output slices; cin a multiple of 16, NHWC)
-        if (pool || p.ks_shift > 0 || p.cin % 16 != 0 || p.in_planar) return 2;
+        if (pool || p.ks_shift > 0 || p.cin % 16 != 0 || p.in_planar || p.cin > 256 || 256 % (p.cin / 2) != 0 || (p.cin / 2) < 8) return 2;
         const long long wide = (long long)((p.W + 31) / 32) * ((p.H + 15) / 16), tall = (long long)((p.W + 15) / 16) * ((p.H + 31) / 32);
         return tall < wide ? launch_vin<4>(p, s) : launch_vin<8>(p, s);
     }

@@ -52,7 +52,7 @@ def test_forward_matches_oracle(oracle, shipped, B, H, W):
 
 @pytest.mark.parametrize('env', [{'MP_DEBUG': v} for v in (
     'persist_min_items=1', 'no_persist', 'no_fuse', 'no_winograd', 'no_winograd,no_fuse', 'no_head_fuse', 'wino43=0', 'wino43=1',
-    'no_planar', 'planar=2', 'wino43=1,planar=2', 'no_fuse43', 'wino43_gen=2', 'wino43_gen=2,planar=2', 'wino43_gen=1', 'vin')])
+    'no_planar', 'planar=2', 'wino43=1,planar=2', 'no_fuse43', 'wino43_gen=2', 'wino43_gen=2,planar=2', 'wino43_gen=1', 'no_vin')])
 @pytest.mark.parametrize('B,H,W', [(6, 120, 160), (3, 200, 328), (3, 240, 320), (4, 64, 96)])
 def test_forward_kernel_variants(oracle, monkeypatch, env, B, H, W):
     """Every convolution kernel variant against the oracle on the same inputs: the persistent one-workgroup-per-CU
@@ -222,15 +222,14 @@ def test_first_block_inside_f43_equals_standalone(oracle, monkeypatch, upd, B, H
 def test_pretransformed_head_input_is_bit_identical(oracle, monkeypatch, upd, B, H, W):
     """The 3x3 head convolutions (512 couts = 8 output slices over ONE input, MultiPoint.py:62-65,78-81) run with their input
     transform V = B^T d B as a pass of its own (conv_wino43.hip: wino43_vprod_kernel + the VIN instantiation that DMAs V) instead of
-    transforming the same windows once per slice (the default: the V round trip through memory costs what the transform saves, so the
-    two-pass form is an opt-in developer switch, MP_DEBUG=vin).  The producer runs the same column-pass / row-pass chains, so the
+    transforming the same windows once per slice (MP_DEBUG=no_vin).  The producer runs the same column-pass / row-pass chains, so the
     outputs are EQUAL -- reflected borders, phantom tiles of partial tile blocks, both item shapes (60x80: 8x4 tiles; 9x13: 4x8)."""
     cfg = dict(oracle.SHIPPED_MODEL_CONFIG); cfg.update(upd)
     img = oracle.make_images(13 + W, B, H, W)
     flags = torch.tensor([[i % 2 == 0] for i in range(B)])
     net, sd = _net(oracle, cfg, seed=8)
     a = net({'image': img.cuda(), 'is_optical': flags})
-    monkeypatch.setenv('MP_DEBUG', 'vin')
+    monkeypatch.setenv('MP_DEBUG', 'no_vin')
     net2, _ = _net(oracle, cfg, seed=8)
     b = net2({'image': img.cuda(), 'is_optical': flags})
     assert torch.equal(a['prob'], b['prob'])
