@@ -66,6 +66,8 @@ struct mp_handle {
     DevBuf ws4;                     // pair metrics: warped keypoints + inverse match map
     DevBuf split_ws;                // F(4x4,3x3) split launches: the ranges' pre-bias output tiles
     DevBuf vin_ws;                  // F(4x4,3x3) layers with >= 4 output slices: the pre-transformed input (ConvParams::vglobal)
+    bool pool_first = true;         // fp16 pooled epilogues pool the accumulators before the activation (bit-identical; MP_DEBUG=no_pool_first:
+                                    // activate all four, then pool)
     int vin_min_slices = 4;         // ... from this many slices on (the 3x3 head convolutions: 8): GEMM pass 0.865 ms at 75 % of the matrix pipe +
                                     // 0.106 ms for the producer against 1.03 ms with the in-kernel transform per slice; MP_DEBUG=no_vin: never
     int splitk_max = 8;             // most ranges the input channels of a small launch are cut into (MP_DEBUG=splitk_max; 1: never)
@@ -610,6 +612,7 @@ int run_conv_h(mp_handle* h, const ConvLayer& L, const _Float16* in, int in_cstr
     p.bn_first = h->cfg.bn_first;
     p.dummy = static_cast<_Float16*>(h->dummy);
     p.ncu = h->ncu; p.xcd_shift = h->xcd_shift; p.res_groups = h->f16_res_groups;
+    p.pool_first = h->pool_first ? 1 : 0;
     int mbw = 32;
     if (L.taps == 9) {
         mbw = pick_mbw(H, W);
@@ -837,6 +840,8 @@ namespace {
 //   no_head_fuse         separate 1x1 convolution / softmax / normalisation launches instead of the fused head tail (fp32 and fp16)
 //   no_vin               the 3x3 head convolutions (>= 4 output slices) transform their input per slice inside the kernel instead of
 //                        taking it pre-transformed from a pass of its own (conv_wino43.hip VIN; bit-identical either way)
+//   no_pool_first        fp16 pooled epilogues activate all four values of a window and pool then (default: pool the accumulators -- max, or
+//                        min where the channel's BatchNorm scale is negative -- and activate once: bit-identical, the activation is monotonic)
 //   no_planar, planar=0|1|2   channel-quad-planar tensors: never / behind conv1 and pooled producers (default) / everywhere
 //   no_persist, persist_min_items=N   direct kernels: per-tile launches / persistent from N items per CU
 //   splitk_max=1..8      most ranges the input channels of a small launch are cut into
@@ -955,6 +960,7 @@ int mp_create(mp_handle** out, int device)
         if (debug_switch("no_persist")) hh->persist = 0;
         if (debug_switch("splitk_max", &v) && v >= 1 && v <= 8) hh->splitk_max = v;
         if (debug_switch("no_vin")) hh->vin_min_slices = 0;
+        hh->pool_first = !debug_switch("no_pool_first");
     }
     hh->splitk_env = hh->splitk_max;
     hh->wino_env = hh->wino; hh->wino43_env = hh->wino43; hh->wino43_gen_env = hh->wino43_gen;

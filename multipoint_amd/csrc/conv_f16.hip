@@ -88,7 +88,8 @@ __device__ __forceinline__ h2 act_h2(float a0, float a1, f32x2 bias, f32x2 scale
     h2 h = __builtin_convertvector(x, h2);
     const h2 zero = {0, 0};
     if (RELU && !BNF) h = __builtin_elementwise_max(h, zero);
-    const f32x2 y = __builtin_convertvector(h, f32x2) * scale + shift;
+    f32x2 y = __builtin_convertvector(h, f32x2) * scale + shift;
+    asm volatile("" : "+v"(y));      // y exists as an fp32 pair (autocast: BatchNorm result in fp32, THEN fp16): no v_fma_mixlo_f16, which rounds once
     h2 o = __builtin_convertvector(y, h2);
     if (RELU && BNF) o = __builtin_elementwise_max(o, zero);
     return o;
@@ -373,6 +374,16 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvParamsH p)
                                                        act_h2<RELU, BNF>(b0, b1, bia[nb], scl[nb], sft[nb]));
                 return m[0] > m[1] ? m[0] : m[1];
             };
+            // p.pool_first: bias add, fp16 rounding and ReLU are non-decreasing and the BatchNorm affine is monotonic in the direction of its
+            // scale's sign, so the maximum of a window's four activations IS the activation of the maximum (scale < 0: the minimum) of its
+            // four accumulators, bit for bit -- one activation per pooled value instead of four (channels li and 32 + li share a packed pair)
+            const f32x2 biap = {bia[0][0], bia[1][0]}, sclp = {scl[0][0], scl[1][0]}, sftp = {sft[0][0], sft[1][0]};
+            const bool neg0 = sclp[0] < 0.f, neg1 = sclp[1] < 0.f;
+            auto pooled_first = [&](const float (&q)[2][4]) __attribute__((always_inline)) -> h2 {
+                const float x0 = fmaxf(fmaxf(q[0][0], q[0][1]), fmaxf(q[0][2], q[0][3])), n0 = fminf(fminf(q[0][0], q[0][1]), fminf(q[0][2], q[0][3]));
+                const float x1 = fmaxf(fmaxf(q[1][0], q[1][1]), fmaxf(q[1][2], q[1][3])), n1 = fminf(fminf(q[1][0], q[1][1]), fminf(q[1][2], q[1][3]));
+                return act_h2<RELU, BNF>(neg0 ? n0 : x0, neg1 ? n1 : x1, biap, sclp, sftp);
+            };
             const bool full = (y0 + G::TH <= p.H) && (x0 + G::TW <= p.W) && (slice * 64 + 64 <= p.cout);
             const int lane_off = 2 * half * cs + li;
             _Float16* const obase = p.out + ((long long)img * Ho * Wo) * cs + p.out_coff + slice * 64;
@@ -380,8 +391,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvParamsH p)
             // registers r and r+RDOWN of one M-block
             constexpr int RDOWN = (MBW == 32) ? 0 : (MBW == 16) ? 8 : 4;
             constexpr int NMB = (MBW == 32) ? 1 : 2;
-            auto store_all = [&](auto full_tag) __attribute__((always_inline)) {
+            auto store_all = [&](auto full_tag, auto pf_tag) __attribute__((always_inline)) {
                 constexpr bool FULL = decltype(full_tag)::value;
+                constexpr bool PF = decltype(pf_tag)::value;
 #pragma unroll
                 for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
@@ -391,9 +403,25 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvParamsH p)
                         const int oy = (MBW == 32) ? (y0 + 2 * wave) >> 1 : (y0 + (2 * wave + mb) * G::MBH + iu / MBW) >> 1;
                         const int oxu = (x0 + iu % MBW) >> 1;                        // + 2*half per lane
                         _Float16* const rowp = obase + ((long long)oy * Wo + oxu) * cs;
+                        h2 vp = {0, 0};
+                        if constexpr (PF) {
+                            float q[2][4];
+#pragma unroll
+                            for (int nb = 0; nb < 2; ++nb) {
+                                if constexpr (MBW == 32) {
+                                    q[nb][0] = acc[0][nb][r]; q[nb][1] = acc[0][nb][r + 1]; q[nb][2] = acc[1][nb][r]; q[nb][3] = acc[1][nb][r + 1];
+                                } else {
+                                    q[nb][0] = acc[mb][nb][r]; q[nb][1] = acc[mb][nb][r + 1];
+                                    q[nb][2] = acc[mb][nb][r + RDOWN]; q[nb][3] = acc[mb][nb][r + RDOWN + 1];
+                                }
+                            }
+                            vp = pooled_first(q);
+                        }
 #pragma unroll
                         for (int nb = 0; nb < 2; ++nb) {
-                            const _Float16 v = (MBW == 32)
+                            _Float16 v;
+                            if constexpr (PF) v = vp[nb];
+                            else v = (MBW == 32)
                                 ? pooled(acc[0][nb][r], acc[0][nb][r + 1], acc[1][nb][r], acc[1][nb][r + 1], nb)
                                 : pooled(acc[mb][nb][r], acc[mb][nb][r + 1], acc[mb][nb][r + RDOWN], acc[mb][nb][r + RDOWN + 1], nb);
                             if constexpr (FULL) {
@@ -406,7 +434,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvParamsH p)
                         }
                     }
             };
-            if (full) store_all(std::true_type{}); else store_all(std::false_type{});
+            if (p.pool_first) { if (full) store_all(std::true_type{}, std::true_type{}); else store_all(std::false_type{}, std::true_type{}); }
+            else { if (full) store_all(std::true_type{}, std::false_type{}); else store_all(std::false_type{}, std::false_type{}); }
         } else {
             // non-pooled: lane = pixel, register r = channel (r&3) + 8*(r>>2) + 4*half of the N-block -> 8-byte stores
             const int cs = p.out_cstride;

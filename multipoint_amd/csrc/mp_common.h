@@ -168,6 +168,8 @@ struct ConvParamsH {
     int nitems;           // work items (tile, slice) of the launch (filled in by the launcher)
     _Float16* dummy;      // >= 1 KiB scratch line that masked-off store lanes write to
     int ncu, xcd_shift;   // machine shape, as in ConvParams
+    int pool_first;       // pooled layers: the epilogue pools the accumulators first (max, or min where the channel's BatchNorm scale is negative) and
+                          // activates once per window -- bit-identical to activating all four (MP_DEBUG=no_pool_first)
     int res_groups;       // conv_f16_res.hip: independent four-wave groups per CU (3; 2 = MP_DEBUG=f16_res_groups=2; the fused-first-block launch always runs 2)
     // conv_f16_res.hip with the first encoder block fused in: the fp32 image [B][H][W] and the Cin = 1 layer's parameters
     // ([9][64] tap-major fp16-representable weights, bias, BN scale / shift); img == nullptr: p.in is read
