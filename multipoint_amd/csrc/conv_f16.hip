@@ -105,6 +105,9 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvParamsH p)
     // bias | BN scale | BN shift of the current 64-channel slice: fetched from global memory only when the slice
     // changes (a global load in every epilogue costs its L2 latency per item)
     __shared__ __attribute__((aligned(16))) float prm[3 * 64];
+    // un-pooled layers: a wave's output block (32 pixels x 64 channels, 4 KiB) passes through LDS so that a lane stores 16 bytes and eight
+    // lanes a pixel's whole 128-byte line (conv_f16_res.hip's epilogue); 16-byte granules XOR-swizzled by the pixel's low bits
+    __shared__ __attribute__((aligned(16))) _Float16 ostage[POOL ? 8 : 4 * 2048];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -490,7 +493,54 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvParamsH p)
                         }
                     }
             };
-            if (full) store_all(std::true_type{}); else store_all(std::false_type{});
+            if (TAPS == 9 || slice * 64 + 64 <= p.cout) {      // (3x3 layers: cout is a multiple of 64, launch_conv_f16 refuses anything else)
+                // Per M-block (32 pixels): every lane writes its eight 8-byte channel quads into the wave's staging block
+                // [pixel][granule ^ (pixel & 7)][8 halfs], then lane l reads granule l & 7 of pixels l >> 3, + 8, + 16, + 24 and stores 16 bytes:
+                // eight lanes = one pixel's 64 channels = one 128-byte line (8-byte pieces 128 bytes apart cost 32 partial lines per store
+                // instruction: measured 20 % of an un-pooled launch)
+                _Float16* const stg = ostage + wave * 2048;
+                int lq = lane;
+                asm volatile("" : "+v"(lq));              // the addresses below are item-invariant: keep hipcc from holding them in registers through the MFMA loop
+                const int wrow = (lq & 31) * 64 + (lq >> 5) * 4, wsw = lq & 7;
+                const int rg_l = lq & 7, rp0 = lq >> 3;
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int rg = 0; rg < 4; ++rg) {
+                            const int cl = nb * 32 + rg * 8 + half * 4;
+                            const f32x4 b4 = *reinterpret_cast<const f32x4*>(&prm[cl]);
+                            const f32x4 s4 = *reinterpret_cast<const f32x4*>(&prm[64 + cl]);
+                            const f32x4 t4 = *reinterpret_cast<const f32x4*>(&prm[128 + cl]);
+                            const h2 lo = act_h2<RELU, BNF>(acc[mb][nb][rg * 4], acc[mb][nb][rg * 4 + 1], f32x2{b4[0], b4[1]},
+                                                            f32x2{s4[0], s4[1]}, f32x2{t4[0], t4[1]});
+                            const h2 hi = act_h2<RELU, BNF>(acc[mb][nb][rg * 4 + 2], acc[mb][nb][rg * 4 + 3], f32x2{b4[2], b4[3]},
+                                                            f32x2{s4[2], s4[3]}, f32x2{t4[2], t4[3]});
+                            *reinterpret_cast<h4*>(stg + wrow + (((nb * 4 + rg) ^ wsw) << 3)) = h4{lo[0], lo[1], hi[0], hi[1]};
+                        }
+                    asm volatile("" ::: "memory");                                // (same wave: the LDS executes its operations in order)
+                    _Float16* const mp = (TAPS == 1) ? obase + (long long)((2 * wave + mb) * 32) * cs
+                                                     : obase + (long long)((2 * wave + mb) * G::MBH) * p.W * cs;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int px = rp0 + 8 * k;                          // (rp0 < 8: px / MBW and the k-part of px % MBW are uniform)
+                        const h8 v = *reinterpret_cast<const h8*>(stg + px * 64 + ((rg_l ^ rp0) << 3));
+                        _Float16* dst = (TAPS == 1) ? mp + (8 * k) * cs + (rp0 * cs + rg_l * 8)
+                                                    : mp + (((8 * k) / MBW) * p.W + (8 * k) % MBW) * cs + (rp0 * cs + rg_l * 8);
+                        if (!full) {
+                            bool okp;
+                            if constexpr (TAPS == 1) okp = px0 + (2 * wave + mb) * 32 + px < p.total_px;
+                            else okp = (y0 + (2 * wave + mb) * G::MBH + px / MBW < p.H) & (x0 + px % MBW < p.W);
+                            dst = okp ? dst : p.dummy + lane * 8;
+                        }
+                        *reinterpret_cast<h8*>(dst) = v;
+                    }
+                    asm volatile("" ::: "memory");
+                }
+            } else if constexpr (TAPS == 1) {
+                store_all(std::false_type{});          // a partial channel slice (cout = 65: the 1x1 detector head as its own launch)
+            }
         }
         MPH_T(t_epi1);
         MPH_ADD(4, t_epi0, t_epi1);                            // epilogue
@@ -633,6 +683,7 @@ __global__ __launch_bounds__(256) void conv_first_f16_kernel(const Conv1ParamsH 
 int launch_conv_f16(const ConvParamsH& p, int taps, int mbw, bool pool, hipStream_t s)
 {
     if (taps == 1) return launch_h<1, 32, false>(p, s);
+    if (p.cout != 64 * p.nslices) return 2;            // 3x3 layers: whole 64-channel slices (the model loader pads them)
     if (mbw == 32) return pool ? launch_h<9, 32, true>(p, s) : launch_h<9, 32, false>(p, s);
     if (mbw == 16) return pool ? launch_h<9, 16, true>(p, s) : launch_h<9, 16, false>(p, s);
     return pool ? launch_h<9, 8, true>(p, s) : launch_h<9, 8, false>(p, s);

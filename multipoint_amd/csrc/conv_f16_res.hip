@@ -117,6 +117,10 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
     __shared__ __attribute__((aligned(16))) _Float16 tiles[NG][G::NPIX * PSR];
     __shared__ __attribute__((aligned(16))) float prm[3 * 64];
     __shared__ unsigned gctr[NG];
+    // un-pooled layers: a wave's output block (32 pixels x 64 channels, 4 KiB) passes through LDS so that a lane stores 16 bytes and eight
+    // lanes a pixel's whole 128-byte line (lane = pixel in the accumulators: 8-byte pieces 128 bytes apart, 32 partial lines per store
+    // instruction -- measured 20 % of enc.conv3's launch); 16-byte granules XOR-swizzled by the pixel's low bits instead of a padded stride
+    __shared__ __attribute__((aligned(16))) _Float16 ostage[POOL ? 8 : NG * 4 * 2048];
     // F1: image patches (two per group: the current item's and the next one's) + a zero tail that the padding taps read
     constexpr int IW = G::LW + 2, IH = G::LH + 2, NIP = IW * IH;
     constexpr int NIPB = ((NIP + 2 * IW + 3 + 7) / 8) * 8;          // halfs per patch buffer incl. the zero tail
@@ -573,13 +577,19 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
             if (p.pool_first) { if (full) store_all(std::true_type{}, std::true_type{}); else store_all(std::false_type{}, std::true_type{}); }
             else { if (full) store_all(std::true_type{}, std::false_type{}); else store_all(std::false_type{}, std::false_type{}); }
         } else {
-            // non-pooled: lane = pixel, register r = channel (r&3) + 8*(r>>2) + 4*half of the N-block -> 8-byte stores
+            // non-pooled: lane = pixel li, register r = channel (r&3) + 8*(r>>2) + 4*half of the N-block.  Per M-block (32 pixels): every lane
+            // writes its eight 8-byte channel quads into the wave's staging block [pixel][granule ^ (pixel & 7)][8 halfs], then lane l reads
+            // granule l & 7 of pixels l >> 3, + 8, + 16, + 24 and stores 16 bytes: eight lanes = one pixel's 64 channels = one 128-byte line
             const int cs = p.out_cstride;
-            const int lane_off = ((li / MBW) * p.W + li % MBW) * cs + half * 4;
             _Float16* const obase = p.out + (((long long)img * p.H + y0) * p.W + x0) * cs + p.out_coff;
             const bool full = (y0 + G::TH <= p.H) && (x0 + G::TW <= p.W);
-            auto store_all = [&](auto full_tag) __attribute__((always_inline)) {
-                constexpr bool FULL = decltype(full_tag)::value;
+            _Float16* const stg = ostage + (grp * 4 + wave) * 2048;
+            int lq = lane;
+            asm volatile("" : "+v"(lq));                  // the addresses below are item-invariant: keep hipcc from holding them in registers through the MFMA loop
+            const int wrow = (lq & 31) * 64 + (lq >> 5) * 4, wsw = lq & 7;         // halfs: this lane's pixel row, + the half's 8 bytes in a granule
+            const int rg_l = lq & 7, rp0 = lq >> 3;                                // read side: granule, first pixel
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -588,27 +598,28 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
                         const f32x4 b4 = *reinterpret_cast<const f32x4*>(&prm[cl]);
                         const f32x4 s4 = *reinterpret_cast<const f32x4*>(&prm[64 + cl]);
                         const f32x4 t4 = *reinterpret_cast<const f32x4*>(&prm[128 + cl]);
-#pragma unroll
-                        for (int mb = 0; mb < 2; ++mb) {
-                            const h2 lo = act_r2<BNF>(acc[mb][nb][rg * 4], acc[mb][nb][rg * 4 + 1], f32x2{b4[0], b4[1]},
-                                                      f32x2{s4[0], s4[1]}, f32x2{t4[0], t4[1]});
-                            const h2 hi = act_r2<BNF>(acc[mb][nb][rg * 4 + 2], acc[mb][nb][rg * 4 + 3], f32x2{b4[2], b4[3]},
-                                                      f32x2{s4[2], s4[3]}, f32x2{t4[2], t4[3]});
-                            const h4 v = h4{lo[0], lo[1], hi[0], hi[1]};
-                            _Float16* const mp = obase + (long long)((2 * wave + mb) * G::MBH) * p.W * cs;
-                            _Float16* const dst = mp + nb * 32 + rg * 8 + lane_off;
-                            if constexpr (FULL) {
-                                if (MPRX & 32) *reinterpret_cast<h4*>(p.out + (long long)item * 16384 + wave * 4096 + ((nb * 4 + rg) * 2 + mb) * 256 + lane * 4) = v;
-                                else
-                                *reinterpret_cast<h4*>(dst) = v;
-                            } else {
-                                const bool okp = (y0 + (2 * wave + mb) * G::MBH + li / MBW < p.H) & (x0 + li % MBW < p.W);
-                                *reinterpret_cast<h4*>(okp ? dst : p.dummy + lane * 4) = v;
-                            }
-                        }
+                        const h2 lo = act_r2<BNF>(acc[mb][nb][rg * 4], acc[mb][nb][rg * 4 + 1], f32x2{b4[0], b4[1]},
+                                                  f32x2{s4[0], s4[1]}, f32x2{t4[0], t4[1]});
+                        const h2 hi = act_r2<BNF>(acc[mb][nb][rg * 4 + 2], acc[mb][nb][rg * 4 + 3], f32x2{b4[2], b4[3]},
+                                                  f32x2{s4[2], s4[3]}, f32x2{t4[2], t4[3]});
+                        *reinterpret_cast<h4*>(stg + wrow + (((nb * 4 + rg) ^ wsw) << 3)) = h4{lo[0], lo[1], hi[0], hi[1]};
                     }
-            };
-            if (full) store_all(std::true_type{}); else store_all(std::false_type{});
+                asm volatile("" ::: "memory");                                    // (same wave: the LDS executes its operations in order)
+                _Float16* const mp = obase + (long long)((2 * wave + mb) * G::MBH) * p.W * cs;
+                const int gy0 = y0 + (2 * wave + mb) * G::MBH;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int px = rp0 + 8 * k;                                    // pixel of the M-block (rp0 < 8: px / MBW and the k-part of px % MBW are uniform)
+                    const h8 v = *reinterpret_cast<const h8*>(stg + px * 64 + ((rg_l ^ rp0) << 3));
+                    _Float16* dst = mp + (((8 * k) / MBW) * p.W + (8 * k) % MBW) * cs + (rp0 * cs + rg_l * 8);
+                    if (!full) {
+                        const bool okp = (gy0 + px / MBW < p.H) & (x0 + px % MBW < p.W);
+                        dst = okp ? dst : p.dummy + lane * 8;
+                    }
+                    *reinterpret_cast<h8*>(dst) = v;
+                }
+                asm volatile("" ::: "memory");
+            }
         }
         MPR_T(t_e1);
         MPR_ADD(5, t_e0, t_e1);                                    // epilogue
@@ -670,7 +681,7 @@ int launch_conv_f16_res(const ConvParamsH& p, int mbw, bool pool, hipStream_t s)
         if (mbw == 16) return pool ? launch_res<16, true, 2>(p, s) : launch_res<16, false, 2>(p, s);
         return pool ? launch_res<8, true, 2>(p, s) : launch_res<8, false, 2>(p, s);
     }
-    if (mbw == 32) return pool ? launch_res<32, true, 3>(p, s) : launch_res<32, false, 3>(p, s);
-    if (mbw == 16) return pool ? launch_res<16, true, 3>(p, s) : launch_res<16, false, 3>(p, s);
-    return pool ? launch_res<8, true, 3>(p, s) : launch_res<8, false, 3>(p, s);
+    if (mbw == 32) return launch_res<32, true, 3>(p, s);          // (ng == 3 is a pooled layer: the un-pooled kernel's staging blocks fit two groups)
+    if (mbw == 16) return launch_res<16, true, 3>(p, s);
+    return launch_res<8, true, 3>(p, s);
 }
