@@ -466,3 +466,34 @@ def test_tie_robust_redo_replaces_only_the_flagged_rows():
             assert torch.equal(out['prob'][b], img[b]) and bool((out['desc'][b] == 0).all())
     assert U.tie_robust_redo(Net(Twin()), {'image': img}, out, [False] * 5) == 0 and len(calls) == 1      # nothing flagged: no forward
     assert U.tie_robust_redo(Net(None), {'image': img}, out, [True] * 5) == 0                               # no second algorithm
+
+
+@pytest.mark.parametrize('bn_first', [False, True])
+def test_max_pool_commutes_with_the_fp16_activation(bn_first):
+    """The identity the fp16 pooled epilogues rest on (conv_f16.hip / conv_f16_res.hip, `pool_first`), checked in torch's own half
+    arithmetic: with f(x) = fp16(BN(ReLU(fp16(x + bias)))) (MultiPoint.py:143-148 under autocast; bn_first: ReLU behind the
+    BatchNorm) the maximum of a 2x2 window's four activations equals f(max of the four accumulators) for channels whose BatchNorm
+    scale is >= 0 and f(min) where it is negative -- bit for bit, ties, zeros and saturating values included -- because every step
+    of f is monotonic.  (A fused multiply-add that rounds ONCE to fp16 would break it: the kernels pin the fp32 intermediate.)"""
+    g = torch.Generator().manual_seed(5)
+    n = 400000
+    x = torch.randn(n, 4, generator=g) * torch.tensor([0.01, 1.0, 30.0, 3000.0])[torch.randint(0, 4, (n, 1), generator=g)]
+    x[: n // 8] = x[: n // 8].round()                       # exact ties between window members
+    x[n // 8: n // 4, 1] = x[n // 8: n // 4, 0]
+    bias = torch.randn(n, 1, generator=g).half().float()
+    scale = torch.randn(n, 1, generator=g) * 2.0
+    scale[: n // 16] = 0.0
+    shift = torch.randn(n, 1, generator=g)
+
+    def act(v):
+        h = (v + bias).half()
+        if not bn_first:
+            h = torch.relu(h)
+        y = (h.float() * scale + shift).half()              # fp32 affine, THEN fp16: two roundings
+        return torch.relu(y) if bn_first else y
+
+    after = act(x).max(dim=1, keepdim=True).values
+    pick = torch.where(scale < 0, x.min(dim=1, keepdim=True).values, x.max(dim=1, keepdim=True).values)
+    first = act(pick)
+    assert torch.equal(after, first)
+    assert int((scale < 0).sum()) > n // 3 and int((x[:, 0] == x[:, 1]).sum()) > n // 16
