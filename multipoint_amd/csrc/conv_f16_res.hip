@@ -119,8 +119,12 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
     __shared__ unsigned gctr[NG];
     // un-pooled layers: a wave's output block (32 pixels x 64 channels, 4 KiB) passes through LDS so that a lane stores 16 bytes and eight
     // lanes a pixel's whole 128-byte line (lane = pixel in the accumulators: 8-byte pieces 128 bytes apart, 32 partial lines per store
-    // instruction -- measured 20 % of enc.conv3's launch); 16-byte granules XOR-swizzled by the pixel's low bits instead of a padded stride
-    __shared__ __attribute__((aligned(16))) _Float16 ostage[POOL ? 8 : NG * 4 * 2048];
+    // instruction -- measured 20 % of enc.conv3's launch); 16-byte granules XOR-swizzled by the pixel's low bits instead of a padded stride.
+    // The staging block lives in the group's own TILE: behind the last chunk's barrier nobody reads the tile any more, and the next item's
+    // chunk 0 waits in the staging registers until the epilogue is through (lds_write() behind it).  A wave stages in the stripes of the
+    // tile that its OWN threads write in lds_write() -- pixels 16 w + 64 j .. + 15 (1280 bytes each), eight 128-byte rows per stripe --
+    // so no other wave's tile write can land in a block that is still being read, and no barrier separates epilogue and tile write.
+    static_assert(G::NITER >= 5 && 16 * PSR >= 8 * 64, "a wave owns four full stripes of 16 tile pixels");
     // F1: image patches (two per group: the current item's and the next one's) + a zero tail that the padding taps read
     constexpr int IW = G::LW + 2, IH = G::LH + 2, NIP = IW * IH;
     constexpr int NIPB = ((NIP + 2 * IW + 3 + 7) / 8) * 8;          // halfs per patch buffer incl. the zero tail
@@ -481,7 +485,9 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
                 }
             } else {
                 if (LAST) cur_pad = nxt_pad;
-                if (!LAST || has_next) lds_write();            // staged registers are free again before the epilogue
+                // (pooled layers: the staged registers are free again before the epilogue; un-pooled ones: the epilogue stages in the
+                //  tile first, see `ostage` above)
+                if (!LAST || (has_next && (POOL || (MPRX & 2)))) lds_write();
             }
             MPR_T(t_w);
             MPR_ADD(3, t_b0, t_w);                                 // tile production / LDS write
@@ -583,10 +589,10 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
             const int cs = p.out_cstride;
             _Float16* const obase = p.out + (((long long)img * p.H + y0) * p.W + x0) * cs + p.out_coff;
             const bool full = (y0 + G::TH <= p.H) && (x0 + G::TW <= p.W);
-            _Float16* const stg = ostage + (grp * 4 + wave) * 2048;
+            _Float16* const stg = lds + (16 * wave) * PSR;                          // + stripe (row >> 3) * 64 * PSR + (row & 7) * 64
             int lq = lane;
             asm volatile("" : "+v"(lq));                  // the addresses below are item-invariant: keep hipcc from holding them in registers through the MFMA loop
-            const int wrow = (lq & 31) * 64 + (lq >> 5) * 4, wsw = lq & 7;         // halfs: this lane's pixel row, + the half's 8 bytes in a granule
+            const int wrow = ((lq & 31) >> 3) * (64 * PSR) + (lq & 7) * 64 + (lq >> 5) * 4, wsw = lq & 7;   // halfs: this lane's pixel row, + the half's 8 bytes in a granule
             const int rg_l = lq & 7, rp0 = lq >> 3;                                // read side: granule, first pixel
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) {
@@ -610,7 +616,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int px = rp0 + 8 * k;                                    // pixel of the M-block (rp0 < 8: px / MBW and the k-part of px % MBW are uniform)
-                    const h8 v = *reinterpret_cast<const h8*>(stg + px * 64 + ((rg_l ^ rp0) << 3));
+                    const h8 v = *reinterpret_cast<const h8*>(stg + k * (64 * PSR) + rp0 * 64 + ((rg_l ^ rp0) << 3));   // row px = rp0 + 8 k: stripe k
                     _Float16* dst = mp + (((8 * k) / MBW) * p.W + (8 * k) % MBW) * cs + (rp0 * cs + rg_l * 8);
                     if (!full) {
                         const bool okp = (gy0 + px / MBW < p.H) & (x0 + px % MBW < p.W);
@@ -621,6 +627,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
                 asm volatile("" ::: "memory");
             }
         }
+        if constexpr (!POOL) { if (has_next && !(MPRX & 2)) lds_write(); }   // the next item's chunk 0 into the tile the epilogue staged in
         MPR_T(t_e1);
         MPR_ADD(5, t_e0, t_e1);                                    // epilogue
 #ifdef MP_TIMING
@@ -667,8 +674,9 @@ bool conv_f16_res_supports(const ConvParamsH& p, int taps)
 
 int launch_conv_f16_res(const ConvParamsH& p, int mbw, bool pool, hipStream_t s)
 {
-    // three groups per CU for the pooled layers, two for the un-pooled ones (their epilogue writes 4x the bytes: enc.conv3
-    // 0.45 vs 0.48 ms, enc.conv5's slices 0.24 vs 0.25 ms with two); MP_DEBUG=f16_res_groups=2 (read per handle in mp_create): two everywhere
+    // three groups per CU for the pooled layers, two for the un-pooled ones (round 3, 8-byte stores: enc.conv3 0.45 vs 0.48 ms with two; round 5,
+    // whole-line stores staged in the tile: 0.379 vs 0.372 ms alone and 4.02 vs 4.00 ms per step in the pipeline -- equal, and two groups leave
+    // 31 KiB of LDS to the side stream's workgroups); MP_DEBUG=f16_res_groups=2 (read per handle in mp_create): two everywhere
     const int ng = (p.res_groups == 2 || !pool) ? 2 : 3;
     if (p.img) {           // first encoder block fused in: the pooled 64 -> 64 layer (enc.conv2), reflection padding
         if (!pool || p.pad_zero) return 2;
@@ -681,7 +689,7 @@ int launch_conv_f16_res(const ConvParamsH& p, int mbw, bool pool, hipStream_t s)
         if (mbw == 16) return pool ? launch_res<16, true, 2>(p, s) : launch_res<16, false, 2>(p, s);
         return pool ? launch_res<8, true, 2>(p, s) : launch_res<8, false, 2>(p, s);
     }
-    if (mbw == 32) return launch_res<32, true, 3>(p, s);          // (ng == 3 is a pooled layer: the un-pooled kernel's staging blocks fit two groups)
+    if (mbw == 32) return launch_res<32, true, 3>(p, s);          // (ng == 3 is a pooled layer)
     if (mbw == 16) return launch_res<16, true, 3>(p, s);
     return launch_res<8, true, 3>(p, s);
 }
