@@ -72,6 +72,53 @@ def pmc_traffic(workload, instantiation):
         return None
 
 
+# ---- the rank program's decisions as pure functions (tests/test_dist_gloo.py holds them to BASELINE.json on the CPU: an 8-GPU node
+# only appears at round end, so the N > 1 line must be right the first time it runs) ----
+def rank_env(environ=None):
+    """(rank, world, local_rank) as torchrun exports them; a plain `python bench.py` is rank 0 of 1."""
+    e = os.environ if environ is None else environ
+    return int(e.get('RANK', 0)), int(e.get('WORLD_SIZE', 1)), int(e.get('LOCAL_RANK', 0))
+
+
+def local_device_index(local_rank, n_visible):
+    """HIP device index of this rank.  torchrun exposes every GPU of the node to every rank: device = LOCAL_RANK.  A launcher
+    that pre-sets HIP_VISIBLE_DEVICES per rank (one GPU each) leaves exactly one device visible: device 0, whatever LOCAL_RANK
+    says.  Anything else (fewer visible devices than local ranks, but more than one) cannot be mapped and is refused."""
+    if n_visible <= 0:
+        raise RuntimeError('bench.py needs an MI355X: no HIP device is visible')
+    if local_rank < n_visible:
+        return local_rank
+    if n_visible == 1:
+        return 0
+    raise RuntimeError('LOCAL_RANK %d but only %d HIP devices are visible (HIP_VISIBLE_DEVICES=%r): give every rank all GPUs '
+                       'of the node (torchrun) or exactly one' % (local_rank, n_visible, os.environ.get('HIP_VISIBLE_DEVICES')))
+
+
+def workload_name(P, world, height, width, topk, c5=False, forward_only=False):
+    """`config.workload` of the printed line: which BASELINE.json config the job IS.  32 pairs per GPU on 8 GPUs is configs[3]
+    (256 pairs sharded 8 x 32, RCCL gather of the metric records only); any other rank count runs configs[2]'s per-GPU batch."""
+    if c5:
+        return ('BASELINE configs[4]%s: %d pairs (=%d images) 1024x1280 per GPU, fp16 MFMA conv path (fp32 accumulate), box-NMS size 4 + '
+                'top-k %d, bilinear desc sampling, mutual-NN match'
+                % (' (64 pairs sharded over 8 GPUs)' if (world == 8 and P == 8) else ' (per-GPU share)', P, 2 * P, topk))
+    if forward_only:
+        return 'BASELINE configs[1]: %d pairs %dx%d per GPU, forward only' % (P, height, width)
+    if world == 8 and P == PAIRS_PER_GPU:
+        return ('BASELINE configs[3]: %d pairs %dx%d sharded over 8 GPUs (%d per GPU = %d images, independent pairs, pair p on rank p mod 8), '
+                'full path: fp32 encoder+heads, box-NMS size 4 + top-k %d, bilinear desc sampling, mutual-NN match; RCCL gathers the '
+                'per-pair metric records only' % (P * world, height, width, P, 2 * P, topk))
+    return ('BASELINE configs[2]: %d pairs (=%d images) %dx%d per GPU, full path: fp32 encoder+heads, box-NMS size 4 + top-k %d, '
+            'bilinear desc sampling, mutual-NN match' % (P, 2 * P, height, width, topk))
+
+
+def runs_extra_legs(world, use_dist, no_cpu_baseline=False, no_secondary=False, forward_only=False, host_input=False, c5=False):
+    """(cpu_baseline + parity, secondary): the legs rank 0 runs AFTER the timed region, on N = 1 only -- on N > 1 the job is the ranks
+    and nothing else (the driver's clock around an N-GPU run must not include a CPU baseline on rank 0's host cores)."""
+    cpu = world == 1 and not no_cpu_baseline
+    sec = cpu and not use_dist and not no_secondary and not forward_only and not host_input and not c5
+    return cpu, sec
+
+
 def make_batch(pair_ids, device, H=H, W=W):
     """Interleaved batch: image 2i = optical, 2i+1 = thermal of global pair id pair_ids[i]."""
     from multipoint_amd.datasets import SyntheticPairs
@@ -257,6 +304,44 @@ def _timed_steps(fn, device, steps, warmup):
     return (time.perf_counter() - t0) / steps
 
 
+class HostFeeder:
+    """--host-input / secondary.host_input: every step first uploads its batch from pinned host memory on a copy stream,
+    double-buffered, overlapping the previous step -- the reference's path starts at utils.data_to_device (utils.py:28-34)."""
+
+    def __init__(self, images, device):
+        self.device = device
+        self.host = images.cpu().pin_memory()
+        self.bufs = [torch.empty_like(images), torch.empty_like(images)]
+        self.copy_stream = torch.cuda.Stream(device)
+        self.copied = [torch.cuda.Event(), torch.cuda.Event()]
+        self.consumed = [torch.cuda.Event(), torch.cuda.Event()]
+        self.n = 0
+        for sl in (0, 1):
+            self.consumed[sl].record(torch.cuda.current_stream(device))
+        self.upload(0)
+
+    def upload(self, slot):
+        with torch.cuda.stream(self.copy_stream):
+            self.copy_stream.wait_event(self.consumed[slot])   # the step that last read this buffer has finished
+            self.bufs[slot].copy_(self.host, non_blocking=True)
+            self.copied[slot].record(self.copy_stream)
+
+    def next_batch(self):
+        slot = self.n & 1
+        self.upload(slot ^ 1)                                  # the next batch travels while this one is computed
+        torch.cuda.current_stream(self.device).wait_event(self.copied[slot])
+        self.n += 1
+        return slot, self.bufs[slot]
+
+    def done(self, slot, out):
+        # the forward runs on the pipeline's own stream: its inputs_consumed event (the caller's stream is ordered behind it too)
+        ev = getattr(out, 'inputs_consumed', None)
+        if ev is not None:
+            self.consumed[slot] = ev
+        else:
+            self.consumed[slot].record(torch.cuda.current_stream(self.device))
+
+
 def secondary_block(device):
     """Rates the round-4 verdict asked to see under the driver's clock, kept OUT of `value` / `config` (N = 1 only, ~15 s):
     `c5` = BASELINE configs[4]'s per-GPU share (8 pairs 1024x1280, fp16 MFMA path, top-k 2000) with the hardware fraction of its
@@ -275,6 +360,32 @@ def secondary_block(device):
         images = make_batch(list(range(pairs)), device, h, w)
         flags = (torch.arange(2 * pairs) % 2 == 0).reshape(-1, 1)
         return net, pipe, images, flags
+
+    # the headline workload through the two other entries a caller has (round-5 verdict item 3):
+    #   converged  = PairPipeline.run_converged, what the CLIs and compute_descriptor_metrics call (evaluation.py:224-285): exact NMS,
+    #                tie guards read from the host once per batch and flagged images redone with conv_algorithm direct
+    #   host_input = the throughput entry fed from pinned host memory every step (utils.data_to_device, utils.py:28-34)
+    net, pipe, images, flags = build(dict(SHIPPED_MODEL_CONFIG), dict(PRED_CFG), PAIRS_PER_GPU, 480, 640)
+    _timed_steps(lambda: pipe.run_converged(images, None, flags), device, 2, 2)
+    redone0 = pipe.tie_redone_total
+    dt = _timed_steps(lambda: pipe.run_converged(images, None, flags), device, 20, 0)
+    sec['converged'] = {'workload': 'BASELINE configs[2] through PairPipeline.run_converged (the entry that guarantees the reference\'s lists: '
+                                    'NMS iterated to its fixed point, tie guards read per batch, flagged images redone with conv_algorithm direct)',
+                        'pairs_per_s': round(PAIRS_PER_GPU / dt, 1), 'ms_per_step': round(dt * 1e3, 3), 'steps': 20,
+                        'images_redone_by_tie_guard': pipe.tie_redone_total - redone0}
+    feeder = HostFeeder(images, device)
+
+    def fed_step():
+        slot, batch = feeder.next_batch()
+        feeder.done(slot, pipe.run_interleaved(batch, None, flags, order_caller=False))
+    dt = _timed_steps(fed_step, device, 20, 3)
+    pipe.check_converged(device)
+    sec['host_input'] = {'workload': 'BASELINE configs[2], every step uploads its 64 images (78.6 MB) from pinned host memory on a copy '
+                                     'stream, double-buffered (PCIe-inclusive; never the headline value)',
+                         'pairs_per_s': round(PAIRS_PER_GPU / dt, 1), 'ms_per_step': round(dt * 1e3, 3), 'steps': 20,
+                         'upload_gb_per_s': round(images.numel() * 4 / dt / 1e9, 2)}
+    del net, pipe, images, feeder
+    torch.cuda.empty_cache()
 
     # c5: 8 pairs 1024x1280 fp16, top-k 2000
     cfg = dict(SHIPPED_MODEL_CONFIG); cfg['mixed_precision'] = True
@@ -359,8 +470,7 @@ def main():
         if args.pairs_per_gpu == PAIRS_PER_GPU:
             args.pairs_per_gpu = 8                # 64 pairs over 8 GPUs
 
-    rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
-    local_rank = int(os.environ.get('LOCAL_RANK', 0))
+    rank, world, local_rank = rank_env()
     if world != args.gpus:
         if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
             self_launch(args)                                   # never returns
@@ -370,11 +480,13 @@ def main():
     from multipoint_amd.dist import bind_rank_to_numa_node
     orig_affinity = os.sched_getaffinity(0) if hasattr(os, 'sched_getaffinity') else None
     # (every rank of a torchrun job binds to its GPU's NUMA node, also a job of ONE rank: the line then shows that the binding works)
-    cpu_set = bind_rank_to_numa_node(local_rank) if (world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ) else None      # before the first GPU call; silent when not exposed
+    # (counting the devices does not initialise the runtime; the binding below must run before the first call that does)
+    dev_index = local_device_index(local_rank, torch.cuda.device_count())
+    cpu_set = bind_rank_to_numa_node(dev_index) if (world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ) else None      # before the first GPU call; silent when not exposed
     if not torch.cuda.is_available():
         sys.exit('bench.py needs an MI355X; torch.cuda.is_available() is False')
-    torch.cuda.set_device(local_rank)
-    device = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev_index)
+    device = torch.device('cuda', dev_index)
     use_dist = world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ      # under torchrun: RCCL even for world 1
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
@@ -397,30 +509,11 @@ def main():
     images = make_batch(pair_ids, device, H, W)
     flags = (torch.arange(2 * P) % 2 == 0).reshape(-1, 1)
 
-    if args.host_input:
-        host_images = images.cpu().pin_memory()
-        dev_bufs = [torch.empty_like(images), torch.empty_like(images)]
-        copy_stream = torch.cuda.Stream(device)
-        copied = [torch.cuda.Event(), torch.cuda.Event()]
-        consumed = [torch.cuda.Event(), torch.cuda.Event()]
-        state = {'n': 0}
-
-        def upload(slot):
-            with torch.cuda.stream(copy_stream):
-                copy_stream.wait_event(consumed[slot])          # the step that last read this buffer has finished
-                dev_bufs[slot].copy_(host_images, non_blocking=True)
-                copied[slot].record(copy_stream)
-        for sl in (0, 1):
-            consumed[sl].record(torch.cuda.current_stream(device))
-        upload(0)
+    feeder = HostFeeder(images, device) if args.host_input else None
 
     def step():
-        if args.host_input:
-            slot = state['n'] & 1
-            upload(slot ^ 1)                                    # next batch travels while this one is computed
-            torch.cuda.current_stream(device).wait_event(copied[slot])
-            batch = dev_bufs[slot]
-            state['n'] += 1
+        if feeder is not None:
+            slot, batch = feeder.next_batch()
         else:
             batch = images
         if args.forward_only:
@@ -429,11 +522,8 @@ def main():
             # (the bench never writes its input batch again -- or, with --host-input, waits on inputs_consumed itself: the caller's
             # stream need not be ordered behind the forward, see PairPipeline.run_interleaved)
             out = pipe.run_interleaved(batch, None, flags, order_caller=args.ordered_caller)
-        if args.host_input:
-            # the forward runs on the pipeline's own stream: its inputs_consumed event (the caller's stream is ordered behind it too)
-            consumed[slot] = out.inputs_consumed if hasattr(out, 'inputs_consumed') and out.inputs_consumed is not None else consumed[slot]
-            if not hasattr(out, 'inputs_consumed'):
-                consumed[slot].record(torch.cuda.current_stream(device))
+        if feeder is not None:
+            feeder.done(slot, out)
         return out
 
     def fence():
@@ -610,13 +700,7 @@ def main():
         # hipEvent time between the forwards of consecutive steps on rank 0 (the first differences include the pipeline filling up)
         'step_ms': {'min': round(min(step_ms), 3), 'median': round(float(np.median(step_ms)), 3), 'max': round(max(step_ms), 3)},
         'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16' if c5 else 'f32', 'data': 'synthetic',
-        'config': {'workload': ('BASELINE configs[4] (per-GPU share): %d pairs (=%d images) 1024x1280, fp16 MFMA conv path '
-                                '(fp32 accumulate), box-NMS size 4 + top-k 2000, bilinear desc sampling, mutual-NN match'
-                                % (P, 2 * P)) if c5 else
-                               'BASELINE configs[2]: %d pairs (=%d images) 480x640 per GPU, full path: fp32 '
-                               'encoder+heads, box-NMS size 4 + top-k 1000, bilinear desc sampling, mutual-NN match'
-                               % (P, 2 * P) if not args.forward_only else
-                               'BASELINE configs[1]: %d pairs 480x640 per GPU, forward only' % P,
+        'config': {'workload': workload_name(P, world, H, W, PRED['topk'], c5, args.forward_only),
                    'pairs_per_gpu': P, 'height': H, 'width': W, 'topk': PRED['topk'], 'nms': PRED['nms'],
                    'weights': 'seeded synthetic state_dict (reference key layout)', 'parallelism': 'dp%d' % world},
         'input': 'pinned host memory, uploaded every step on a copy stream (PCIe-inclusive, secondary measurement)'
@@ -639,7 +723,8 @@ def main():
                         'gathered_records': int(metrics.shape[0]) if metrics is not None else None,
                         'record_fields': list(RECORD_FIELDS),
                         'rank0_cpu_affinity': ('%d CPUs: %d-%d' % (len(cpu_set), cpu_set[0], cpu_set[-1])) if cpu_set else None}
-    if world == 1 and not args.no_cpu_baseline:
+    want_cpu, want_secondary = runs_extra_legs(world, use_dist, args.no_cpu_baseline, args.no_secondary, args.forward_only, args.host_input, c5)
+    if want_cpu:
         if orig_affinity is not None:
             os.sched_setaffinity(0, orig_affinity)                # the CPU figure is the host's, not one NUMA node's
         cb, cres, prob_cpu, desc_cpu = cpu_baseline(sd, cfg, min(P, 4 if c5 else 16), H, W, PRED)
@@ -662,7 +747,7 @@ def main():
                                't_forward_ms': round(float(metrics[:, 4].mean()), 4), 't_nms_ms': round(float(metrics[:, 5].mean()), 4),
                                't_match_ms': round(float(metrics[:, 6].mean()), 4),
                                'desc_err_max': float(checked.max()) if checked.size else None, 'desc_err_pairs_checked': int(checked.size)}
-    if world == 1 and not use_dist and not args.no_secondary and not args.no_cpu_baseline and not args.forward_only and not args.host_input and not c5:
+    if want_secondary:
         del pipe, net, images
         torch.cuda.empty_cache()
         out['secondary'] = secondary_block(device)

@@ -113,7 +113,7 @@ int main(int argc, char** argv)
     /* MultiPoint.forward (MultiPoint.py:99-135) */
     CHECK_MP(mp_forward(handle, d_img, NULL, B, H, W, d_prob, NULL, d_desc, stream));
     /* box_nms(size 4, thr 0.015, iou 0.1, top-k) + torch.nonzero (utils.py:78-122, predict_align_image_pair.py:170) */
-    CHECK_MP(mp_detect_keypoints(handle, d_prob, NULL, B, H, W, 4.f, 0.015f, 0.1f, topk, K, d_kp, NULL, d_cnt, 0, stream));
+    CHECK_MP(mp_detect_keypoints(handle, d_prob, NULL, B, H, W, 4.f, 0.015f, 0.1, topk, K, d_kp, NULL, d_cnt, 0, stream));
     /* interpolate_descriptors (utils.py:159-167) */
     CHECK_MP(mp_sample_descriptors(handle, d_desc, B, Hc, Wc, D, H, W, d_kp, d_cnt, K, d_kpdesc, stream));
     /* get_matches 'bfmatcher' crossCheck (matching.py:4-33): pair p = images 2p, 2p+1 */

@@ -111,9 +111,15 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
  *   max_rounds  0: run until converged (groups of 8 rounds, one 4-byte host read per group: synchronises
  *               `stream`; at most 4096 rounds); >0: enqueue exactly that many (<= 64) fixed-point rounds
  *               asynchronously, check with mp_nms_unresolved() after a sync.
+ *   iou         DOUBLE: torchvision's CPU kernel (nms_kernel_impl(dets, scores, double iou_threshold)) compares the fp32 overlap
+ *               ratio with the caller's Python float in double, and 0.1 is not 0.1f (they differ where ratio == (float)iou,
+ *               e.g. size 11, iou 0.1, offset 9: 22 / 220).
+ * Any H x W (the reference takes any 2-D / 4-D map, utils.py:90-91; W need not be a multiple of 4 here either).  Deviation:
+ * box sizes above 16 are refused with MP_EINVAL (a footprint row is one 32-bit mask; the reference has no limit, its shipped
+ * configs use 4).
  * Tie-break (stated rule): priority = (score descending, row-major index ascending). */
 int mp_box_nms(mp_handle* h, const float* prob, const unsigned char* valid_mask, int B, int H, int W,
-               float size, float min_prob, float iou, int keep_top_k, float* prob_nms,
+               float size, float min_prob, double iou, int keep_top_k, float* prob_nms,
                int max_rounds, void* stream);
 
 /* fused box_nms + torch.nonzero(prob_nms > min_prob) (predict_align_image_pair.py:170-171,
@@ -121,7 +127,7 @@ int mp_box_nms(mp_handle* h, const float* prob, const unsigned char* valid_mask,
  *   kp_yx [B][K][2], kp_score [B][K] (may be NULL), kp_count [B]; kp_count may exceed K when
  *   keep_top_k == 0 and more than K pixels survive (only the first K are stored). */
 int mp_detect_keypoints(mp_handle* h, const float* prob, const unsigned char* valid_mask, int B, int H,
-                        int W, float size, float min_prob, float iou, int keep_top_k, int K,
+                        int W, float size, float min_prob, double iou, int keep_top_k, int K,
                         int* kp_yx, float* kp_score, int* kp_count, int max_rounds, void* stream);
 
 /* number of still-undecided NMS candidates summed over all mp_box_nms / mp_detect_keypoints calls since
@@ -137,9 +143,20 @@ int mp_nms_unresolved(mp_handle* h, int* unresolved, void* stream);
  * the image when BOTH counts reach `min_each_side` (default 4; 0 switches the guard off).  A flagged image is one whose list the
  * caller should recompute from a forward with conv_algorithm 3 (direct), which keeps exact ties; the Python mirror does that in
  * PairPipeline.run_converged / utils.box_nms_tie_robust, the throughput entry only reports the count.
+ * Two more conditions raise the same per-image flag:
+ *   - the cut splits a run of EXACTLY equal scores (some admitted, some not), whatever their number;
+ *   - footprint tie guard (also for keep_top_k == 0, the shipped configs' `topk: 0`): at least `min_pairs` (default 16; 0: off)
+ *     of the image's NMS decisions were taken between scores within `eps` -- a candidate suppressed by kept neighbours that are
+ *     ALL within eps of its own score, i.e. a suppression the noise could have turned around.  Heat maps of independent
+ *     scores hold 0-5 such pairs per 480x640 image at eps 6e-5 (measured on the oracle's maps); a plateau of tied scores inside
+ *     one footprint holds hundreds.
+ * What the guard does NOT cover (stated residual): fewer than min_each_side / min_pairs near-ties -- a single near-tied pair
+ * straddling the cut or inside a footprint flips with the noise; those are the explained fp32 flips the parity tests bound
+ * (<= 0.2 % of the keypoints, tests/test_gpu_e2e_parity.py).
  *   mp_topk_ambiguous: flags [B] (host ints, 0/1) of the LATEST mp_box_nms / mp_detect_keypoints call; *total = flagged
  *   images summed over all calls since the previous read (resets).  Synchronises `stream`. */
 int mp_topk_tie_guard(mp_handle* h, float eps, int min_each_side);
+int mp_nms_tie_guard(mp_handle* h, int min_pairs);
 int mp_topk_ambiguous(mp_handle* h, int* flags, int B, int* total, void* stream);
 
 /* replaces torch.nonzero(map > thr) on an arbitrary dense map; with valid_mask (uint8 [B][H][W] or NULL) it is

@@ -50,12 +50,13 @@ SIGNATURES = {
     'mp_load_weights': (c_int, [c_void_p, ctypes.POINTER(ModelConfig), ctypes.POINTER(Tensor), c_int]),
     'mp_forward': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p,
                            c_void_p, c_void_p]),
-    'mp_box_nms': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, c_float,
+    'mp_box_nms': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float, ctypes.c_double,
                            c_int, c_void_p, c_int, c_void_p]),
     'mp_detect_keypoints': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_float,
-                                    c_float, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+                                    ctypes.c_double, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     'mp_nms_unresolved': (c_int, [c_void_p, ctypes.POINTER(c_int), c_void_p]),
     'mp_topk_tie_guard': (c_int, [c_void_p, c_float, c_int]),
+    'mp_nms_tie_guard': (c_int, [c_void_p, c_int]),
     'mp_topk_ambiguous': (c_int, [c_void_p, ctypes.POINTER(c_int), c_int, ctypes.POINTER(c_int), c_void_p]),
     'mp_extract_keypoints': (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p,
                                      c_void_p, c_void_p, c_void_p]),

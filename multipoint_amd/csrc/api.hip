@@ -81,6 +81,9 @@ struct mp_handle {
     float tie_eps = 6e-5f;          // ... a survivor within this of the k-th score counts as 'at the cut' (mp_topk_tie_guard)
     int tie_min = 4;                // ... an image is flagged when at least this many sit at the cut on EACH side of it; 0: guard off
     int tie_last_B = 0;
+    int* tie_pairs = nullptr;       // device int [tie_pairs_cap]: footprint tie guard, per-image counts of the latest call's NMS (nms.hip)
+    int tie_pairs_cap = 0;
+    int tie_pairs_min = 16;         // ... an image is flagged when at least this many of its NMS decisions fell between scores within tie_eps; 0: off
     int head_channels = 256;        // width of each 3x3 head convolution (MultiPoint.py:38-53)
     void* dummy = nullptr;          // scratch line for masked-off store lanes of the fp16 kernels
     bool wino = true;               // Winograd F(4x4,3x3) for the 3x3 layers (MP_DEBUG=no_winograd / conv_algorithm 'direct': the direct kernels)
@@ -585,9 +588,11 @@ int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, 
             L.cin >= 16 && h->vin_min_slices > 0 &&
             L.nslices >= h->vin_min_slices) {
             // many output slices over one input (heads: 512 couts = 8 slices): transform the input ONCE (conv_wino43.hip VIN)
-            int rc = ensure(h, h->vin_ws, (size_t)conv_wino43_vglobal_floats(p) * 4);
-            if (rc) return rc;
-            p.vglobal = static_cast<float*>(h->vin_ws.p);
+            // The pre-transformed input is an OPTIONAL workspace (2.25 x the layer's input, linear in B): without it the kernel
+            // transforms per slice, bit-identically -- so an allocation failure here is not a failure of the forward
+            const int rc = ensure(h, h->vin_ws, (size_t)conv_wino43_vglobal_floats(p) * 4);
+            if (rc == MP_OK) p.vglobal = static_cast<float*>(h->vin_ws.p);
+            else { (void)hipGetLastError(); h->err.clear(); }
         }
         big = f43 == 2 ? launch_conv_wino43b(p, L.pool, s) : launch_conv_wino43(p, L.pool, s, fuse != nullptr);
     } else {
@@ -727,10 +732,11 @@ int forward_f16(mp_handle* h, const float* images, int B, int H, int W, int nset
     return MP_OK;
 }
 
-bool footprint(float size, float iou, NmsFootprint& fp)
+bool footprint(float size, double iou, NmsFootprint& fp)
 {
     // torchvision nms CPU kernel arithmetic (fp32) for two size x size boxes offset by (dy,dx):
     //   inter = max(0, size-|dy|) * max(0, size-|dx|); ovr = inter / (area + area - inter) > iou
+    // -- the last comparison in DOUBLE: nms_kernel_impl(dets, scores, double iou_threshold) promotes the fp32 ovr (include/multipoint_hip.h: mp_box_nms)
     int R = (int)std::ceil(size) - 1;
     if (R < 0) R = 0;
     if (R > MP_NMS_MAX_R) return false;
@@ -748,22 +754,26 @@ bool footprint(float size, float iou, NmsFootprint& fp)
             float hh = std::fmin(x2a, x2b) - std::fmax(x1a, x1b); if (hh < 0.f) hh = 0.f;
             const float inter = w * hh;
             const float ovr = inter / (area_a + area_b - inter);
-            if (ovr > iou) m |= 1u << (dx + R);
+            if ((double)ovr > iou) m |= 1u << (dx + R);
         }
         fp.rowmask[dy + R] = m;
     }
     return true;
 }
 
-int nms_common(mp_handle* h, const float* prob, const unsigned char* mask, int B, int H, int W,
-               float size, float min_prob, float iou, int topk, int K, int* kp_yx, float* kp_score,
+int nms_common(mp_handle* h, const float* prob, const unsigned char* mask, int B, int H, int Wc,
+               float size, float min_prob, double iou, int topk, int K, int* kp_yx, float* kp_score,
                int* kp_count, float* prob_nms, int max_rounds, hipStream_t s)
 {
-    if (B <= 0 || H <= 0 || W <= 0 || (W % 4) != 0)
-        return fail(h, MP_EINVAL, "box_nms: need B,H,W > 0 and W % 4 == 0");
+    if (B <= 0 || H <= 0 || Wc <= 0)
+        return fail(h, MP_EINVAL, "box_nms: need B,H,W > 0");
     NmsFootprint fp{};
     if (!footprint(size, iou, fp))
         return fail(h, MP_EINVAL, "box_nms: box size > " + std::to_string(MP_NMS_MAX_R + 1) + " unsupported");
+    // the work map's rows are the caller's rounded up to a multiple of 4 floats (the kernels move 16-byte groups); the padding
+    // columns are never candidates, and row-major order -- the tie-break -- is the same in both geometries.  Wc % 4 != 0 (any H x W
+    // is a legal argument of utils.box_nms, utils.py:90-91): round 0 reads the map with the generic kernel's scalar loads
+    const int W = (Wc + 3) & ~3;
     const long long n = (long long)B * H * W;
     const int ntiles = B * ((W + 31) / 32) * ((H + 31) / 32);
     // workspace: work map | list_idx | list_score
@@ -776,6 +786,18 @@ int nms_common(mp_handle* h, const float* prob, const unsigned char* mask, int B
     int* list_idx = reinterpret_cast<int*>(work + n);
     float* list_score = work + 2 * n;
     int* remaining = static_cast<int*>(h->nms_state.p);
+    // footprint tie guard: per-image counters the rounds add to and launch_select_keypoints reads and clears
+    int* pairs = nullptr;
+    if (h->tie_pairs_min > 0) {
+        if (h->tie_pairs_cap < B) {
+            if (h->tie_pairs) { MP_HIP(hipStreamSynchronize(s)); (void)hipFree(h->tie_pairs); h->tie_pairs = nullptr; h->tie_pairs_cap = 0; }
+            const int cap = B < 256 ? 256 : B;
+            MP_HIP(hipMalloc(reinterpret_cast<void**>(&h->tie_pairs), (size_t)cap * 4));
+            MP_HIP(hipMemsetAsync(h->tie_pairs, 0, (size_t)cap * 4, s));
+            h->tie_pairs_cap = cap;
+        }
+        pairs = h->tie_pairs;
+    }
     // the candidate listing (prob * mask > min_prob) is fused into round 0, which reads the probability map itself
     // Rounds: a fixed number without any host read (max_rounds > 0, at most 64), or groups of 8 with one 4-byte read
     // of the undecided count after each group until it is zero (max_rounds == 0).  A round settles every chain of
@@ -786,8 +808,8 @@ int nms_common(mp_handle* h, const float* prob, const unsigned char* mask, int B
     const int cap = max_rounds > 0 ? per : 4096;
     for (;;) {
         for (int r = 0; r < per && round < cap; ++r, ++round) {
-            if (round == 0) launch_nms_round0(prob, mask, min_prob, work, B, H, W, fp, remaining, s);
-            else launch_nms_round(work, B, H, W, fp, remaining, round, s);
+            if (round == 0) launch_nms_round0(prob, mask, min_prob, work, B, H, W, fp, remaining, s, Wc, h->tie_eps, pairs);
+            else launch_nms_round(work, B, H, W, fp, remaining, round, s, h->tie_eps, pairs);
         }
         if (max_rounds > 0 || round >= cap) break;
         launch_nms_accumulate(remaining, B, H, W, round - 1, nullptr, s);          // the tiles' undecided counts -> the round's slot
@@ -802,7 +824,7 @@ int nms_common(mp_handle* h, const float* prob, const unsigned char* mask, int B
     }
     launch_nms_accumulate(remaining, B, H, W, round - 1, h->nms_total, s);
     int* tie = nullptr;
-    if (topk > 0 && h->tie_min > 0) {
+    if ((topk > 0 && h->tie_min > 0) || pairs) {
         if (!h->tie_state) {
             MP_HIP(hipMalloc(reinterpret_cast<void**>(&h->tie_state), (1 + MP_TIE_MAX_IMAGES) * 4));
             MP_HIP(hipMemsetAsync(h->tie_state, 0, (1 + MP_TIE_MAX_IMAGES) * 4, s));
@@ -813,7 +835,8 @@ int nms_common(mp_handle* h, const float* prob, const unsigned char* mask, int B
         h->tie_last_B = 0;
     }
     launch_select_keypoints(work, B, H, W, topk, K, list_idx, list_score, H * W, kp_yx, kp_score, kp_count,
-                            prob_nms, static_cast<int*>(h->kp_scratch.p), s, h->tie_eps, h->tie_min, tie);
+                            prob_nms, static_cast<int*>(h->kp_scratch.p), s, h->tie_eps, topk > 0 ? h->tie_min : 0, tie, Wc,
+                            pairs, h->tie_pairs_min);
     MP_HIP(hipGetLastError());
     if (max_rounds == 0 && round >= cap) {
         MP_HIP(hipMemcpyAsync(h->pinned, remaining + ((round - 1) & 63), 4, hipMemcpyDeviceToHost, s));
@@ -916,6 +939,20 @@ int mp_create(mp_handle** out, int device)
         return fail(h, MP_EINVAL, "mp_create: device " + std::to_string(device) + " not available (" +
                                       std::to_string(ndev) + " HIP devices visible)");
     MP_HIP(hipSetDevice(device));
+    {
+        // Rounds 1-4 read ~20 MP_* kernel-selection variables; round 5 folded them into MP_DEBUG=key[=value],... .  A script that
+        // still sets an old name would silently A/B the default against itself: say so once.
+        static const char* const legacy[] = {"MP_NO_WINOGRAD", "MP_WINO43", "MP_WINO43_GEN", "MP_NO_FUSE", "MP_NO_FUSE43", "MP_NO_HEAD_FUSE",
+            "MP_NO_PLANAR", "MP_PLANAR", "MP_NO_PERSIST", "MP_PERSIST_MIN_ITEMS", "MP_SPLITK_MAX", "MP_F16_NO_RES", "MP_F16_NO_FUSE1",
+            "MP_F16_RES_GROUPS", "MP_NCU", "MP_NXCD", "MP_POST_OVERLAP", "MP_NO_VIN", "MP_NO_POOL_FIRST"};
+        static bool warned = false;
+        for (const char* k : legacy)
+            if (!warned && getenv(k)) {
+                warned = true;
+                fprintf(stderr, "libmultipoint_hip: the environment variable %s is no longer read (nor are the other MP_* kernel switches): "
+                                "use MP_DEBUG=key[=value],... -- the keys are listed in csrc/api.hip (debug_switch)\n", k);
+            }
+    }
     hipDeviceProp_t prop;
     MP_HIP(hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
@@ -986,6 +1023,7 @@ void mp_destroy(mp_handle* h)
     if (h->kp_scratch.p) (void)hipFree(h->kp_scratch.p);
     if (h->nms_total) (void)hipFree(h->nms_total);
     if (h->tie_state) (void)hipFree(h->tie_state);
+    if (h->tie_pairs) (void)hipFree(h->tie_pairs);
     if (h->dummy) (void)hipFree(h->dummy);
     if (h->pinned) (void)hipHostFree(h->pinned);
     for (auto& e : h->prof_entries) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -1211,7 +1249,7 @@ int mp_forward(mp_handle* h, const float* images, const unsigned char* is_optica
 }
 
 int mp_box_nms(mp_handle* h, const float* prob, const unsigned char* valid_mask, int B, int H, int W,
-               float size, float min_prob, float iou, int keep_top_k, float* prob_nms, int max_rounds,
+               float size, float min_prob, double iou, int keep_top_k, float* prob_nms, int max_rounds,
                void* stream)
 {
     if (!h) return MP_EINVAL;
@@ -1222,7 +1260,7 @@ int mp_box_nms(mp_handle* h, const float* prob, const unsigned char* valid_mask,
 }
 
 int mp_detect_keypoints(mp_handle* h, const float* prob, const unsigned char* valid_mask, int B, int H,
-                        int W, float size, float min_prob, float iou, int keep_top_k, int K, int* kp_yx,
+                        int W, float size, float min_prob, double iou, int keep_top_k, int K, int* kp_yx,
                         float* kp_score, int* kp_count, int max_rounds, void* stream)
 {
     if (!h) return MP_EINVAL;
@@ -1250,6 +1288,14 @@ int mp_topk_tie_guard(mp_handle* h, float eps, int min_each_side)
     if (!h) return MP_EINVAL;
     if (!(eps >= 0.f) || min_each_side < 0) return fail(h, MP_EINVAL, "mp_topk_tie_guard: eps >= 0 and min_each_side >= 0 (0: off)");
     h->tie_eps = eps; h->tie_min = min_each_side;
+    return MP_OK;
+}
+
+int mp_nms_tie_guard(mp_handle* h, int min_pairs)
+{
+    if (!h) return MP_EINVAL;
+    if (min_pairs < 0) return fail(h, MP_EINVAL, "mp_nms_tie_guard: min_pairs >= 0 (0: off)");
+    h->tie_pairs_min = min_pairs;
     return MP_OK;
 }
 

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(BTS) void select_keypoints_kernel(
     const float* __restrict__ work, int H, int W, int topk, int K, int* __restrict__ list_idx,
     float* __restrict__ list_score, int list_cap, int* __restrict__ kp_yx, float* __restrict__ kp_score,
     int* __restrict__ kp_count, float* __restrict__ prob_nms, const int* __restrict__ list_count,
-    float tie_eps, int tie_min, int* __restrict__ tie_state)
+    float tie_eps, int tie_min, int* __restrict__ tie_state, int Wout, int* __restrict__ tie_pairs, int pairs_min)
 {
     __shared__ int s_wave[BTS / 64];
     __shared__ unsigned s_hist[256];
@@ -224,13 +224,22 @@ __global__ __launch_bounds__(BTS) void select_keypoints_kernel(
             }
             if (kp_score) kp_score[(long long)b * K + pos] = sc;
         }
-        if (sel && prob_nms) prob_nms[(long long)b * n + idx] = sc;        // utils.py:120
+        // utils.py:120 (Wout: the dense output's row stride -- the caller's width; W is that rounded up to a multiple of 4)
+        if (sel && prob_nms) prob_nms[(long long)b * H * Wout + (long long)(idx / W) * Wout + idx % W] = sc;
     }
     if (tid == 0 && kp_count) kp_count[b] = out_base;      // may exceed K when topk == 0: overflow
     if (tie_state) {
         __syncthreads();
         if (tid == 0) {
-            const int flag = select && s_near[0] >= tie_min && s_near[1] >= tie_min;
+            // (1) the cut lies inside a plateau of near-tied scores (>= tie_min survivors within tie_eps on EITHER side of it);
+            // (2) the cut splits a run of EXACTLY equal scores (tie_base of them, `need` admitted): whatever their number -- lowest index
+            //     first is the reference's rule only if the reference's map holds the same tie;
+            // (3) footprint tie guard: >= pairs_min NMS decisions of this image were taken between scores within tie_eps (nms.hip)
+            int flag = tie_min > 0 && select && ((s_near[0] >= tie_min && s_near[1] >= tie_min) || (need > 0 && tie_base > need));
+            if (tie_pairs) {
+                if (pairs_min > 0 && tie_pairs[b] >= pairs_min) flag = 1;
+                tie_pairs[b] = 0;
+            }
             if (b < MP_TIE_MAX_IMAGES) tie_state[1 + b] = flag;
             if (flag) atomicAdd(&tie_state[0], 1);
         }
@@ -243,19 +252,23 @@ __global__ __launch_bounds__(BTS) void select_keypoints_kernel(
 void launch_select_keypoints(const float* work, int B, int H, int W, int topk, int K, int* list_idx,
                              float* list_score, int list_cap, int* kp_yx, float* kp_score,
                              int* kp_count, float* prob_nms, int* seg_scratch, hipStream_t s, float tie_eps, int tie_min,
-                             int* tie_state)
+                             int* tie_state, int Wout, int* tie_pairs, int pairs_min)
 {
     if (B <= 0) return;
+    if (Wout <= 0) Wout = W;
     const int n = H * W, nseg = (n + SEG - 1) / SEG;
     int* seg_count = seg_scratch;
     int* list_count = seg_scratch + (size_t)B * nseg;
     const dim3 g(nseg, B);
-    hipLaunchKernelGGL(count_segments_kernel<0>, g, dim3(BT), 0, s, work, n, 0.f, nseg, seg_count, prob_nms,
+    // zeros_like(prob) (utils.py:119): fused into the counting pass when the dense output has the work map's geometry
+    if (prob_nms && Wout != W) (void)hipMemsetAsync(prob_nms, 0, (size_t)B * H * Wout * sizeof(float), s);
+    hipLaunchKernelGGL(count_segments_kernel<0>, g, dim3(BT), 0, s, work, n, 0.f, nseg, seg_count, Wout == W ? prob_nms : (float*)nullptr,
                        (const unsigned char*)nullptr);
     hipLaunchKernelGGL(compact_segments_kernel<0>, g, dim3(BT), 0, s, work, n, 0.f, W, nseg, seg_count, list_cap,
                        (long long)list_cap, list_idx, list_score, (int*)nullptr, list_count, (const unsigned char*)nullptr);
     hipLaunchKernelGGL(select_keypoints_kernel, dim3(B), dim3(BTS), 0, s, work, H, W, topk, K, list_idx,
-                       list_score, list_cap, kp_yx, kp_score, kp_count, prob_nms, list_count, tie_eps, tie_min, tie_state);
+                       list_score, list_cap, kp_yx, kp_score, kp_count, prob_nms, list_count, tie_eps, tie_min, tie_state, Wout,
+                       tie_pairs, pairs_min);
 }
 
 void launch_extract_threshold(const float* map, const unsigned char* mask, int B, int H, int W, float thr, int K, int* kp_yx,

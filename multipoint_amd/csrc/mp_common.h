@@ -244,7 +244,7 @@ void launch_desc_l2norm_f16(const _Float16* raw, float* out, long long npx, int 
 // ---------------------------------------------------------------------------------------------
 // keypoint extraction
 // ---------------------------------------------------------------------------------------------
-#define MP_NMS_MAX_R 8   // footprint radius supported by the NMS kernels (box size <= 9)
+#define MP_NMS_MAX_R 15  // footprint radius supported by the NMS kernels (box size <= 16: a row of the footprint is one 32-bit mask)
 struct NmsFootprint {
     int R;                                   // radius
     unsigned rowmask[2 * MP_NMS_MAX_R + 1];  // bit (dx+R) of rowmask[dy+R] set <=> IoU > thr
@@ -253,17 +253,22 @@ struct NmsFootprint {
 // work map encoding: > 0 undecided candidate (its score), 0 dead / not a candidate, < 0 kept (-score)
 void launch_nms_init(const float* prob, const uint8_t* mask, float min_prob, float* work,
                      long long n, hipStream_t s);
+// tie_pairs (optional, int [B]): footprint tie guard -- += candidates that died to kept neighbours within tie_eps of their score only
 void launch_nms_round(float* work, int B, int H, int W, const NmsFootprint& fp, int* remaining,
-                      int round, hipStream_t s);
+                      int round, hipStream_t s, float tie_eps = 0.f, int* tie_pairs = nullptr);
+// W: width of the work map (a multiple of 4), Ws <= W: row stride (true width) of prob / mask
 void launch_nms_round0(const float* prob, const uint8_t* mask, float min_prob, float* work, int B, int H, int W,
-                       const NmsFootprint& fp, int* remaining, hipStream_t s);
+                       const NmsFootprint& fp, int* remaining, hipStream_t s, int Ws, float tie_eps = 0.f, int* tie_pairs = nullptr);
 void launch_nms_accumulate(int* remaining, int B, int H, int W, int round, int* total, hipStream_t s);
 // per image: ordered (row-major) list of kept pixels, top-k selection by (score desc, index asc),
 // outputs kp_yx [B][K][2] int32, kp_score [B][K], kp_count [B]; optional dense map prob_nms
+// Wout <= W: row stride of prob_nms (the caller's true width when the work map's rows are padded to a multiple of 4); kp_yx are
+// true coordinates either way.  tie_pairs / pairs_min: the footprint tie guard's per-image counts (nms.hip; read and reset here)
 void launch_select_keypoints(const float* work, int B, int H, int W, int topk, int K,
                              int* list_idx, float* list_score, int list_cap, int* kp_yx,
                              float* kp_score, int* kp_count, float* prob_nms, int* seg_scratch, hipStream_t s,
-                             float tie_eps = 0.f, int tie_min = 0, int* tie_state = nullptr);
+                             float tie_eps = 0.f, int tie_min = 0, int* tie_state = nullptr, int Wout = 0,
+                             int* tie_pairs = nullptr, int pairs_min = 0);
 // top-k tie guard state (device ints): [0] flagged images since the last read, [1 + b] flag of image b of the latest call
 #define MP_TIE_MAX_IMAGES 1000
 // ints of device scratch (segment counts + list totals) launch_select_keypoints / launch_extract_threshold need

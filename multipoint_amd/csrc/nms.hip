@@ -61,9 +61,14 @@ __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work
                                                        int* __restrict__ flags, int ntiles_total,
                                                        int round,
                                                        const float* __restrict__ prob, const uint8_t* __restrict__ mask,
-                                                       float min_prob)
+                                                       float min_prob, int Ws, float tie_eps, int* __restrict__ tie_pairs)
 {
-    __shared__ float t[(NT + 2 * MP_NMS_MAX_R) * (NT + 2 * MP_NMS_MAX_R)];
+    // Ws (INIT only): row stride = true width of prob / mask; the work map's W is Ws rounded up to a multiple of 4 (api.hip), the
+    // columns beyond Ws are never candidates.
+    // tie_pairs (footprint tie guard, optional): per image, the candidates that die to a kept neighbour whose score is within
+    // tie_eps of their own and to no kept neighbour with a clear margin -- decisions the convolution's rounding noise could flip
+    constexpr int TR = RT > 0 ? RT : MP_NMS_MAX_R;
+    __shared__ float t[(NT + 2 * TR) * (NT + 2 * TR)];
     __shared__ unsigned short list[2][NT * NT];
     __shared__ int cnt[2];
     const int R = RT > 0 ? RT : fp.R;
@@ -95,15 +100,15 @@ __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work
         const int ly = f / LW, lx = f - ly * LW;
         const int gy = y0 + ly - R, gx = x0 + lx - R;
         float v = 0.f;
-        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
-            const long long gi = (long long)b * H * W + (long long)gy * W + gx;
-            if constexpr (INIT) {
+        if constexpr (INIT) {
+            if (gy >= 0 && gy < H && gx >= 0 && gx < Ws) {
+                const long long gi = (long long)b * H * Ws + (long long)gy * Ws + gx;
                 v = prob[gi];
                 if (mask) v *= mask[gi] ? 1.f : 0.f;            // prob * valid_mask (predict_align_image_pair.py:128)
                 v = (v > min_prob) ? v : 0.f;                   // utils.py:97
-            } else {
-                v = work[gi];
             }
+        } else if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            v = work[(long long)b * H * W + (long long)gy * W + gx];
         }
         return v;
     };
@@ -183,16 +188,18 @@ __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work
                 float nb[2 * RT + 1];
 #pragma unroll
                 for (int dx = -RT; dx <= RT; ++dx) nb[dx + RT] = t[c + row_off + dx];
-                bool kill = false, blocked = false;
+                bool kill = false, blocked = false, near = false, clear = false;
 #pragma unroll
                 for (int dx = -RT; dx <= RT; ++dx) {
                     const bool on = row_on && ((rm >> (dx + RT)) & 1u) && !(dx == 0 && row_same);
                     const float v = on ? nb[dx + RT] : 0.f;             // 0: neither kept (< 0) nor of higher priority (s > 0)
                     kill |= v < 0.f;
+                    const bool tied = (v < 0.f) && (-v - s <= tie_eps);         // a kept neighbour within the guard's window
+                    near |= tied; clear |= (v < 0.f) && !tied;
                     const bool earlier = row_earlier || (row_same && dx < 0);   // lower flat index
                     blocked |= (v > s) || (v == s && earlier);
                 }
-                unsigned f = (kill ? 1u : 0u) | (blocked ? 2u : 0u);
+                unsigned f = (kill ? 1u : 0u) | (blocked ? 2u : 0u) | (near ? 4u : 0u) | (clear ? 8u : 0u);
                 f |= (unsigned)__shfl_xor((int)f, 1);
                 f |= (unsigned)__shfl_xor((int)f, 2);
                 f |= (unsigned)__shfl_xor((int)f, 4);
@@ -201,6 +208,7 @@ __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work
                     if (nvv != s) {
                         changed = 1;
                         t[c] = nvv;
+                        if (tie_pairs && (f & 13u) == 5u) atomicAdd(&tie_pairs[b], 1);     // died to near-tied kept neighbours only
                         if constexpr (!INIT) {      // later rounds change a handful of pixels: those go to the work map one by one
                             const int ly = c / LW, lx = c - ly * LW;
                             img[(long long)(y0 + ly - RT) * W + (x0 + lx - RT)] = nvv;
@@ -229,13 +237,15 @@ __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work
             if (i < n) {
                 const int c = list[cur][i];
                 const float s = t[c];
-                bool kill = false, blocked = false;
+                bool kill = false, blocked = false, near = false, clear = false;
                 for (int dy = -R; dy <= R; ++dy) {
                     const unsigned rmask = fp.rowmask[dy + R];
                     for (int dx = -R; dx <= R; ++dx)
                         if (((rmask >> (dx + R)) & 1u) && (dy != 0 || dx != 0)) {
                             const float nb = t[c + dy * LW + dx];
                             kill |= nb < 0.f;
+                            const bool tied = (nb < 0.f) && (-nb - s <= tie_eps);
+                            near |= tied; clear |= (nb < 0.f) && !tied;
                             const bool earlier = (dy < 0) || (dy == 0 && dx < 0);       // lower flat index
                             blocked |= (nb > s) || (nb == s && earlier);
                         }
@@ -243,6 +253,7 @@ __global__ __launch_bounds__(256) void nms_round_kernel(float* __restrict__ work
                 pos[k] = c;
                 nv[k] = kill ? 0.f : (blocked ? s : -s);
                 changed |= (nv[k] != s);
+                if (tie_pairs && kill && near && !clear) atomicAdd(&tie_pairs[b], 1);
             }
         }
         const int any = __syncthreads_or(changed);          // all reads of t[] done
@@ -318,7 +329,7 @@ void launch_nms_init(const float* prob, const uint8_t* mask, float min_prob, flo
 // layout behind `remaining`: remaining[0..63] per-round undecided totals (written by nms_accumulate_kernel when the host asks),
 // then the 2 * ntiles ping-pong tile counts
 void launch_nms_round(float* work, int B, int H, int W, const NmsFootprint& fp, int* remaining,
-                      int round, hipStream_t s)
+                      int round, hipStream_t s, float tie_eps, int* tie_pairs)
 {
     const int tiles_x = (W + NT - 1) / NT, tiles_y = (H + NT - 1) / NT;
     const int ntiles = B * tiles_x * tiles_y;
@@ -335,35 +346,36 @@ void launch_nms_round(float* work, int B, int H, int W, const NmsFootprint& fp, 
 #ifndef MP_NMS_NO_LOOP       // (developer A/B: tools/build_variant.sh nl "-DMP_NMS_NO_LOOP" nms.hip)
     if (fp.R == 3 && round >= MP_NMS_LOOP_FROM)       // the usual footprint (size 4): later rounds on a small grid that walks the tiles
         hipLaunchKernelGGL((nms_round_kernel<3, false, true>), dim3((unsigned)(ntiles < MP_NMS_LOOP_GRID ? ntiles : MP_NMS_LOOP_GRID)), dim3(256), 0, s, work, H, W,
-                           tiles_x, tiles_y, fp, flags, ntiles, round, np, nm, 0.f);
+                           tiles_x, tiles_y, fp, flags, ntiles, round, np, nm, 0.f, W, tie_eps, tie_pairs);
     else
 #endif
     if (fp.R == 3)
         hipLaunchKernelGGL((nms_round_kernel<3, false>), dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
-                           tiles_y, fp, flags, ntiles, round, np, nm, 0.f);
+                           tiles_y, fp, flags, ntiles, round, np, nm, 0.f, W, tie_eps, tie_pairs);
     else if (fp.R == 1)
         hipLaunchKernelGGL((nms_round_kernel<1, false>), dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
-                           tiles_y, fp, flags, ntiles, round, np, nm, 0.f);
+                           tiles_y, fp, flags, ntiles, round, np, nm, 0.f, W, tie_eps, tie_pairs);
     else
         hipLaunchKernelGGL((nms_round_kernel<0, false>), dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
-                           tiles_y, fp, flags, ntiles, round, np, nm, 0.f);
+                           tiles_y, fp, flags, ntiles, round, np, nm, 0.f, W, tie_eps, tie_pairs);
 }
 
 // round 0 with the candidate listing fused in: replaces launch_nms_init + launch_nms_round(round 0)
+// W: width of the work map (a multiple of 4); Ws <= W: true width = row stride of prob / mask (Ws != W: the generic kernel's scalar loads)
 void launch_nms_round0(const float* prob, const uint8_t* mask, float min_prob, float* work, int B, int H, int W,
-                       const NmsFootprint& fp, int* remaining, hipStream_t s)
+                       const NmsFootprint& fp, int* remaining, hipStream_t s, int Ws, float tie_eps, int* tie_pairs)
 {
     const int tiles_x = (W + NT - 1) / NT, tiles_y = (H + NT - 1) / NT;
     const int ntiles = B * tiles_x * tiles_y;
     if (ntiles <= 0) return;
     int* flags = remaining + 64;
-    if (fp.R == 3)
+    if (fp.R == 3 && Ws == W)
         hipLaunchKernelGGL((nms_round_kernel<3, true>), dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
-                           tiles_y, fp, flags, ntiles, 0, prob, mask, min_prob);
-    else if (fp.R == 1)
+                           tiles_y, fp, flags, ntiles, 0, prob, mask, min_prob, Ws, tie_eps, tie_pairs);
+    else if (fp.R == 1 && Ws == W)
         hipLaunchKernelGGL((nms_round_kernel<1, true>), dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
-                           tiles_y, fp, flags, ntiles, 0, prob, mask, min_prob);
+                           tiles_y, fp, flags, ntiles, 0, prob, mask, min_prob, Ws, tie_eps, tie_pairs);
     else
         hipLaunchKernelGGL((nms_round_kernel<0, true>), dim3((unsigned)ntiles), dim3(256), 0, s, work, H, W, tiles_x,
-                           tiles_y, fp, flags, ntiles, 0, prob, mask, min_prob);
+                           tiles_y, fp, flags, ntiles, 0, prob, mask, min_prob, Ws, tie_eps, tie_pairs);
 }

@@ -25,20 +25,34 @@ def hw_queues_note():
 
 
 def _visible_device_index(local_rank):
-    """The PHYSICAL index (KFD / ROCr enumeration order) of the GPU HIP device `local_rank` is, honouring HIP_VISIBLE_DEVICES /
-    ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES when they are plain integer lists.  None when a filter is set that cannot be
-    mapped by hand (UUIDs, or two filters at once): the caller then does not bind at all -- a wrong node is worse than none."""
-    filters = [os.environ[k] for k in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES')
-               if os.environ.get(k, '') != '']
-    if not filters:
-        return local_rank
-    if len(filters) > 1 and len(set(filters)) > 1:
-        return None
+    """The PHYSICAL index (KFD / ROCr enumeration order) of the GPU HIP device `local_rank` is, honouring the device filters when
+    they are plain integer lists.  HIP_VISIBLE_DEVICES and CUDA_VISIBLE_DEVICES are aliases (HIP reads either): they must agree.
+    ROCR_VISIBLE_DEVICES is a different LAYER -- it filters what the ROCr runtime exposes, and HIP then indexes into that
+    filtered list -- so the two COMPOSE: physical = rocr_ids[hip_ids[local_rank]] (ROCR='2,3' with HIP='0,1' is GPUs 2 and 3,
+    also when the two strings happen to be equal).  None when a filter cannot be mapped by hand (UUIDs, disagreeing aliases,
+    an index out of range): the caller then does not bind at all -- a wrong node is worse than none."""
+    def ints(key):
+        v = os.environ.get(key, '')
+        if v == '':
+            return None
+        return [int(x) for x in v.split(',') if x.strip() != '']          # ValueError: not an integer list
     try:
-        ids = [int(x) for x in filters[0].split(',') if x.strip() != '']
+        rocr, hip, cuda = ints('ROCR_VISIBLE_DEVICES'), ints('HIP_VISIBLE_DEVICES'), ints('CUDA_VISIBLE_DEVICES')
     except ValueError:
         return None
-    return ids[local_rank] if local_rank < len(ids) else None
+    if hip is not None and cuda is not None and hip != cuda:
+        return None
+    hip = hip if hip is not None else cuda
+    idx = local_rank
+    if hip is not None:
+        if idx >= len(hip):
+            return None
+        idx = hip[idx]
+    if rocr is not None:
+        if idx < 0 or idx >= len(rocr):
+            return None
+        idx = rocr[idx]
+    return idx if idx >= 0 else None
 
 
 def _kfd_gpu_nodes():

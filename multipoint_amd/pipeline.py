@@ -234,21 +234,30 @@ class PairPipeline:
             is_optical = (torch.arange(B) % 2 == 0).reshape(B, 1)
         data = {'image': images, 'is_optical': is_optical}
         out = self.net(data)
-        res = self._post(out, valid_mask, dev, B, H, W)
-        tie_checked = not (self.tie_robust and self.nms > 0 and self.topk > 0)
+        res = self._settle(self._post(out, valid_mask, dev, B, H, W), out, valid_mask, dev, B, H, W)
+        self.tie_redone = 0
+        if self.tie_robust and self.nms > 0:
+            # tie guards (include/multipoint_hip.h), evaluated on the CONVERGED pass -- the flags of the latest detect call, i.e. of
+            # the lists `res` holds: images whose top-k cut fell inside a plateau of scores tied within the default convolution
+            # algorithm's rounding noise (or whose NMS decided many such near-ties, whatever `topk`) are re-evaluated ONCE with the
+            # tie-exact algorithm, so that their lists follow the reference's exact score order (utils.py:97-116); one small host
+            # read per batch.  The read also drains the running total the extra passes of _settle() added to, so that a later
+            # check_converged().tie_flagged only counts lists that were actually returned.
+            flags, _ = U.topk_ambiguous(dev, B)
+            self.tie_redone = U.tie_robust_redo(self.net, data, out, flags) if any(flags) else 0
+            self.tie_redone_total += self.tie_redone
+            if self.tie_redone:
+                res = self._settle(self._post(out, valid_mask, dev, B, H, W), out, valid_mask, dev, B, H, W)
+                U.topk_ambiguous(dev, B)                         # (the redone lists flag the same plateaus again: read and drop)
+        self._last = res
+        if self.keep_maps:
+            res.prob, res.desc_map = out['prob'], out['desc']
+        return res
+
+    def _settle(self, res, out, valid_mask, dev, B, H, W):
+        """Redo the post-processing of a batch until its NMS is exact and its lists hold every keypoint (run_converged)."""
         for attempt in range(6):
-            if not tie_checked:
-                # top-k tie guard (include/multipoint_hip.h): images whose top-k cut fell inside a plateau of scores tied within the
-                # default convolution algorithm's rounding noise are re-evaluated ONCE with the tie-exact algorithm, so that their
-                # lists follow the reference's exact score order (utils.py:97-116); one small host read per batch
-                tie_checked = True
-                flags, _ = U.topk_ambiguous(dev, B)
-                self.tie_redone = U.tie_robust_redo(self.net, data, out, flags) if any(flags) else 0
-                self.tie_redone_total += self.tie_redone
-                if self.tie_redone:
-                    res = self._post(out, valid_mask, dev, B, H, W)
-                    U.topk_ambiguous(dev, B)                     # (the redone lists flag the same plateaus again: read and drop)
-            # both conditions are evaluated after EVERY pass, the last one included (check first, at most four redone passes): the
+            # both conditions are evaluated after EVERY pass, the last one included (check first, at most five redone passes): the
             # exact NMS of a redone pass can keep more keypoints than the asynchronous rounds left, i.e. overflow lists that fitted
             redo_nms = self.nms > 0 and U.nms_unresolved(dev)
             K = res.kp_yx.shape[1]
@@ -256,17 +265,14 @@ class PairPipeline:
             need = 0 if (self._capacity_is_exact(K) or not B) else int(res.kp_count.max())
             overflow = need > K
             if not (redo_nms or overflow):
-                break
+                return res
             if attempt == 5:
-                raise RuntimeError('run_converged: keypoint lists / NMS did not settle after 5 redone passes (capacity %d)' % K)
+                break
             # lists that overflowed their capacity (topk == 0: the reference keeps EVERY keypoint, utils.py:109-116) are
             # rebuilt with the exact size -- dropping the row-major tail would silently change nn_map / m_score
             res = self._post(out, valid_mask, dev, B, H, W, nms_rounds=0 if redo_nms else None,
                              capacity=((need + 255) // 256) * 256 if overflow else K)
-        self._last = res
-        if self.keep_maps:
-            res.prob, res.desc_map = out['prob'], out['desc']
-        return res
+        raise RuntimeError('run_converged: keypoint lists / NMS did not settle after 5 redone passes (capacity %d)' % res.kp_yx.shape[1])
 
     def check_converged(self, device=None):
         """Synchronises; raises if the fixed number of asynchronous NMS rounds was not enough.  Also reads the top-k tie guard:
@@ -276,10 +282,10 @@ class PairPipeline:
             self._post_stream.synchronize()
             with torch.cuda.stream(self._post_stream):
                 n = U.nms_unresolved(device)
-                self.tie_flagged = U.topk_ambiguous(device, 0)[1] if (self.nms > 0 and self.topk > 0) else 0
+                self.tie_flagged = U.topk_ambiguous(device, 0)[1] if self.nms > 0 else 0
         else:
             n = U.nms_unresolved(device)
-            self.tie_flagged = U.topk_ambiguous(device, 0)[1] if (self.nms > 0 and self.topk > 0) else 0
+            self.tie_flagged = U.topk_ambiguous(device, 0)[1] if self.nms > 0 else 0
         if n:
             raise RuntimeError('box_nms: %d candidates undecided after %d rounds; raise nms_rounds'
                                % (n, self.nms_rounds))

@@ -10,7 +10,7 @@ from .. import _lib
 
 __all__ = ['dict_update', 'data_to_device', 'data_unsqueeze', 'fix_model_weigth_keys', 'depth_to_space',
            'space_to_depth', 'box_nms', 'detect_keypoints', 'extract_keypoints', 'nms_unresolved',
-           'interpolate_descriptors', 'interpolate_descriptors_batched', 'topk_ambiguous', 'topk_tie_guard',
+           'interpolate_descriptors', 'interpolate_descriptors_batched', 'topk_ambiguous', 'topk_tie_guard', 'nms_tie_guard',
            'tie_robust_redo', 'box_nms_tie_robust']
 
 
@@ -133,9 +133,10 @@ def nms_unresolved(device=None):
 
 
 def topk_ambiguous(device=None, B=0):
-    """Top-k tie guard (include/multipoint_hip.h: mp_topk_ambiguous): (flags, total) -- flags[b] is True when the top-k cut of
-    image b of the LATEST box_nms / detect_keypoints call (keep_top_k > 0) fell inside a plateau of scores tied within the
-    convolution's rounding noise; total counts the flagged images of all calls since the previous read.  Synchronises."""
+    """Tie guards (include/multipoint_hip.h: mp_topk_ambiguous): (flags, total) -- flags[b] is True when, in the LATEST box_nms /
+    detect_keypoints call, the top-k cut of image b fell inside a plateau of scores tied within the convolution's rounding noise
+    (keep_top_k > 0), split a run of exactly equal scores, or -- footprint guard, any keep_top_k -- many of the image's NMS
+    decisions were taken between such scores; total counts the flagged images of all calls since the previous read.  Synchronises."""
     dev = _lib.require_cuda(device)
     h = _lib.get_handle(dev)
     flags = (ctypes.c_int * max(B, 1))()
@@ -149,6 +150,14 @@ def topk_tie_guard(device=None, eps=6e-5, min_each_side=4):
     dev = _lib.require_cuda(device)
     h = _lib.get_handle(dev)
     h.check(h.lib.mp_topk_tie_guard(h.ptr, float(eps), int(min_each_side)))
+
+
+def nms_tie_guard(device=None, min_pairs=16):
+    """Footprint tie guard of this device's handle: an image is flagged when at least `min_pairs` candidates were suppressed by
+    kept neighbours that are all within the guard's eps of their own score (0 switches it off)."""
+    dev = _lib.require_cuda(device)
+    h = _lib.get_handle(dev)
+    h.check(h.lib.mp_nms_tie_guard(h.ptr, int(min_pairs)))
 
 
 def tie_robust_redo(net, data, out, flags):
@@ -178,12 +187,11 @@ def box_nms_tie_robust(net, data, out, size, min_prob, iou=0.1, keep_top_k=0, on
     for them) and suppressed again, so the kept indices follow the reference's exact score order (utils.py:97-116) where the
     default algorithm's rounding noise would have picked other members of the plateau.  What the predict_* CLIs call."""
     res = box_nms(out['prob'], size, min_prob, iou, keep_top_k, on_cpu, valid_mask)
-    if keep_top_k > 0:
-        B = out['prob'].shape[0] if out['prob'].dim() == 4 else 1
-        flags, _ = topk_ambiguous(out['prob'].device, B)
-        if any(flags) and tie_robust_redo(net, data, out, flags):
-            res = box_nms(out['prob'], size, min_prob, iou, keep_top_k, on_cpu, valid_mask)
-            topk_ambiguous(out['prob'].device, B)            # the redone call flags the same plateaus again: read and drop
+    B = out['prob'].shape[0] if out['prob'].dim() == 4 else 1
+    flags, _ = topk_ambiguous(out['prob'].device, B)         # (keep_top_k == 0: the footprint guard's flags)
+    if any(flags) and tie_robust_redo(net, data, out, flags):
+        res = box_nms(out['prob'], size, min_prob, iou, keep_top_k, on_cpu, valid_mask)
+        topk_ambiguous(out['prob'].device, B)                # the redone call flags the same plateaus again: read and drop
     return res
 
 

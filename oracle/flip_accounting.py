@@ -36,7 +36,7 @@ def footprint_offsets(size, iou):
             w = max(np.float32(0), size - np.float32(abs(dx)))
             h = max(np.float32(0), size - np.float32(abs(dy)))
             inter = np.float32(w * h)
-            if np.float32(inter / np.float32(area + area - inter)) > np.float32(iou):
+            if float(np.float32(inter / np.float32(area + area - inter))) > float(iou):      # fp32 ovr against the DOUBLE threshold
                 offs.append((dy, dx))
     return offs
 

@@ -333,7 +333,7 @@ def _load_nms_lib():
         lib = ctypes.CDLL(path)
         lib.oracle_nms_greedy.restype = ctypes.c_int64
         lib.oracle_nms_greedy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64,
-                                          ctypes.c_float, ctypes.c_void_p]
+                                          ctypes.c_double, ctypes.c_void_p]
         _nms_lib = lib
     return _nms_lib
 
@@ -346,7 +346,7 @@ def nms_greedy(boxes, scores, iou):
     n = scores.shape[0]
     keep = np.empty(max(n, 1), dtype=np.int64)
     nk = _load_nms_lib().oracle_nms_greedy(boxes.ctypes.data, scores.ctypes.data, n,
-                                           ctypes.c_float(iou), keep.ctypes.data)
+                                           ctypes.c_double(iou), keep.ctypes.data)
     return keep[:nk].copy()
 
 
@@ -368,7 +368,7 @@ def nms_greedy_py(boxes, scores, iou):
         w = np.maximum(np.float32(0), xx2 - xx1); h = np.maximum(np.float32(0), yy2 - yy1)
         inter = (w * h).astype(np.float32)
         ovr = inter / (area[i] + area[rest] - inter)
-        sup[rest[ovr > np.float32(iou)]] = True
+        sup[rest[ovr.astype(np.float64) > float(iou)]] = True          # fp32 ovr against the double threshold (nms_greedy.c)
     return np.asarray(keep, dtype=np.int64)
 
 

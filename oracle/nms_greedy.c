@@ -11,7 +11,11 @@
  *   order = argsort(scores, descending, stable)           -- ties: lower candidate index first
  *   for _i in order: if suppressed[i] continue; keep i;
  *       for every later _j: ovr = inter / (area_i + area_j - inter);  suppress j if ovr > iou
- *   with inter = max(0, xx2-xx1) * max(0, yy2-yy1), everything in fp32.
+ *   with inter = max(0, xx2-xx1) * max(0, yy2-yy1), everything in fp32 -- EXCEPT the last comparison: the kernel's signature is
+ *   nms_kernel_impl(const at::Tensor& dets, const at::Tensor& scores, double iou_threshold), so `ovr > iou_threshold` promotes
+ *   the fp32 `ovr` to double and compares it with the caller's Python float (0.1 is the double 0.1, not 0.1f).  The two
+ *   comparisons differ exactly when ovr == (float)iou, e.g. size 11, iou 0.1, offset (9, 0): inter / union = 22 / 220 rounds to
+ *   0.1f > 0.1 -- torchvision suppresses (tests/test_oracle_nms.py::test_threshold_is_compared_in_double).
  *
  * PARITY UNPINNED at this third-party boundary: the reference holds no test/golden vector for
  * box_nms; the tie-break rule stated in DESIGN.md is
@@ -35,7 +39,7 @@ static int cmp_desc_stable(const void *a, const void *b)
 
 /* boxes: n x 4 as (c0_lo, c1_lo, c0_hi, c1_hi); returns number kept; keep[] in visiting order
  * (descending score) exactly like torchvision.ops.nms. */
-int64_t oracle_nms_greedy(const float *boxes, const float *scores, int64_t n, float iou,
+int64_t oracle_nms_greedy(const float *boxes, const float *scores, int64_t n, double iou,
                           int64_t *keep)
 {
     if (n <= 0) return 0;
@@ -69,7 +73,7 @@ int64_t oracle_nms_greedy(const float *boxes, const float *scores, int64_t n, fl
             float h = yy2 - yy1; if (h < 0.f) h = 0.f;
             const float inter = w * h;
             const float ovr = inter / (iarea + area[j] - inter);
-            if (ovr > iou) sup[j] = 1;
+            if ((double)ovr > iou) sup[j] = 1;      /* fp32 ovr against the DOUBLE threshold, as torchvision */
         }
     }
     free(order); free(sup); free(area);

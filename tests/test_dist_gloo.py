@@ -151,10 +151,77 @@ def test_numa_binding_resolves_the_visible_device(monkeypatch):
     monkeypatch.setenv('HIP_VISIBLE_DEVICES', '4,5,6,7')
     assert D._visible_device_index(1) == 5 and D._visible_device_index(4) is None
     monkeypatch.setenv('CUDA_VISIBLE_DEVICES', '4,5,6,7')
-    assert D._visible_device_index(0) == 4                       # the same filter twice: fine
+    assert D._visible_device_index(0) == 4                       # the HIP / CUDA aliases agree: fine
+    monkeypatch.setenv('CUDA_VISIBLE_DEVICES', '0,1,2,3')
+    assert D._visible_device_index(0) is None                    # the aliases disagree: not ours to guess
+    monkeypatch.delenv('CUDA_VISIBLE_DEVICES')
+    # ROCR_VISIBLE_DEVICES is another layer: HIP indexes into the ROCr-filtered list (round-5 advisor)
     monkeypatch.setenv('ROCR_VISIBLE_DEVICES', '1,0')
-    assert D._visible_device_index(0) is None                    # two different filters: composition is not ours to guess
-    monkeypatch.delenv('HIP_VISIBLE_DEVICES'); monkeypatch.delenv('CUDA_VISIBLE_DEVICES')
+    assert D._visible_device_index(0) is None                    # HIP index 4 of a two-entry ROCr list: unmappable
+    monkeypatch.setenv('ROCR_VISIBLE_DEVICES', '2,3'); monkeypatch.setenv('HIP_VISIBLE_DEVICES', '0,1')
+    assert D._visible_device_index(0) == 2 and D._visible_device_index(1) == 3
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '2,3')             # identical strings are still two layers
+    assert D._visible_device_index(0) is None
+    monkeypatch.setenv('ROCR_VISIBLE_DEVICES', '4,5,6,7'); monkeypatch.setenv('HIP_VISIBLE_DEVICES', '3,1')
+    assert D._visible_device_index(0) == 7 and D._visible_device_index(1) == 5 and D._visible_device_index(2) is None
+    monkeypatch.delenv('HIP_VISIBLE_DEVICES')
+    assert D._visible_device_index(1) == 5                       # ROCr filter alone
     monkeypatch.setenv('ROCR_VISIBLE_DEVICES', 'GPU-deadbeef')
     assert D._visible_device_index(0) is None                    # UUIDs cannot be mapped without a GPU call
     assert D.bind_rank_to_numa_node(0) is None                   # and then nothing is bound
+
+
+def test_c4_split_world8_gloo(tmp_path):
+    """BASELINE configs[3]: 256 pairs over 8 ranks, 32 each, pair p on rank p mod 8 -- the exact split the 8-GPU line runs -- and a
+    ragged total (250 pairs: ranks 0-1 own 32, the rest 31); every record gathered once, identical on every rank."""
+    from multipoint_amd.dist import shard_pairs
+    for n in (256, 250):
+        owned = [shard_pairs(n, r, 8) for r in range(8)]
+        assert sorted(p for o in owned for p in o) == list(range(n))
+        assert all(all(p % 8 == r for p in o) for r, o in enumerate(owned))
+        assert [len(o) for o in owned] == [n // 8 + (1 if r < n % 8 else 0) for r in range(8)]
+    n_pairs, world = 250, 8
+    mp.spawn(_worker, args=(world, _free_port(), n_pairs, str(tmp_path)), nprocs=world, join=True)
+    recs = [torch.load(tmp_path / ('rank%d.pt' % r)) for r in range(world)]
+    assert all(torch.equal(recs[0], r) for r in recs[1:]) and recs[0].shape == (n_pairs, 4)
+    assert sorted(recs[0][:, 0].tolist()) == list(range(n_pairs))
+
+
+def test_bench_rank_program_decisions(monkeypatch):
+    """bench.py's rank program, the parts that decide WHAT the N > 1 job is (pure functions, no GPU): the device of a rank under
+    torchrun (all GPUs visible: LOCAL_RANK) and under a launcher that pre-sets HIP_VISIBLE_DEVICES per rank (one visible: 0);
+    `config.workload` names BASELINE configs[3] for --gpus 8 --pairs-per-gpu 32; the CPU baseline / parity / secondary legs run
+    on N = 1 only, so that the timed N > 1 job is the ranks and nothing else."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    assert bench.rank_env({}) == (0, 1, 0)
+    assert bench.rank_env({'RANK': '5', 'WORLD_SIZE': '8', 'LOCAL_RANK': '5'}) == (5, 8, 5)
+    assert [bench.local_device_index(r, 8) for r in range(8)] == list(range(8))       # torchrun: every GPU visible to every rank
+    assert [bench.local_device_index(r, 1) for r in range(8)] == [0] * 8              # HIP_VISIBLE_DEVICES=<one GPU> per rank
+    import pytest
+    with pytest.raises(RuntimeError):
+        bench.local_device_index(5, 4)
+    with pytest.raises(RuntimeError):
+        bench.local_device_index(0, 0)
+    w8 = bench.workload_name(32, 8, 480, 640, 1000)
+    assert w8.startswith('BASELINE configs[3]: 256 pairs 480x640 sharded over 8 GPUs (32 per GPU')
+    for world in (1, 2, 4):
+        assert bench.workload_name(32, world, 480, 640, 1000).startswith('BASELINE configs[2]: 32 pairs (=64 images) 480x640 per GPU')
+    assert bench.workload_name(16, 8, 480, 640, 1000).startswith('BASELINE configs[2]')          # not C4's split
+    assert bench.workload_name(8, 8, 1024, 1280, 2000, c5=True).startswith('BASELINE configs[4] (64 pairs sharded over 8 GPUs)')
+    assert bench.workload_name(8, 1, 1024, 1280, 2000, c5=True).startswith('BASELINE configs[4] (per-GPU share)')
+    assert bench.runs_extra_legs(1, False) == (True, True)
+    assert bench.runs_extra_legs(1, True) == (True, False)                                       # torchrun at world 1: no secondary
+    for world in (2, 4, 8):
+        assert bench.runs_extra_legs(world, True) == (False, False)
+    assert bench.runs_extra_legs(1, False, no_cpu_baseline=True) == (False, False)
+    assert bench.runs_extra_legs(1, False, c5=True) == (True, False)
+    # the NUMA binding sees the same device: a rank with one visible GPU resolves ITS filter entry, not entry LOCAL_RANK
+    from multipoint_amd import dist as D
+    for k in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '5')
+    assert D._visible_device_index(bench.local_device_index(5, 1)) == 5

@@ -259,6 +259,27 @@ def test_planar_layout_is_bit_identical(oracle, monkeypatch, upd, B, H, W):
     assert torch.equal(c['prob'], b['prob']) and torch.equal(c['desc'], b['desc'])
 
 
+@pytest.mark.parametrize('bn_first', [False, True])
+@pytest.mark.parametrize('B,H,W', [(2, 64, 64), (1, 240, 320), (2, 104, 72)])
+def test_pooled_epilogue_with_negative_batchnorm_scales(oracle, bn_first, B, H, W):
+    """The pooled F(4x4,3x3) epilogue pools BEFORE it activates, with the sign of the channel's BatchNorm scale folded into the
+    bias multiply-add (conv_wino43.hip; tests/test_host_logic.py holds the identity): a third of every encoder BatchNorm's
+    gammas negative, one exactly zero -- the synthetic generator only draws positive ones."""
+    import multipoint_amd.models as M
+    cfg = dict(oracle.SHIPPED_MODEL_CONFIG); cfg['bn_first'] = bn_first
+    sd = oracle.make_weights(3, cfg)
+    for k in list(sd):
+        if k.startswith('encoder.') and k.endswith('.weight') and sd[k].dim() == 1:
+            g = sd[k].clone(); g[::3] *= -1.0; g[1] = 0.0
+            sd[k] = g
+    net = M.MultiPoint(dict(cfg)); net.load_state_dict(sd); net.to('cuda'); net.eval()
+    img = oracle.make_images(50 + H, B, H, W)
+    ref = oracle.forward(sd, img, cfg)
+    out = net({'image': img.cuda()})
+    assert (out['prob'].cpu() - ref['prob']).abs().max().item() <= PROB_TOL
+    assert (out['desc'].cpu() - ref['desc']).abs().max().item() <= DESC_TOL
+
+
 @pytest.mark.parametrize('upd', [{'channel_version': 1}, {'channel_version': 2}, {'channel_version': 1, 'descriptor_size': 128},
                                  {'channel_version': 2, 'multispectral': True, 'reflection_pad': False}])
 def test_forward_channel_versions(oracle, upd):
@@ -435,12 +456,75 @@ def test_box_nms_edge_cases(oracle, U):
     ramp = np.linspace(0.02, 0.9, 64 * 200, dtype=np.float32).reshape(64, 200)   # long dependency chain
     assert np.array_equal(U.box_nms(torch.from_numpy(ramp).cuda(), 4, 0.015).cpu().numpy(), oracle.box_nms(ramp, 4, 0.015))
     with pytest.raises(ValueError):
-        U.box_nms(torch.rand(16, 24, device='cuda'), 40, 0.015)               # footprint radius unsupported
+        U.box_nms(torch.rand(16, 24, device='cuda'), 40, 0.015)               # footprint radius unsupported (stated deviation: size <= 16)
     m = U.extract_keypoints(torch.from_numpy(ramp).cuda(), 0.5)
     assert np.array_equal(m[0][0, :int(m[2][0])].cpu().numpy(), np.argwhere(ramp > 0.5))
     vm = np.random.default_rng(0).random(ramp.shape) < 0.5                     # nonzero((prob > thr) * valid_mask)
     m = U.extract_keypoints(torch.from_numpy(ramp).cuda(), 0.5, valid_mask=torch.from_numpy(vm).cuda())
     assert np.array_equal(m[0][0, :int(m[2][0])].cpu().numpy(), np.argwhere((ramp > 0.5) & vm))
+
+
+@pytest.mark.parametrize('H,W,size,iou,topk', [(37, 45, 4, 0.1, 0), (33, 131, 4, 0.1, 60), (40, 50, 11, 0.1, 0), (17, 23, 3, 0.05, 9),
+                                                (64, 101, 12, 0.1, 0), (48, 66, 16, 0.2, 5), (5, 3, 4, 0.1, 0), (31, 1, 2, 0.1, 0)])
+def test_box_nms_any_frame_and_large_boxes(oracle, U, H, W, size, iou, topk):
+    """utils.box_nms takes any H x W and any box size (utils.py:78-122): widths that are no multiple of 4 (the work map's rows are
+    padded internally), sizes up to 16, the threshold compared in double (size 11 / iou 0.1: offset 9 overlaps by exactly 0.1f)."""
+    rng = np.random.default_rng(H * 1000 + W)
+    p = _heat(rng, 2, H, W, 0.5, 5)
+    mask = rng.random((2, 1, H, W)) < 0.8
+    ref = oracle.box_nms(p * mask, size, 0.015, iou=iou, keep_top_k=topk)
+    out = U.box_nms(torch.from_numpy(p).cuda(), size, 0.015, iou=iou, keep_top_k=topk, valid_mask=torch.from_numpy(mask).cuda())
+    assert out.shape == p.shape and np.array_equal(out.cpu().numpy(), ref)
+    assert np.array_equal(U.box_nms(torch.from_numpy(p[0, 0]).cuda(), size, 0.015, iou=iou, keep_top_k=topk).cpu().numpy(),
+                          oracle.box_nms(p[0, 0], size, 0.015, iou=iou, keep_top_k=topk))
+    kp, sc, cnt = U.detect_keypoints(torch.from_numpy(p).cuda(), size, 0.015, iou=iou, keep_top_k=topk, capacity=H * W,
+                                     valid_mask=torch.from_numpy(mask).cuda())
+    for b in range(2):
+        okp = oracle.keypoints_from_map(ref[b, 0], 0.015)
+        assert int(cnt[b]) == len(okp) and np.array_equal(kp[b, :len(okp)].cpu().numpy().astype(np.int64), okp)
+        assert np.array_equal(sc[b, :len(okp)].cpu().numpy(), ref[b, 0][okp[:, 0], okp[:, 1]])
+
+
+def test_box_nms_threshold_compared_in_double(oracle, U):
+    """oracle/nms_greedy.c: torchvision compares the fp32 overlap ratio with the DOUBLE threshold -- 22 / 220 = 0.1f > 0.1."""
+    p = np.zeros((8, 40), dtype=np.float32)
+    p[4, 10] = 0.9; p[4, 19] = 0.5
+    out = U.box_nms(torch.from_numpy(p).cuda(), 11, 0.015, iou=0.1).cpu().numpy()
+    assert out[4, 10] == np.float32(0.9) and out[4, 19] == 0 and np.array_equal(out, oracle.box_nms(p, 11, 0.015, iou=0.1))
+    out = U.box_nms(torch.from_numpy(p).cuda(), 11, 0.015, iou=float(np.float32(0.1))).cpu().numpy()
+    assert out[4, 19] == np.float32(0.5)
+
+
+def test_tie_guards_flag_plateaus_only(oracle, U):
+    """Footprint tie guard (any keep_top_k) and the exact-tie split of the top-k cut (include/multipoint_hip.h)."""
+    rng = np.random.default_rng(3)
+    H, W = 96, 128
+    noise = _heat(rng, 1, H, W, 0.05)[0, 0]                  # independent scores: next to no near-ties inside a footprint
+    plateau = np.zeros((H, W), dtype=np.float32)
+    plateau[8:88:2, 8:120:2] = 0.25                          # equal scores two pixels apart: every suppression is a tie
+    near = plateau.copy(); near[plateau > 0] += (rng.random(int((plateau > 0).sum())).astype(np.float32) * 4e-5)
+    p = np.stack([noise, plateau, near, noise])[:, None]
+    U.topk_ambiguous(None, 0)                                # (drain what earlier calls on this handle left in the running total)
+    for topk in (0, 50):
+        out = U.box_nms(torch.from_numpy(p).cuda(), 4, 0.015, keep_top_k=topk)
+        assert np.array_equal(out.cpu().numpy(), oracle.box_nms(p, 4, 0.015, keep_top_k=topk))      # (the guard only reports)
+        flags, total = U.topk_ambiguous(None, 4)
+        assert flags == [False, True, True, False] and total == 2
+    assert U.topk_ambiguous(None, 4)[1] == 0                 # the read drained the running total
+    U.nms_tie_guard(None, 0)                                 # footprint guard off: topk 0 flags nothing ...
+    try:
+        U.box_nms(torch.from_numpy(p).cuda(), 4, 0.015, keep_top_k=0)
+        assert U.topk_ambiguous(None, 4) == ([False] * 4, 0)
+        # ... and with a top-k cut only what the CUT sees: 4 survivors of one score around rank 3 split an exact tie -- flagged
+        # although fewer than min_each_side (4) sit on either side
+        q = np.zeros((2, 1, 32, 64), dtype=np.float32)
+        q[0, 0, 4, 4:64:8] = [0.9, 0.8, 0.5, 0.5, 0.5, 0.5, 0.2, 0.1]
+        q[1, 0, 4, 4:64:8] = [0.9, 0.8, 0.7, 0.6, 0.5, 0.4, 0.2, 0.1]
+        out = U.box_nms(torch.from_numpy(q).cuda(), 4, 0.015, keep_top_k=3)
+        assert np.array_equal(out.cpu().numpy(), oracle.box_nms(q, 4, 0.015, keep_top_k=3))
+        assert U.topk_ambiguous(None, 2) == ([True, False], 1)
+    finally:
+        U.nms_tie_guard(None, 16)
 
 
 def test_box_nms_async_rounds_and_overflow(oracle, U):
@@ -502,6 +586,58 @@ def test_pipeline_falls_back_to_converging_nms(oracle, shipped):
     r = few.run_interleaved(PairPipeline.interleave(img[0::2], img[1::2]))
     with pytest.raises(RuntimeError, match='undecided'):        # the throughput entry reports instead of repeating
         few.check_converged()
+
+
+class _MapNet:
+    """Stand-in for a model inside PairPipeline.run_converged: returns prepared heat maps (image b's id is its first pixel) -- the
+    default algorithm's maps, or the tie-exact twin's."""
+
+    def __init__(self, maps, twin_maps=None, desc=None):
+        self.maps, self.twin_maps, self.desc, self.calls = maps, twin_maps, desc, []
+
+    def __call__(self, data):
+        ids = data['image'][:, 0, 0, 0].round().long()
+        self.calls.append(ids.tolist())
+        return {'prob': self.maps.index_select(0, ids).clone(), 'logits': None, 'desc': self.desc.index_select(0, ids).clone()}
+
+    def direct_twin(self):
+        return _MapNet(self.twin_maps, None, self.desc) if self.twin_maps is not None else None
+
+
+@pytest.mark.parametrize('topk', [0, 40])
+def test_run_converged_reads_the_tie_guards_on_the_converged_pass(oracle, U, topk):
+    """PairPipeline.run_converged (evaluation.py:224-285's loop head): the tie guards are read from the pass whose lists are
+    returned -- after the NMS / capacity loop -- flagged images are redone with the tie-exact twin and settled again, and the
+    running total a later check_converged() reports is drained.  Also with `topk: 0` (the shipped configs): the footprint guard."""
+    from multipoint_amd.pipeline import PairPipeline
+    rng = np.random.default_rng(5)
+    H, W = 64, 640
+    noise = _heat(rng, 1, H, W, 0.03)[0, 0]
+    exact = np.zeros((H, W), dtype=np.float32); exact[8:56:2, 8:632:2] = 0.25                     # the reference's map: exact ties
+    noisy = exact.copy(); noisy[exact > 0] += rng.random(int((exact > 0).sum())).astype(np.float32) * 4e-5     # ... seen through rounding noise
+    # one round of NMS is not enough for this one (a chain of dependent decisions across 20 tiles; neighbours differ by >= 1e-4: no near-ties)
+    ramp = (0.02 + 1e-3 * np.arange(W, dtype=np.float32)[None, :] + 1e-4 * np.arange(H, dtype=np.float32)[:, None]).astype(np.float32)
+    auto = torch.from_numpy(np.stack([noise, noisy, ramp, noise])[:, None]).cuda()
+    twin = torch.from_numpy(np.stack([noise, exact, ramp, noise])[:, None]).cuda()
+    desc = torch.nn.functional.normalize(torch.rand(4, 64, H // 8, W // 8, device='cuda'), dim=1)
+    img = torch.zeros(4, 1, H, W, device='cuda'); img[:, 0, 0, 0] = torch.arange(4, device='cuda')
+    pred = {'nms': 4, 'detection_threshold': 0.015, 'topk': topk,
+            'matching': {'method': 'bfmatcher', 'method_kwargs': {'crossCheck': True}, 'knn_matches': False}}
+    net = _MapNet(auto, twin, desc)
+    pipe = PairPipeline(net, pred, capacity=64 if topk == 0 else None, nms_rounds=1)      # (topk 0: the lists overflow and are regrown too)
+    res = pipe.run_converged(img)
+    assert pipe.tie_redone == 1 and net.calls == [[0, 1, 2, 3]]
+    want = oracle.box_nms(twin.cpu().numpy(), 4, 0.015, keep_top_k=topk)
+    for b in range(4):
+        okp = oracle.keypoints_from_map(want[b, 0], 0.015)
+        assert int(res.kp_count[b]) == len(okp) and np.array_equal(res.kp_yx[b, :len(okp)].cpu().numpy().astype(np.int64), okp)
+    pipe.check_converged()
+    assert pipe.tie_flagged == 0                               # nothing left over from the passes that were redone
+    plain = PairPipeline(_MapNet(auto, None, desc), pred, capacity=64 if topk == 0 else None, nms_rounds=1, tie_robust=False)
+    res = plain.run_converged(img)                             # without the guard: the noisy map's own lists
+    want = oracle.box_nms(auto.cpu().numpy(), 4, 0.015, keep_top_k=topk)
+    okp = oracle.keypoints_from_map(want[1, 0], 0.015)
+    assert plain.tie_redone == 0 and np.array_equal(res.kp_yx[1, :len(okp)].cpu().numpy().astype(np.int64), okp)
 
 
 def test_inputs_may_be_overwritten_after_run_interleaved(oracle, shipped):

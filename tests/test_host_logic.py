@@ -497,3 +497,52 @@ def test_max_pool_commutes_with_the_fp16_activation(bn_first):
     first = act(pick)
     assert torch.equal(after, first)
     assert int((scale < 0).sum()) > n // 3 and int((x[:, 0] == x[:, 1]).sum()) > n // 16
+
+
+def _fma32(a, b, c):
+    """fp32 fused multiply-add: the product of two fp32 values is exact in fp64; the one fp64 addition is rounded to fp32 (the same
+    emulation on both sides of the identity below, and monotonic in every argument like the hardware's)."""
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+
+def _relu_bits(x):
+    """The kernels' ReLU: an INTEGER max of the float's bits with 0 (v_max_i32: negative floats and -0.0 are negative integers)."""
+    return np.maximum(x.view(np.int32), 0).view(np.float32)
+
+
+@pytest.mark.parametrize('bn_first', [False, True])
+def test_max_pool_commutes_with_the_fp32_activation_under_the_sign_fold(bn_first):
+    """The identity the fp32 pooled F(4x4,3x3) epilogue rests on (conv_wino43.hip, POOL): with g = sign of the channel's BatchNorm
+    scale folded into the multiply-add that scales the transform's value and adds the bias (x' = fma(z, g k, g b) = g x exactly),
+    ONE max-pool of x' and one activation of the pooled value -- clamp by v_med3_i32 with the bounds (0, INT_MAX) for g = 1 and
+    (INT_MIN, 0) for g = -1, then fma with |s| -- give the bits of activating all four values and pooling then."""
+    rng = np.random.default_rng(17 + bn_first)
+    n = 200000
+    z = rng.normal(0, 1, (n, 4)).astype(np.float32)
+    z[: n // 10] = np.round(z[: n // 10] * 4) / 4                       # ties inside a window
+    z[n // 10: n // 8] = 0.0
+    k = rng.choice(np.array([1.0, 0.75, 0.5625, 0.421875, 0.31640625], dtype=np.float32), (n, 4))      # sigma_r sigma_c = a^e
+    b = (rng.normal(0, 0.5, (n, 1)) * (rng.random((n, 1)) < 0.9)).astype(np.float32)
+    s = (rng.normal(0, 1, (n, 1)) * np.where(rng.random((n, 1)) < 0.02, 0.0, 1.0)).astype(np.float32)    # both signs, some zeros
+    t = rng.normal(0, 0.5, (n, 1)).astype(np.float32)
+    bb, ss, tt = (np.broadcast_to(v, (n, 4)).copy() for v in (b, s, t))
+    # reference order (MultiPoint.py:137-148 then the MaxPool2d of :168-185): activate every value, pool
+    x = _fma32(z, k, bb)
+    act = _relu_bits(_fma32(x, ss, tt)) if bn_first else _fma32(_relu_bits(x), ss, tt)
+    want = act.max(axis=1)
+    # kernel order
+    g = np.where(s < 0, np.float32(-1), np.float32(1)).astype(np.float32)
+    gg = np.broadcast_to(g, (n, 4))
+    xp = _fma32(z, k * gg, bb * gg)
+    assert np.array_equal(xp, x * gg)                                   # the sign fold is exact
+    m = xp.max(axis=1)
+    sa, t1, g1 = np.abs(s[:, 0]), t[:, 0], g[:, 0]
+    if bn_first:
+        got = _relu_bits(_fma32(m, sa, t1))
+    else:
+        lo = np.where(g1 < 0, np.int32(-2 ** 31), np.int32(0)); hi = np.where(g1 < 0, np.int32(0), np.int32(2 ** 31 - 1))
+        c = np.clip(m.view(np.int32), lo, hi).view(np.float32)          # v_med3_i32
+        got = _fma32(c, sa, t1)
+    assert np.array_equal(got, want)                                    # values ...
+    same_bits = got.view(np.int32) == want.view(np.int32)
+    assert np.all(same_bits | ((got == 0) & (want == 0)))               # ... and bits, up to the sign of an exact zero

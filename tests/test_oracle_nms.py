@@ -111,3 +111,22 @@ def test_box_nms_dispatch_does_not_change_the_result():
         assert np.array_equal(a, b)
     small = np.zeros((2, 1, 16, 16), dtype=np.float32); small[0, 0, 3, 3] = 0.5; small[1, 0, 8, 9] = 0.7
     assert np.array_equal(O.box_nms(small, 4, 0.015), O.box_nms(small, 4, 0.015, dispatch='torchvision'))
+
+
+def test_threshold_is_compared_in_double(oracle):
+    """torchvision's CPU kernel is nms_kernel_impl(dets, scores, double iou_threshold): the fp32 overlap ratio is promoted and
+    compared with the caller's Python float.  Boxes of size 11 at offset 9 overlap by 22 / 220, which rounds to 0.1f --
+    greater than the double 0.1 (suppressed), not greater than 0.1f (what a float comparison would say)."""
+    f = np.float32
+    ovr = f(22) / f(220)
+    assert ovr == f(0.1) and float(ovr) > 0.1 and not (ovr > f(0.1))
+    p = np.zeros((8, 40), dtype=np.float32)
+    p[4, 10] = 0.9; p[4, 19] = 0.5                        # offset (0, 9)
+    for use_c in (True, False):
+        out = oracle.box_nms(p, 11, 0.015, iou=0.1, use_c=use_c)
+        assert out[4, 10] == f(0.9) and out[4, 19] == 0    # suppressed, as by torchvision
+        out = oracle.box_nms(p, 11, 0.015, iou=float(f(0.1)), use_c=use_c)
+        assert out[4, 19] == f(0.5)                        # a threshold of exactly 0.1f is not exceeded
+    from oracle import flip_accounting as FA
+    assert (0, 9) in FA.footprint_offsets(11, 0.1) and (9, 0) in FA.footprint_offsets(11, 0.1)
+    assert (0, 9) not in FA.footprint_offsets(11, float(f(0.1)))
