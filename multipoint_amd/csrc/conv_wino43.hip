@@ -86,6 +86,15 @@ __device__ __forceinline__ void dma16(const float* sbase, unsigned voff_bytes, u
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff_bytes), "s"(sbase), "s"(lds_byte) : "memory");
 }
+// the same behind a wave-uniform branch: the five wait states an SGPR base needs behind a VALU write must lie INSIDE the branch's
+// own block (multipoint_amd/build.py checks it), so the statement opens with two more
+__device__ __forceinline__ void dma16b(const float* sbase, unsigned voff_bytes, unsigned lds_byte)
+{
+    if (MPQX & 2) return;
+    unsigned keep;
+    asm volatile("s_nop 1\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff_bytes), "s"(sbase), "s"(lds_byte) : "memory");
+}
 // 4 bytes per lane: 64 lanes x 4 bytes from (uniform base + per-lane byte offset) to LDS [lds_byte + 4 * lane, + 4)
 __device__ __forceinline__ void dma4(const float* sbase, unsigned voff_bytes, unsigned lds_byte)
 {
@@ -181,7 +190,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     __shared__ __attribute__((aligned(16))) float Us[2 * UB4];
     __shared__ __attribute__((aligned(16))) float raw[VIN ? 256 : 3 * RB4 + 256];        // VIN: only the dummy DMA block
     __shared__ __attribute__((aligned(16))) float scr[VIN ? 4 : 8 * SW4];
-    __shared__ __attribute__((aligned(16))) float prm[3 * 64];
+    // bias | BatchNorm scale | shift per output channel of the slice; POOL && !SPLIT (the epilogue pools before it activates): | sign of the
+    // scale (+-1) | integer clamp bounds of the ReLU on the sign-folded value, and the scale slot holds |scale|
+    __shared__ __attribute__((aligned(16))) float prm[(POOL && !SPLIT ? 6 : 3) * 64];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -264,14 +275,41 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
         if (MPQX & 128) { dma16(p.in, (unsigned)lane * 16u, dst); return; }   // L1-hot source
         dma16(src, (MPQX & 64) ? (unsigned)lane * 16u : rvoff[j], dst);
     };
-    // weight block i of this wave (36 KiB-blocks of 1 KiB per unit: waves 0-3 take 5, waves 4-7 take 4; index 36+ = dummy
-    // re-load of block 35) of the unit at `ub` -> U[buf]
-    auto u_dma = [&](const float* ub, int buf, int i) __attribute__((always_inline)) {
-        int b = wave + 8 * i;
-        b = b < 36 ? b : 35;
+    // the unit's 36 weight blocks of 1 KiB over the waves: wave w issues blocks [u_first, u_first + u_cnt), up to three per site (two
+    // sites per unit).  No dummy loads: the unit barrier's vmcnt(2) / vmcnt(3) leaves the NEWEST two / three loads in flight -- the raw /
+    // V loads every wave issues in equal number behind its weight loads -- however many weight loads precede them.  Plain launches:
+    // 5 blocks on waves 0-3, 4 on waves 4-7.  F1: waves 0, 1 also produce the second raw block of every unit (612 patch pixels are 10
+    // blocks of 64 for 8 waves), so SIMDs 0, 1 (waves 0, 4 / 1, 5) issue 3 + 4 weight loads and SIMDs 2, 3 (waves 2, 6 / 3, 7) 6 + 5:
+    // an LDS-DMA costs ~50 cycles of its SIMD's issue next to the MFMA stream, the extra raw block ~170.
+    int u_first, u_cnt;
+    if constexpr (F1 && !(MPQX & 33554432)) {
+        constexpr int cnt_[8] = {3, 3, 6, 6, 4, 4, 5, 5}, first_[8] = {0, 3, 14, 20, 6, 10, 26, 31};
+        u_cnt = 3; u_first = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { u_cnt = wave == w ? cnt_[w] : u_cnt; u_first = wave == w ? first_[w] : u_first; }
+    } else {
+        u_cnt = wave < 4 ? 5 : 4; u_first = wave < 4 ? 5 * wave : 20 + 4 * (wave - 4);
+    }
+    // site 0: blocks k = 0..2 of this wave, site 1: k = 3..5 (wave-uniform branches)
+    auto u_dma_site = [&](const float* ub, int buf, int site) __attribute__((always_inline)) {
         if (MPQX & 32) return;
-        if (MPQX & 256) { dma16(p.wpack, (unsigned)lane * 16u, us_lds + (unsigned)(buf * UB4 + b * 256) * 4u); return; }     // L1-hot source
-        dma16(ub + b * 256, (unsigned)lane * 16u, us_lds + (unsigned)(buf * UB4 + b * 256) * 4u);
+        if constexpr (VIN) {
+            // (the pre-transformed-input instantiation sits at 252 registers: the branch-free form with four dummy re-loads of block 35
+            // per unit -- five loads on every wave, blocks wave + 8 i -- keeps it free of scratch)
+#pragma unroll
+            for (int i = 3 * site; i < (site ? 5 : 3); ++i) {
+                int b = wave + 8 * i;
+                b = b < 36 ? b : 35;
+                dma16((MPQX & 256) ? p.wpack : ub + b * 256, (unsigned)lane * 16u, us_lds + (unsigned)(buf * UB4 + b * 256) * 4u);
+            }
+            return;
+        }
+#pragma unroll
+        for (int k = 3 * site; k < 3 * site + 3; ++k)
+            if (k < u_cnt) {
+                const int b = u_first + k;
+                dma16b((MPQX & 256) ? p.wpack : ub + b * 256, (unsigned)lane * 16u, us_lds + (unsigned)(buf * UB4 + b * 256) * 4u);
+            }
     };
     auto u_ptr = [&](int slice) __attribute__((always_inline)) -> const float* {      // unit 0 of a slice
         return p.wpack + (long long)slice * NC * UB4;
@@ -279,7 +317,15 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     auto load_prm = [&](int vslice) __attribute__((always_inline)) {
         const int slice = SPLIT ? vslice >> p.ks_shift : vslice;
         if (tid < 64) {
-            prm[tid] = p.bias[slice * 64 + tid]; prm[64 + tid] = p.scale[slice * 64 + tid]; prm[128 + tid] = p.shift[slice * 64 + tid];
+            const float sc = p.scale[slice * 64 + tid];
+            prm[tid] = p.bias[slice * 64 + tid]; prm[128 + tid] = p.shift[slice * 64 + tid];
+            if constexpr (POOL && !SPLIT) {
+                const bool neg = sc < 0.f;
+                prm[64 + tid] = fabsf(sc); prm[192 + tid] = neg ? -1.f : 1.f;
+                prm[256 + tid] = __int_as_float(neg ? (int)0x80000000 : 0); prm[320 + tid] = __int_as_float(neg ? 0 : 0x7fffffff);
+            } else {
+                prm[64 + tid] = sc;
+            }
         }
     };
 
@@ -576,10 +622,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
         raw_dma(rsrc, 2u * RB4 * 4u, 0); raw_dma(rsrc, 2u * RB4 * 4u, 1); ld_advance();                 // raw(2)
     }
     unsigned rd_byte = 0u, rt_byte = RB4 * 4u;           // byte offsets of the raw buffer unit n DMAs into / transforms from
-#pragma unroll
-    for (int i = 0; i < 5; ++i) u_dma(up, 0, i);                                       // U(0)
-#pragma unroll
-    for (int i = 0; i < 5; ++i) u_dma(up + UB4, 1, i);                                 // U(1)
+    u_dma_site(up, 0, 0); u_dma_site(up, 0, 1);                                        // U(0)
+    u_dma_site(up + UB4, 1, 0); u_dma_site(up + UB4, 1, 1);                            // U(1)
     load_prm(cur.slice);
     dma_wait();
     __syncthreads();
@@ -667,8 +711,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                         // fragment of U[vb] by then), raw(n+3) in groups 0, 1 of the next body -- six groups of MFMAs
                         // before the next weights queue up behind it.  The barrier waits with vmcnt(2): for everything
                         // but the two patch DMAs, which have until the NEXT barrier.
-                        if (g == 7) { u_dma(un2, vb, 0); u_dma(un2, vb, 1); u_dma(un2, vb, 2); }
-                        else if (g == 8) { u_dma(un2, vb, 3); u_dma(un2, vb, 4); }
+                        if (g == 7) u_dma_site(un2, vb, 0);
+                        else if (g == 8) u_dma_site(un2, vb, 1);
                         else if (g == 0) { if constexpr (VIN) v_dma(vcur, (vs + 3) & 3, 0); else if constexpr (!F1) raw_dma(rsrc, rd_byte, 0); }
                         else if (g == 1) { if constexpr (VIN) v_dma(vcur, (vs + 3) & 3, 1); else if constexpr (!F1) raw_dma(rsrc, rd_byte, 1); }
                         else if (g == 2) { if constexpr (VIN) v_dma(vcur, (vs + 3) & 3, 2); }
@@ -812,6 +856,56 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                 }
                 }
                 const f32x2 bb = {b4[2 * h], b4[2 * h + 1]}, ss = {s4[2 * h], s4[2 * h + 1]}, tt = {t4[2 * h], t4[2 * h + 1]};
+                f32x2 res[NO][NO];
+                if constexpr (POOL) {
+                    // Pool BEFORE the activation: one activation per pooled value instead of four (-17 % of the epilogue's vector
+                    // instructions, and next to the fp32 MFMA stream every vector instruction is matrix-pipe time).  Bit for bit the
+                    // same result: bias add, ReLU and the BatchNorm affine are monotonic per channel -- non-decreasing where the
+                    // scale is >= 0, non-increasing where it is negative -- so max(f(x_i)) = f(max x_i), or f(min x_i) for a negative
+                    // scale.  The sign g = +-1 of the channel's scale is folded into the multiply-add that scales and adds the bias
+                    // anyway (x' = g x exactly: an fma is odd in its product and addend), one max-pool serves both signs
+                    // (max g x = g * max / min x), and the activation of the sign-folded value needs no multiplication back:
+                    //   conv -> ReLU -> BN:  s relu(x) + t = |s| clamp(x') + t,  clamp = max(x', 0) for g = 1, min(x', 0) for g = -1
+                    //                        (one v_med3_i32 on the float bits, as the ReLU is one v_max_i32)
+                    //   conv -> BN -> ReLU:  relu(s x + t) = relu(|s| x' + t)
+                    // (tests/test_gpu_parity.py::test_pooled_epilogue_pools_before_the_activation compares against the direct kernels.)
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(&prm[192 + cl]);
+                    const f32x4 lo4 = *reinterpret_cast<const f32x4*>(&prm[256 + cl]), hi4 = *reinterpret_cast<const f32x4*>(&prm[320 + cl]);
+                    const f32x2 gg = {g4[2 * h], g4[2 * h + 1]};
+                    const f32x2 gb = bb * gg;                                                  // g * bias (exact)
+                    constexpr float A1 = (float)MP_W43_A, A2 = A1 * A1, A3 = A2 * A1, A4 = A2 * A2;
+                    const f32x2 gk[5] = {gg, gg * f32x2{A1, A1}, gg * f32x2{A2, A2}, gg * f32x2{A3, A3}, gg * f32x2{A4, A4}};      // g * sigma_r sigma_c
+                    f32x2 xv[4][4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        f32x2 y[4];
+                        at6s(tcol[a], y);
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const int e = (a == 1 ? 1 : a == 2 ? 2 : 0) + (b == 1 ? 1 : b == 2 ? 2 : 0);      // w43_out_scale(a, b) = A1^e
+                            xv[a][b] = __builtin_elementwise_fma(y[b], gk[e], gb);
+                        }
+                    }
+#pragma unroll
+                    for (int a = 0; a < NO; ++a)
+#pragma unroll
+                        for (int b = 0; b < NO; ++b) {
+                            f32x2 m;
+#pragma unroll
+                            for (int r = 0; r < 2; ++r)
+                                m[r] = fmaxf(fmaxf(xv[2 * a][2 * b][r], xv[2 * a][2 * b + 1][r]), fmaxf(xv[2 * a + 1][2 * b][r], xv[2 * a + 1][2 * b + 1][r]));
+                            if (BNF) {
+                                m = __builtin_elementwise_fma(m, ss, tt);
+                                m = f32x2{relu_q(m[0]), relu_q(m[1])};
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 2; ++r)
+                                    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(m[r]) : "v"(m[r]), "v"(lo4[2 * h + r]), "v"(hi4[2 * h + r]));
+                                m = __builtin_elementwise_fma(m, ss, tt);
+                            }
+                            res[a][b] = m;
+                        }
+                } else {
                 f32x2 yv[4][4];                                         // [row a][col b] -> this pair's 2 channels
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
@@ -825,20 +919,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
                         yv[a][b] = v;
                     }
                 }
-                f32x2 res[NO][NO];
 #pragma unroll
                 for (int a = 0; a < NO; ++a)
 #pragma unroll
-                    for (int b = 0; b < NO; ++b) {
-                        if constexpr (POOL) {
-#pragma unroll
-                            for (int r = 0; r < 2; ++r)
-                                res[a][b][r] = fmaxf(fmaxf(yv[2 * a][2 * b][r], yv[2 * a][2 * b + 1][r]),
-                                                     fmaxf(yv[2 * a + 1][2 * b][r], yv[2 * a + 1][2 * b + 1][r]));
-                        } else {
-                            res[a][b] = yv[a][b];
-                        }
-                    }
+                    for (int b = 0; b < NO; ++b) res[a][b] = yv[a][b];
+                }
                 if (h == 0) {
 #pragma unroll
                     for (int a = 0; a < NO; ++a)
