@@ -85,7 +85,7 @@ def local_device_index(local_rank, n_visible):
     that pre-sets HIP_VISIBLE_DEVICES per rank (one GPU each) leaves exactly one device visible: device 0, whatever LOCAL_RANK
     says.  Anything else (fewer visible devices than local ranks, but more than one) cannot be mapped and is refused."""
     if n_visible <= 0:
-        raise RuntimeError('bench.py needs an MI355X: no HIP device is visible')
+        raise RuntimeError('bench.py needs an MI355X; no HIP device is visible')
     if local_rank < n_visible:
         return local_rank
     if n_visible == 1:
@@ -481,7 +481,10 @@ def main():
     orig_affinity = os.sched_getaffinity(0) if hasattr(os, 'sched_getaffinity') else None
     # (every rank of a torchrun job binds to its GPU's NUMA node, also a job of ONE rank: the line then shows that the binding works)
     # (counting the devices does not initialise the runtime; the binding below must run before the first call that does)
-    dev_index = local_device_index(local_rank, torch.cuda.device_count())
+    try:
+        dev_index = local_device_index(local_rank, torch.cuda.device_count())
+    except RuntimeError as e:
+        sys.exit(str(e))
     cpu_set = bind_rank_to_numa_node(dev_index) if (world > 1 or 'TORCHELASTIC_RUN_ID' in os.environ) else None      # before the first GPU call; silent when not exposed
     if not torch.cuda.is_available():
         sys.exit('bench.py needs an MI355X; torch.cuda.is_available() is False')

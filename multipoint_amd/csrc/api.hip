@@ -66,8 +66,6 @@ struct mp_handle {
     DevBuf ws4;                     // pair metrics: warped keypoints + inverse match map
     DevBuf split_ws;                // F(4x4,3x3) split launches: the ranges' pre-bias output tiles
     DevBuf vin_ws;                  // F(4x4,3x3) layers with >= 4 output slices: the pre-transformed input (ConvParams::vglobal)
-    bool pool_first = true;         // fp16 pooled epilogues pool the accumulators before the activation (bit-identical; MP_DEBUG=no_pool_first:
-                                    // activate all four, then pool)
     int vin_min_slices = 4;         // ... from this many slices on (the 3x3 head convolutions: 8): GEMM pass 0.865 ms at 75 % of the matrix pipe +
                                     // 0.106 ms for the producer against 1.03 ms with the in-kernel transform per slice; MP_DEBUG=no_vin: never
     int splitk_max = 8;             // most ranges the input channels of a small launch are cut into (MP_DEBUG=splitk_max; 1: never)
@@ -90,7 +88,7 @@ struct mp_handle {
     int persist = 8;                // persistent conv workgroups for launches with >= this many items per CU
                                     // (MP_DEBUG=no_persist: never; MP_DEBUG=persist_min_items=n overrides the threshold)
     bool fuse_first = true;         // fuse the Cin=1 block into the second convolution (MP_DEBUG=no_fuse disables)
-    int planar = 1;                 // 0 (MP_DEBUG=no_planar): NHWC everywhere; 1: channel-quad-planar tensors where they pay; 2 (MP_DEBUG=planar=2): between every two F(4x4,3x3) layers
+    int planar = 1;                 // 0 (MP_DEBUG=no_planar): NHWC everywhere; 1: channel-quad-planar tensors where they pay (behind conv1 and pooled F(4x4,3x3) producers)
     int wino43 = 2;                 // MP_DEBUG=wino43: 0 off (direct kernels), 1 F(4x4,3x3) for the 3x3 layers with 64 input channels only, 2 (default) every 3x3 layer
     bool head_fuse = true;          // MP_DEBUG=no_head_fuse: separate 1x1 convolution / softmax / normalisation launches
     bool fuse43 = true;             // first block evaluated inside the F(4x4,3x3) conv2 kernel (MP_DEBUG=no_fuse43: its own launch)
@@ -521,7 +519,7 @@ int launch_failed(mp_handle* h, int code, const char* name, int B, int H, int W)
 int wino43_kind(const mp_handle* h, const ConvLayer& L, int H, int W, bool fuse, int in_cstride = 0, int in_coff = 0,
                 int out_cstride = 0, int out_coff = 0)
 {
-    if (!(L.taps == 9 && L.u43pack && h->wino && (h->wino43 == 2 || L.cin == 64))) return 0;
+    if (!(L.taps == 9 && L.u43pack && h->wino && h->wino43 == 2)) return 0;
     ConvParams q{};
     q.pad_zero = h->cfg.reflection_pad ? 0 : 1; q.cin = L.cin; q.cout = L.cout; q.H = H; q.W = W;
     q.in_cstride = in_cstride; q.in_coff = in_coff; q.out_cstride = out_cstride; q.out_coff = out_coff;
@@ -617,7 +615,6 @@ int run_conv_h(mp_handle* h, const ConvLayer& L, const _Float16* in, int in_cstr
     p.bn_first = h->cfg.bn_first;
     p.dummy = static_cast<_Float16*>(h->dummy);
     p.ncu = h->ncu; p.xcd_shift = h->xcd_shift; p.res_groups = h->f16_res_groups;
-    p.pool_first = h->pool_first ? 1 : 0;
     int mbw = 32;
     if (L.taps == 9) {
         mbw = pick_mbw(H, W);
@@ -856,16 +853,14 @@ namespace {
 // `key` or `key=value` -- kernel selection for A/B runs and for the parity tests, which hold every kernel variant to the CPU reference path.
 // They are not configuration: a model's algorithm is `model.conv_algorithm` / `model.batch_invariant` (mp_model_config).
 //   no_winograd          the direct implicit-GEMM kernels for every 3x3 layer (what conv_algorithm 3 selects per model)
-//   wino43=0|1|2         F(4x4,3x3) for no layer / the 64-input-channel layers only / every 3x3 layer (default 2)
+//   wino43=0             F(4x4,3x3) for no layer (round 6 retired the value 1 = 64-input-channel layers only: no routing selects it)
 //   wino43_gen=0|1|2     0 conv_wino43.hip where it applies and conv_wino43b.hip elsewhere; 1 / 2: only that kernel
 //   no_fuse              the fp32 first block as its own launch in front of the direct conv2 kernel
 //   no_fuse43            ... in front of the F(4x4,3x3) conv2 kernel
 //   no_head_fuse         separate 1x1 convolution / softmax / normalisation launches instead of the fused head tail (fp32 and fp16)
 //   no_vin               the 3x3 head convolutions (>= 4 output slices) transform their input per slice inside the kernel instead of
 //                        taking it pre-transformed from a pass of its own (conv_wino43.hip VIN; bit-identical either way)
-//   no_pool_first        fp16 pooled epilogues activate all four values of a window and pool then (default: pool the accumulators -- max, or
-//                        min where the channel's BatchNorm scale is negative -- and activate once: bit-identical, the activation is monotonic)
-//   no_planar, planar=0|1|2   channel-quad-planar tensors: never / behind conv1 and pooled producers (default) / everywhere
+//   no_planar            channel-quad-planar tensors never (default: behind conv1 and pooled producers; round 6 retired planar=2 = everywhere)
 //   no_persist, persist_min_items=N   direct kernels: per-tile launches / persistent from N items per CU
 //   splitk_max=1..8      most ranges the input channels of a small launch are cut into
 //   f16_no_res, f16_no_fuse1, f16_res_groups=2   fp16 path: streaming kernel everywhere / first block as its own launch / two groups
@@ -990,14 +985,12 @@ int mp_create(mp_handle** out, int device)
         hh->f16_fuse1 = !debug_switch("f16_no_fuse1");
         if (debug_switch("f16_res_groups", &v) && v == 2) hh->f16_res_groups = 2;
         if (debug_switch("no_planar")) hh->planar = 0;
-        if (debug_switch("planar", &v) && v >= 0 && v <= 2) hh->planar = v;
-        if (debug_switch("wino43", &v) && v >= 0 && v <= 2) hh->wino43 = v;
+        if (debug_switch("wino43", &v) && v == 0) hh->wino43 = 0;
         if (debug_switch("wino43_gen", &v) && v >= 0 && v <= 2) hh->wino43_gen = v;
         if (debug_switch("persist_min_items", &v) && v > 0) hh->persist = v;
         if (debug_switch("no_persist")) hh->persist = 0;
         if (debug_switch("splitk_max", &v) && v >= 1 && v <= 8) hh->splitk_max = v;
         if (debug_switch("no_vin")) hh->vin_min_slices = 0;
-        hh->pool_first = !debug_switch("no_pool_first");
     }
     hh->splitk_env = hh->splitk_max;
     hh->wino_env = hh->wino; hh->wino43_env = hh->wino43; hh->wino43_gen_env = hh->wino43_gen;
@@ -1180,7 +1173,7 @@ static int forward_checked(mp_handle* h, const float* images, const unsigned cha
             if (E.conv[i].pool) { hh /= 2; ww /= 2; }
         }
         pl[0] = h->planar && f43[0] && !E.first_pool;
-        for (int i = 1; i < E.nconv; ++i) pl[i] = h->planar && f43[i - 1] && f43[i] && (E.conv[i - 1].pool || h->planar == 2);
+        for (int i = 1; i < E.nconv; ++i) pl[i] = h->planar && f43[i - 1] && f43[i] && E.conv[i - 1].pool;
         c1.out_planar = pl[0] ? 1 : 0;
         c1.pool = E.first_pool ? 1 : 0;
         if (!fuse1) {

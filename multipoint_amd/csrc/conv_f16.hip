@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvParamsH p)
 #pragma unroll
             for (int s = 0; s < G::STEPS; ++s) {
                 // ONE memory instruction behind each MFMA: issued as a burst in front of the four MFMAs of a step, the same
-                // loads cost ~45 cycles of matrix-pipe time each instead of ~10 (tools/mfma_probe10.hip)
+                // loads cost ~45 cycles of matrix-pipe time each instead of ~10 (round-2 probe; docs/HISTORY.md A.3)
                 const h8* const wsrc = (s + PF < G::STEPS) ? wc + (s + PF) * 128 : wt + (s + PF - G::STEPS) * 128;
                 acc[0][0] = mma(af[s % RA][0], bf[s % RB][0], (FIRST && s == 0) ? zero16 : acc[0][0]);
                 __builtin_amdgcn_sched_barrier(0);
@@ -372,12 +372,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvParamsH p)
             }
             const int Ho = p.H >> 1, Wo = p.W >> 1;
             const int cs = p.out_cstride;
-            auto pooled = [&](float a0, float a1, float b0, float b1, int nb) __attribute__((always_inline)) -> _Float16 {
-                const h2 m = __builtin_elementwise_max(act_h2<RELU, BNF>(a0, a1, bia[nb], scl[nb], sft[nb]),
-                                                       act_h2<RELU, BNF>(b0, b1, bia[nb], scl[nb], sft[nb]));
-                return m[0] > m[1] ? m[0] : m[1];
-            };
-            // p.pool_first: bias add, fp16 rounding and ReLU are non-decreasing and the BatchNorm affine is monotonic in the direction of its
+            // Pool BEFORE the activation: bias add, fp16 rounding and ReLU are non-decreasing and the BatchNorm affine is monotonic in the direction of its
             // scale's sign, so the maximum of a window's four activations IS the activation of the maximum (scale < 0: the minimum) of its
             // four accumulators, bit for bit -- one activation per pooled value instead of four (channels li and 32 + li share a packed pair)
             const f32x2 biap = {bia[0][0], bia[1][0]}, sclp = {scl[0][0], scl[1][0]}, sftp = {sft[0][0], sft[1][0]};
@@ -394,9 +389,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvParamsH p)
             // registers r and r+RDOWN of one M-block
             constexpr int RDOWN = (MBW == 32) ? 0 : (MBW == 16) ? 8 : 4;
             constexpr int NMB = (MBW == 32) ? 1 : 2;
-            auto store_all = [&](auto full_tag, auto pf_tag) __attribute__((always_inline)) {
+            auto store_all = [&](auto full_tag) __attribute__((always_inline)) {
                 constexpr bool FULL = decltype(full_tag)::value;
-                constexpr bool PF = decltype(pf_tag)::value;
 #pragma unroll
                 for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
@@ -406,8 +400,8 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvParamsH p)
                         const int oy = (MBW == 32) ? (y0 + 2 * wave) >> 1 : (y0 + (2 * wave + mb) * G::MBH + iu / MBW) >> 1;
                         const int oxu = (x0 + iu % MBW) >> 1;                        // + 2*half per lane
                         _Float16* const rowp = obase + ((long long)oy * Wo + oxu) * cs;
-                        h2 vp = {0, 0};
-                        if constexpr (PF) {
+                        h2 vp;
+                        {
                             float q[2][4];
 #pragma unroll
                             for (int nb = 0; nb < 2; ++nb) {
@@ -422,11 +416,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvParamsH p)
                         }
 #pragma unroll
                         for (int nb = 0; nb < 2; ++nb) {
-                            _Float16 v;
-                            if constexpr (PF) v = vp[nb];
-                            else v = (MBW == 32)
-                                ? pooled(acc[0][nb][r], acc[0][nb][r + 1], acc[1][nb][r], acc[1][nb][r + 1], nb)
-                                : pooled(acc[mb][nb][r], acc[mb][nb][r + 1], acc[mb][nb][r + RDOWN], acc[mb][nb][r + RDOWN + 1], nb);
+                            const _Float16 v = vp[nb];
                             if constexpr (FULL) {
                                 rowp[nb * 32 + lane_off] = v;
                             } else {
@@ -437,8 +427,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvParamsH p)
                         }
                     }
             };
-            if (p.pool_first) { if (full) store_all(std::true_type{}, std::true_type{}); else store_all(std::false_type{}, std::true_type{}); }
-            else { if (full) store_all(std::true_type{}, std::false_type{}); else store_all(std::false_type{}, std::false_type{}); }
+            if (full) store_all(std::true_type{}); else store_all(std::false_type{});
         } else {
             // non-pooled: lane = pixel, register r = channel (r&3) + 8*(r>>2) + 4*half of the N-block -> 8-byte stores
             const int cs = p.out_cstride;

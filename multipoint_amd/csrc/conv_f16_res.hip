@@ -517,12 +517,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
             }
             const int Ho = p.H >> 1, Wo = p.W >> 1;
             const int cs = p.out_cstride;
-            auto pooled = [&](float a0, float a1, float b0, float b1, int nb) __attribute__((always_inline)) -> _Float16 {
-                const h2 m = __builtin_elementwise_max(act_r2<BNF>(a0, a1, bia[nb], scl[nb], sft[nb]),
-                                                       act_r2<BNF>(b0, b1, bia[nb], scl[nb], sft[nb]));
-                return m[0] > m[1] ? m[0] : m[1];
-            };
-            // p.pool_first: bias add, fp16 rounding and ReLU are non-decreasing and the BatchNorm affine is monotonic in the direction of its
+            // Pool BEFORE the activation: bias add, fp16 rounding and ReLU are non-decreasing and the BatchNorm affine is monotonic in the direction of its
             // scale's sign, so the maximum of a window's four activations IS the activation of the maximum (scale < 0: the minimum) of its
             // four accumulators, bit for bit -- one activation per pooled value instead of four (channels li and 32 + li share a packed pair)
             const f32x2 biap = {bia[0][0], bia[1][0]}, sclp = {scl[0][0], scl[1][0]}, sftp = {sft[0][0], sft[1][0]};
@@ -537,9 +532,8 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
             _Float16* const obase = p.out + ((long long)img * Ho * Wo) * cs + p.out_coff;
             constexpr int RDOWN = (MBW == 32) ? 0 : (MBW == 16) ? 8 : 4;
             constexpr int NMB = (MBW == 32) ? 1 : 2;
-            auto store_all = [&](auto full_tag, auto pf_tag) __attribute__((always_inline)) {
+            auto store_all = [&](auto full_tag) __attribute__((always_inline)) {
                 constexpr bool FULL = decltype(full_tag)::value;
-                constexpr bool PF = decltype(pf_tag)::value;
 #pragma unroll
                 for (int mb = 0; mb < NMB; ++mb)
 #pragma unroll
@@ -549,8 +543,8 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
                         const int oy = (MBW == 32) ? (y0 + 2 * wave) >> 1 : (y0 + (2 * wave + mb) * G::MBH + iu / MBW) >> 1;
                         const int oxu = (x0 + iu % MBW) >> 1;
                         _Float16* const rowp = obase + ((long long)oy * Wo + oxu) * cs;
-                        h2 vp = {0, 0};
-                        if constexpr (PF) {
+                        h2 vp;
+                        {
                             float q[2][4];
 #pragma unroll
                             for (int nb = 0; nb < 2; ++nb) {
@@ -565,11 +559,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
                         }
 #pragma unroll
                         for (int nb = 0; nb < 2; ++nb) {
-                            _Float16 v;
-                            if constexpr (PF) v = vp[nb];
-                            else v = (MBW == 32)
-                                ? pooled(acc[0][nb][r], acc[0][nb][r + 1], acc[1][nb][r], acc[1][nb][r + 1], nb)
-                                : pooled(acc[mb][nb][r], acc[mb][nb][r + 1], acc[mb][nb][r + RDOWN], acc[mb][nb][r + RDOWN + 1], nb);
+                            const _Float16 v = vp[nb];
                             if constexpr (FULL) {
                                 rowp[nb * 32 + lane_off] = v;
                             } else {
@@ -580,8 +570,7 @@ __global__ __launch_bounds__(256 * NG, NG) void conv_f16_res_kernel(const ConvPa
                         }
                     }
             };
-            if (p.pool_first) { if (full) store_all(std::true_type{}, std::true_type{}); else store_all(std::false_type{}, std::true_type{}); }
-            else { if (full) store_all(std::true_type{}, std::false_type{}); else store_all(std::false_type{}, std::false_type{}); }
+            if (full) store_all(std::true_type{}); else store_all(std::false_type{});
         } else {
             // non-pooled: lane = pixel li, register r = channel (r&3) + 8*(r>>2) + 4*half of the N-block.  Per M-block (32 pixels): every lane
             // writes its eight 8-byte channel quads into the wave's staging block [pixel][granule ^ (pixel & 7)][8 halfs], then lane l reads

@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(const ConvParams p)
     // -------- operand pipelines --------------------------------------------------------------
     // B (weights): one linear stream over (chunk, step) straight from L2 into VGPRs, fetched two
     //   steps ahead and NEVER restarted inside a tile (a restart at every chunk boundary stalls
-    //   all co-resident waves at once: measured 95 % -> 88 % of peak in tools/mfma_probe2.hip).
+    //   all co-resident waves at once: measured 95 % -> 88 % of peak in a round-1 probe; docs/HISTORY.md A.5).
     //   The last two prefetches of a tile run past the slice (padding in the packed buffer).
     // A (activations): chunk c+1 is fetched global -> VGPR while chunk c is being multiplied
     //   (one 16-byte load per step, steps S0..), and moved VGPR -> LDS between two barriers.
@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256, 1) void conv_mfma_persist_kernel(const ConvPar
     using G = Geo<TAPS, MBW>;
     constexpr bool RELU = (TAPS == 9);
     constexpr bool SWAP = !POOL;
-    // ONE workgroup per CU (a second MFMA stream per SIMD only gets in the first one's way), which
+    // ONE workgroup per CU (a second MFMA stream per SIMD only gets in the first one's way, see docs/HISTORY.md A.5), which
     // leaves room for a double-buffered LDS image: chunk c+1 is written into the other buffer while chunk c is being
     // multiplied (each staged vector 8 steps after its load was issued), so a chunk boundary is ONE barrier
     static_assert(TAPS == 9, "the persistent kernel handles the 3x3 layers");

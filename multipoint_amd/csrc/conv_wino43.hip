@@ -5,7 +5,7 @@
 // (multipoint/models/MultiPoint.py:143-148).  fp32 throughout; U = G g G^T is computed once on the host (in double, rounded
 // once), V = B^T d B and Y = A^T M A are short fixed-order multiply-add chains whose coefficients are exact binary fractions.
 // Interpolation points {0, +-3/4, +-3/2, inf} instead of the textbook {0, +-1, +-2, inf}: same instruction count, 3.4x smaller
-// maximum error (mp_common.h; measured on trained-like statistics in DESIGN.md section 4).
+// maximum error (mp_common.h; measured on trained-like statistics: docs/HISTORY.md section 4).
 //
 // Structure (the round-2 lessons of conv_wino.hip apply unchanged: every operand through LDS, filled by LDS-DMA; ONE counted
 // wait + barrier per unit; no control flow inside a unit; vector work clustered):
@@ -106,7 +106,7 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 __device__ __forceinline__ unsigned lds_addr(const void* p) { return (unsigned)(size_t)p; }
 
 // Packed fp32 arithmetic as explicit instructions: hipcc scalarises a third of the transform's packed multiply-adds (4 v_fma_f32
-// for 2 v_pk_fma_f32 per pass), and next to an MFMA stream every vector instruction costs matrix-pipe time.
+// for 2 v_pk_fma_f32 per pass), and next to an MFMA stream every vector instruction costs matrix-pipe time (docs/HISTORY.md A.3).
 // The transform coefficients come in scalar register pairs (VOP3P takes no literal on gfx950).
 // Two coefficients share one scalar register pair (low / high half, picked by op_sel: the selected half feeds both lanes), so the
 // six coefficients of the input transform occupy three pairs instead of six (SGPRs are what the fused-first-block instantiation
@@ -172,7 +172,7 @@ __device__ __forceinline__ void bt6(const f32x2 d[6], f32x2 r[6])
 // item k + 2 arrives by 4-byte LDS-DMA during the epilogue of item k.
 // VIN (round 5: layers with MANY output slices -- the 3x3 head convolutions, 512 couts = 8 slices): the input arrives already
 // TRANSFORMED.  Every 64-cout slice of a tile block needs the same V = B^T d B, and the in-kernel transform is what the matrix pipe
-// waits for (Appendix B: 2470 cycles per unit without it, 3300-3650 with); wino43_vprod_kernel below writes V once per (tile block,
+// waits for (docs/HISTORY.md Appendix B: 2470 cycles per unit without it, 3300-3650 with); wino43_vprod_kernel below writes V once per (tile block,
 // unit) into p.vglobal in exactly the LDS order [unit][ch 4][tile 32][pos 36] (18 KiB, the same bits the in-kernel transform
 // produces), and this instantiation DMAs it straight into a ring of FOUR V buffers three units ahead: no raw patches, no
 // scratch, no vector work in the unit body at all.  The 8 slices of a tile block are consecutive items = 8 workgroups of one XCD at
@@ -367,7 +367,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
         bt6(td, tr);                                      // tr[i'] = (B^T d)[i'][column sub6]
         p1_a = p1_base + next_byte; p1_b = p1_base + 4u * PX * 16u + next_byte;
     };
-    // the LDS write path takes two 8-byte stores per MFMA gap for free and saturates beyond: the transform's
+    // the LDS write path takes two 8-byte stores per MFMA gap for free and saturates beyond (docs/HISTORY.md A.3): the transform's
     // stores go out in pairs, one pair per gap
     auto tf_pass1w = [&](int k) __attribute__((always_inline)) {                // rows 2k, 2k+1 of the scratch
         if (MPQX & 1) return;

@@ -63,7 +63,7 @@ __device__ __forceinline__ void dma16(const float* sbase, unsigned voff_bytes, u
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 1\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff_bytes), "s"(sbase), "s"(lds_byte) : "memory");
 }
-// ... with the instruction's immediate offset OFF: it moves the source AND the LDS destination (tools/probes/dma_offset_probe.hip), which
+// ... with the instruction's immediate offset OFF: it moves the source AND the LDS destination (round-4 probe; docs/HISTORY.md 3.3), which
 // is exactly what a block-for-block copy wants -- one scalar source base, one scalar destination base and one lane-offset register
 // serve a wave's nine weight blocks (the unit bodies are short of scalar registers, and a lane-offset register per block would
 // be spilled: the epilogue needs every register, and a reload inside a unit body waits with vmcnt(0) for ALL DMAs in flight).

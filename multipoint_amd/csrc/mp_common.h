@@ -105,7 +105,7 @@ void launch_conv_first(const Conv1Params& p, hipStream_t s);
 // convolution.  The same set scaled by 3/4 -- a = 3/4, b = 3/2 -- keeps every transform coefficient an exact binary
 // fraction (a^2 = 9/16, b^2 = 9/4, a^2 b^2 = 81/64, a^2 + b^2 = 45/16), keeps the even/odd structure (12 multiply-adds per
 // 1-D input transform, as before) and cuts the maximum error 3.4x and the rms error 2x (CPU emulation over a grid of dyadic
-// (a, b): the minimum is broad around a b ~ 1, b / a ~ 2).  Shared by the kernel and the host-side
+// (a, b): the minimum is broad around a b ~ 1, b / a ~ 2; docs/HISTORY.md section 4).  Shared by the kernel and the host-side
 // weight transform U = G g G^T (api.hip).
 #ifndef MP_W43_A
 #define MP_W43_A 0.75
@@ -168,8 +168,6 @@ struct ConvParamsH {
     int nitems;           // work items (tile, slice) of the launch (filled in by the launcher)
     _Float16* dummy;      // >= 1 KiB scratch line that masked-off store lanes write to
     int ncu, xcd_shift;   // machine shape, as in ConvParams
-    int pool_first;       // pooled layers: the epilogue pools the accumulators first (max, or min where the channel's BatchNorm scale is negative) and
-                          // activates once per window -- bit-identical to activating all four (MP_DEBUG=no_pool_first)
     int res_groups;       // conv_f16_res.hip: independent four-wave groups per CU (3; 2 = MP_DEBUG=f16_res_groups=2; the fused-first-block launch always runs 2)
     // conv_f16_res.hip with the first encoder block fused in: the fp32 image [B][H][W] and the Cin = 1 layer's parameters
     // ([9][64] tap-major fp16-representable weights, bias, BN scale / shift); img == nullptr: p.in is read

@@ -136,7 +136,7 @@ class PairPipeline:
             # convolution workgroup needs a whole CU; when batch n's post-processing and batch n+1's first convolution become
             # ready together, the dispatcher must hand the CUs to the convolution first -- otherwise the chain of ~20 small
             # dependent post-processing kernels keeps landing on freed CUs and the convolution's last workgroups start up to
-            # 0.4 ms late (measured: enc.conv1+2 4.35 instead of 4.05 ms).
+            # 0.4 ms late (measured: enc.conv1+2 4.35 instead of 4.05 ms; docs/HISTORY.md section 7).
             if self._post_stream is None or self._post_stream.device != dev:
                 self._post_stream = torch.cuda.Stream(device=dev, priority=int(_lib.debug_switch("post_priority", "0")))
                 self._fwd_stream = torch.cuda.Stream(device=dev, priority=int(_lib.debug_switch("fwd_priority", "-1")))

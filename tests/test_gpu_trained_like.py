@@ -18,7 +18,7 @@ What is asserted, per severity and for F(4x4,3x3) (default), the any-frame-size 
     evaluates the 16 outputs of a tile by 16 different formulas, so it breaks those ties by rounding noise where the direct
     kernel keeps them -- 110 of 2 055 keypoints on the 'wide' case, margin 0, all explained.
 The interpolation points of the F(4x4,3x3) transforms were changed from the textbook {0, +-1, +-2} to {0, +-3/4, +-3/2} on
-this evidence: 3.3x smaller error on every severity (csrc/mp_common.h; the table is in DESIGN.md section 4)."""
+this evidence: 3.3x smaller error on every severity (csrc/mp_common.h; the table is in docs/HISTORY.md section 4)."""
 import json
 
 import pytest

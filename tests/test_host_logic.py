@@ -429,7 +429,7 @@ def test_mp_debug_switch_parser(monkeypatch):
     doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
     import re
     keys = set(re.findall(r'debug_switch\("([a-z0-9_]+)"', api))
-    assert {'no_winograd', 'wino43', 'wino43_gen', 'no_fuse', 'no_fuse43', 'no_head_fuse', 'no_vin', 'no_planar', 'planar', 'no_persist',
+    assert {'no_winograd', 'wino43', 'wino43_gen', 'no_fuse', 'no_fuse43', 'no_head_fuse', 'no_vin', 'no_planar', 'no_persist',
             'persist_min_items', 'splitk_max', 'f16_no_res', 'f16_no_fuse1', 'f16_res_groups', 'ncu', 'nxcd'} <= keys
     for k in keys:
         assert k in doc, 'MP_DEBUG key %s is not documented in INTEGRATION.md' % k

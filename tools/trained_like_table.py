@@ -1,4 +1,4 @@
-"""GPU box: error of every convolution family on trained-like statistics (oracle/trained_like.py), for DESIGN section 4.
+"""GPU box: error of every convolution family on trained-like statistics (oracle/trained_like.py), for docs/HISTORY.md section 4.
     python tools/trained_like_table.py [H W B]"""
 import json
 import os
