@@ -147,9 +147,9 @@ int mp_nms_unresolved(mp_handle* h, int* unresolved, void* stream);
  *   - the cut splits a run of EXACTLY equal scores (some admitted, some not), whatever their number;
  *   - footprint tie guard (also for keep_top_k == 0, the shipped configs' `topk: 0`): at least `min_pairs` (default 16; 0: off)
  *     of the image's NMS decisions were taken between scores within `eps` -- a candidate suppressed by kept neighbours that are
- *     ALL within eps of its own score, i.e. a suppression the noise could have turned around.  Heat maps of independent
- *     scores hold 0-5 such pairs per 480x640 image at eps 6e-5 (measured on the oracle's maps); a plateau of tied scores inside
- *     one footprint holds hundreds.
+ *     ALL within eps of its own score, i.e. a suppression the noise could have turned around -- and they are at least 1 % of the
+ *     image's survivors.  Heat maps of independent scores hold about one such pair per 1000 survivors (0-5 per 480x640 image at
+ *     eps 6e-5, measured on the oracle's maps); a plateau of tied scores inside one footprint holds several per survivor.
  * What the guard does NOT cover (stated residual): fewer than min_each_side / min_pairs near-ties -- a single near-tied pair
  * straddling the cut or inside a footprint flips with the noise; those are the explained fp32 flips the parity tests bound
  * (<= 0.2 % of the keypoints, tests/test_gpu_e2e_parity.py).

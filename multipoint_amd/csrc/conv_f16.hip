@@ -364,6 +364,11 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvParamsH p)
         if constexpr (POOL) {
             // lane = channel (li), register r = pixel (r&3) + 8*(r>>2) + 4*half of the M-block; registers r, r+1
             // are horizontally adjacent pixels -> one packed pair
+            // (the lane's item-invariant epilogue values -- parameter addresses, store offset -- are derived from an OPAQUE copy of the lane id,
+            // so that hipcc recomputes them here instead of carrying them through the MFMA loop: it spilled 7 of them to scratch)
+            int lq = lane;
+            asm volatile("" : "+v"(lq));
+            const int li = lq & 31, half = lq >> 5;
             f32x2 bia[2], scl[2], sft[2];
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
@@ -421,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvParamsH p)
                                 rowp[nb * 32 + lane_off] = v;
                             } else {
                                 const bool ok = (oy < Ho) & (oxu + 2 * half < Wo) & (slice * 64 + nb * 32 + li < p.cout);
-                                _Float16* dst = ok ? rowp + nb * 32 + lane_off : p.dummy + lane;
+                                _Float16* dst = ok ? rowp + nb * 32 + lane_off : p.dummy + lq;
                                 *dst = v;
                             }
                         }

@@ -234,10 +234,12 @@ __global__ __launch_bounds__(BTS) void select_keypoints_kernel(
             // (1) the cut lies inside a plateau of near-tied scores (>= tie_min survivors within tie_eps on EITHER side of it);
             // (2) the cut splits a run of EXACTLY equal scores (tie_base of them, `need` admitted): whatever their number -- lowest index
             //     first is the reference's rule only if the reference's map holds the same tie;
-            // (3) footprint tie guard: >= pairs_min NMS decisions of this image were taken between scores within tie_eps (nms.hip)
+            // (3) footprint tie guard: >= pairs_min NMS decisions of this image were taken between scores within tie_eps (nms.hip), AND they
+            //     are >= 1 % of its survivors -- maps of independent scores hold ~1 such pair per 1000 survivors whatever the frame size
+            //     (0-5 at 480x640), a plateau inside a footprint several per survivor
             int flag = tie_min > 0 && select && ((s_near[0] >= tie_min && s_near[1] >= tie_min) || (need > 0 && tie_base > need));
             if (tie_pairs) {
-                if (pairs_min > 0 && tie_pairs[b] >= pairs_min) flag = 1;
+                if (pairs_min > 0 && tie_pairs[b] >= pairs_min && (long long)tie_pairs[b] * 100 >= nk) flag = 1;
                 tie_pairs[b] = 0;
             }
             if (b < MP_TIE_MAX_IMAGES) tie_state[1 + b] = flag;

@@ -23,4 +23,7 @@ bash tools/pmc_f16.sh "$R/sq_c3" 64 > "$R/sq_c3.txt" 2>&1
 # 240x320 (BASELINE configs[0] frame: the deep layers are 30x40, no multiple of the 4x4 tile): B = 64 throughput and single-pair latency,
 # with the round-3 routing (conv_wino43.hip + direct kernels for the odd frames; the F(2x2,3x3) kernel it used then is gone) and today's
 { for g in 1 0; do echo "== MP_DEBUG=wino43_gen=$g"; MP_DEBUG=wino43_gen=$g python3 tools/bench_layers.py 64 240 320; MP_DEBUG=wino43_gen=$g python3 tools/latency.py; done; } 2>&1 | grep -v amdgpu.ids > "$R/bench_240x320.txt"
+# same-box A/B of this round's fp32 kernel against the previous round's (when its variant library travels with the snapshot:
+# multipoint_amd/libmultipoint_hip_exp_r05.so = today's objects with round 5's conv_wino43.o), alternating child processes
+if [ -f multipoint_amd/libmultipoint_hip_exp_r05.so ]; then python3 tools/ab_layers.py 5 r05 new 2>&1 | grep -v amdgpu.ids > "$R/ab_layers.txt"; fi
 ls -l "$R" | head -40

@@ -123,6 +123,7 @@ for name, out in (('bench_n1', 'bench_n1'), ('bench_c5', 'bench_c5_f16_n1'), ('b
             json.dump(json.loads(lines[-1]), open(os.path.join(dst, '%s_%s.json' % (tag, out)), 'w'), indent=1)
 if os.path.exists(os.path.join(src, 'latency.txt')):
     shutil.copy(os.path.join(src, 'latency.txt'), os.path.join(dst, tag + '_latency.txt'))
-for name, out in (('sq_c5.txt', '_pmc_sq_counters_c5.txt'), ('sq_c3.txt', '_pmc_sq_counters_c3.txt'), ('bench_240x320.txt', '_bench_240x320.txt')):
+for name, out in (('sq_c5.txt', '_pmc_sq_counters_c5.txt'), ('sq_c3.txt', '_pmc_sq_counters_c3.txt'), ('bench_240x320.txt', '_bench_240x320.txt'),
+                  ('ab_layers.txt', '_ab_layers.txt')):
     if os.path.exists(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, tag + out))
