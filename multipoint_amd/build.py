@@ -70,6 +70,36 @@ def check_dma_hazards(asm_path, wait_states=5):
     return n
 
 
+# Convolution kernels must not use scratch memory: a spilled register's reload is a vector-memory load, and the wait in front of its
+# first use (s_waitcnt vmcnt(0)) also waits for every LDS-DMA, staging load and epilogue store in flight (round-5 verdict).  The
+# generated code of these sources is therefore checked per kernel (.private_segment_fixed_size of the code-object metadata) against
+# a cap in bytes per lane; the caps above zero are the known exceptions, so that a REGRESSION fails the build:
+#   conv_wino43b.hip   the any-frame-size F(4x4,3x3) kernel runs ONE wave per SIMD on all 512 registers (288 accumulators); its 13-46
+#                      spilled registers sit in the item hand-over and the epilogue, 1-2 reloads per unit body (docs/HISTORY.md 3.3)
+#   conv_wino43.hip    the fused conv1+conv2 instantiation keeps ONE spilled register (an item-invariant patch coordinate, reloaded once
+#                      per item behind the epilogue); removing it by recomputation measured +0.7 % on the launch
+#   conv_f16.hip       the pooled instantiations for 16- and 8-pixel-wide M-blocks (frames narrower than 32 pixels) keep 1-2; the
+#                      32-wide ones every benchmark shape runs have none since round 6
+SCRATCH_CAPS = {'conv_mfma.hip': 0, 'conv_wino43.hip': 8, 'conv_wino43b.hip': 136, 'conv_split.hip': 0, 'conv_f16.hip': 12,
+                'conv_f16_res.hip': 0, 'conv_first.hip': 0, 'head_tail.hip': 0, 'head_tail_f16.hip': 0}
+
+
+def check_scratch(asm_path, cap):
+    """Fail if a kernel of this source uses more than `cap` bytes of scratch per lane.  Returns {kernel: bytes} of the non-zero ones."""
+    import re
+    text = open(asm_path).read()
+    found = re.findall(r'\.name:\s+(\S+)\n(?:(?!\.name:).*\n)*?\s+\.private_segment_fixed_size:\s+(\d+)', text)
+    if not found:
+        raise RuntimeError('%s: no kernel metadata found -- the scratch check is looking at the wrong file' % asm_path)
+    used = {k: int(v) for k, v in found if int(v) > 0}
+    over = {k: v for k, v in used.items() if v > cap}
+    if over:
+        raise RuntimeError('%s: %d kernel(s) use more scratch than the %d bytes per lane this source is allowed (spilled registers: '
+                           'their reloads wait for every load in flight): %s' % (asm_path, len(over), cap, ', '.join(
+                               '%s %d B' % (k, v) for k, v in sorted(over.items())[:6])))
+    return used
+
+
 def _compile(src):
     """Compile one source.  The object only appears under its final name (which `_stale` looks at) AFTER the LDS-DMA hazard
     check has passed: a failed check must not leave a fresh-looking object behind for the next build to link."""
@@ -77,7 +107,7 @@ def _compile(src):
     obj = os.path.join(OBJ_DIR, stem + '.o')
     tmp_stem = stem + '.tmp%d' % os.getpid()
     tmp = os.path.join(OBJ_DIR, tmp_stem + '.o')
-    extra = ['-save-temps=obj'] if src in DMA_SOURCES else []
+    extra = ['-save-temps=obj'] if (src in DMA_SOURCES or src in SCRATCH_CAPS) else []
     cmd = [HIPCC] + FLAGS + extra + ['-c', os.path.join(CSRC, src), '-o', tmp]
     try:
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -85,6 +115,8 @@ def _compile(src):
             raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, ' '.join(cmd), r.stderr))
         if src in DMA_SOURCES:
             check_dma_hazards(os.path.join(OBJ_DIR, stem + '-hip-amdgcn-amd-amdhsa-gfx950.s'))   # named after the source
+        if src in SCRATCH_CAPS:
+            check_scratch(os.path.join(OBJ_DIR, stem + '-hip-amdgcn-amd-amdhsa-gfx950.s'), SCRATCH_CAPS[src])
         os.replace(tmp, obj)
     finally:
         for f in os.listdir(OBJ_DIR):                      # the temporary object and the -save-temps leftovers (19 MB)

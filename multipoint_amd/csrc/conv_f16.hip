@@ -295,7 +295,11 @@ __global__ __launch_bounds__(256, 2) void conv_f16_kernel(const ConvParamsH p)
                     nxt = decode(item_next);
                     src = offsets(nxt);
                     nxt_pad = !goff_rel;
-                    wnext = reinterpret_cast<const h8*>(p.wpack) + ((long long)nxt.slice * nchunks) * (G::STEPS * 128) + lane;
+                    // (from an opaque copy of the lane id: `p.wpack + lane` is item-invariant, and hipcc kept it as a 64-bit register pair
+                    // through the MFMA loop -- spilled, and its reload here was an s_waitcnt vmcnt(0) on the loads in flight)
+                    int lw = lane;
+                    asm volatile("" : "+v"(lw));
+                    wnext = reinterpret_cast<const h8*>(p.wpack) + ((long long)nxt.slice * nchunks) * (G::STEPS * 128) + lw;
                 }
                 in_next = src;                                  // !has_next: dummy re-read of the current tile
             }

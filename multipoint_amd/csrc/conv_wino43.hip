@@ -464,6 +464,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     // image patch of item w -> patch buffer par: 720 pixels, one 4-byte DMA granule each (waves 0..3 issue two blocks)
     auto patch_dma = [&](const Where& w, int par) __attribute__((always_inline)) {
         const float* const im = p.img + (long long)w.img * p.H * p.W;
+        // (the patch coordinates of a thread are item-invariant and hipcc carries them through the unit loop -- ONE of them in scratch, reloaded
+        // here once per item.  Recomputing them from an opaque thread id removes the spill and measured +0.7 % on the launch (round 6, 8
+        // alternating rounds): the spill stays, multipoint_amd/build.py caps this source at its 8 bytes.)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (wave * 64 + 512 * j >= IH1 * IW1) continue;       // (wave-uniform)

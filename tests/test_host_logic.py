@@ -345,6 +345,37 @@ def test_build_checks_dma_hazards(tmp_path):
     assert b.check_dma_hazards(str(lab)) == 1
 
 
+def test_build_refuses_scratch_in_convolution_kernels(tmp_path, monkeypatch):
+    """multipoint_amd/build.py reads every convolution kernel's scratch bytes from the generated code-object metadata and fails the
+    build above the source's cap (0 for the kernels the benchmark shapes run; round-5 verdict): a spilled register's reload waits for
+    every load in flight."""
+    from multipoint_amd import build as b
+    meta = ('amdhsa.kernels:\n  - .args: []\n    .name:           _Zk1\n    .private_segment_fixed_size: 0\n    .vgpr_count: 200\n'
+            '  - .args: []\n    .name:           _Zk2\n    .private_segment_fixed_size: %d\n    .vgpr_count: 256\n')
+    f = tmp_path / 'k.s'
+    f.write_text(meta % 0)
+    assert b.check_scratch(str(f), 0) == {}
+    f.write_text(meta % 24)
+    assert b.check_scratch(str(f), 64) == {'_Zk2': 24}
+    with pytest.raises(RuntimeError, match='_Zk2 24 B'):
+        b.check_scratch(str(f), 0)
+    f.write_text('\ts_nop 0\n')
+    with pytest.raises(RuntimeError, match='no kernel metadata'):
+        b.check_scratch(str(f), 0)
+    # the kernels of every headline / c5 launch are capped at zero
+    for src in ('conv_f16_res.hip', 'conv_mfma.hip', 'head_tail.hip', 'head_tail_f16.hip'):
+        assert b.SCRATCH_CAPS[src] == 0
+    assert b.SCRATCH_CAPS['conv_wino43.hip'] <= 8                     # one register of the fused launch, reloaded once per item
+    # and a compile that exceeds its cap leaves no object behind
+    monkeypatch.setattr(b, 'OBJ_DIR', str(tmp_path)); monkeypatch.setattr(b, 'CSRC', str(tmp_path))
+    monkeypatch.setattr(b, 'DMA_SOURCES', ()); monkeypatch.setattr(b, 'SCRATCH_CAPS', {'s.hip': 0})
+    (tmp_path / 's.hip').write_text('#include <hip/hip_runtime.h>\n__global__ void s(float* p, int n) { float a[64]; for (int i = 0; i < 64; ++i) '
+                                    'a[i] = p[i * n]; float t = 0; for (int i = 0; i < 64; ++i) t += a[(i * n) & 63]; p[threadIdx.x] = t; }\n')
+    with pytest.raises(RuntimeError, match='more scratch'):
+        b._compile('s.hip')
+    assert [x for x in os.listdir(tmp_path) if x not in ('s.hip', 'k.s')] == []
+
+
 def test_failed_hazard_check_leaves_no_object(tmp_path, monkeypatch):
     """A source whose generated code fails the LDS-DMA hazard check must not leave `<stem>.o` behind: the next build would
     see it as fresh, skip compile + check and link the hazardous object (round-2 advisor finding)."""
