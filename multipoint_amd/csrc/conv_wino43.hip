@@ -283,7 +283,13 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     // an LDS-DMA costs ~50 cycles of its SIMD's issue next to the MFMA stream, the extra raw block ~170.
     int u_first, u_cnt;
     if constexpr (F1 && !(MPQX & 33554432)) {
+#if defined(MP_DMA_BAL) && MP_DMA_BAL == 0          // (developer A/B) no dummies, not balanced: 5 on waves 0-3, 4 on waves 4-7
+        constexpr int cnt_[8] = {5, 5, 5, 5, 4, 4, 4, 4}, first_[8] = {0, 5, 10, 15, 20, 24, 28, 32};
+#elif defined(MP_DMA_BAL) && MP_DMA_BAL == 3        // (developer A/B) SIMDs 0, 1: 8, SIMDs 2, 3: 10
+        constexpr int cnt_[8] = {4, 4, 5, 5, 4, 4, 5, 5}, first_[8] = {0, 4, 8, 13, 18, 22, 26, 31};
+#else
         constexpr int cnt_[8] = {3, 3, 6, 6, 4, 4, 5, 5}, first_[8] = {0, 3, 14, 20, 6, 10, 26, 31};
+#endif
         u_cnt = 3; u_first = 0;
 #pragma unroll
         for (int w = 0; w < 8; ++w) { u_cnt = wave == w ? cnt_[w] : u_cnt; u_first = wave == w ? first_[w] : u_first; }
@@ -657,14 +663,27 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
         const float* unext = u_ptr(next_slice);
         // schedule of the input transform inside a unit (group g, slot e behind the e-th MFMA of the group)
         auto tf_at = [&](const int g, const int e, const int vb) __attribute__((always_inline)) {
-            if (g == 0 && e == 2) tf_pass1();
-            else if (g == 2 && e == 2) { tf_pass1b(F1 ? (unsigned)vb * (RB4 * 4u) : 3u * RB4 * 4u - rd_byte - rt_byte); tf_pass1w(0); }   // unit n+1 transforms raw(n+2): ring of 3 (F1: of 2, buffer n & 1)
-            else if (g == 2 && e == 3) tf_pass1w(1);
-            else if (g == 3 && e == 1) tf_pass1w(2);
-            else if (g == 3 && e == 2) tf_pass2();
-            else if (g == 5 && e == 2) { tf_pass2b(); tf_pass2w(vb ^ 1, 0); }
-            else if (g == 5 && e == 3) tf_pass2w(vb ^ 1, 1);
-            else if (g == 6 && e == 1) tf_pass2w(vb ^ 1, 2);
+#ifndef MP_TF_SCHED
+#define MP_TF_SCHED -1
+#endif
+            // slots (group, MFMA of the group) of: raw reads | column pass + hand-over stores 0 | 1 | 2 | scratch reads | row pass + V stores 0 | 1 | 2.
+            // Row 0: the schedule of rounds 3-5, kept for the fused launch (its production steps fill the neighbouring slots) and the
+            // 32 x 16-pixel items.  Row 1 (round 6): the row pass one slot earlier and its stores one per group instead of back to back --
+            // conv4 -2.3 %, conv6 -1.6 %, conv3 -0.8 % on one box (eight schedules tried: profiles/r06_transform_schedules.txt); the
+            // same schedule costs conv7 / conv8 1 % and leaves the fused launch where it is.
+            constexpr int S[2][8][2] = {
+                {{0, 2}, {2, 2}, {2, 3}, {3, 1}, {3, 2}, {5, 2}, {5, 3}, {6, 1}},
+                {{0, 2}, {2, 2}, {2, 3}, {3, 1}, {3, 2}, {4, 3}, {5, 1}, {6, 1}}};
+            constexpr int TFS = MP_TF_SCHED >= 0 ? MP_TF_SCHED : ((TC4 == 8 && !F1) ? 1 : 0);
+            auto at = [&](const int k) { return g == S[TFS][k][0] && e == S[TFS][k][1]; };
+            if (at(0)) tf_pass1();
+            if (at(1)) { tf_pass1b(F1 ? (unsigned)vb * (RB4 * 4u) : 3u * RB4 * 4u - rd_byte - rt_byte); tf_pass1w(0); }   // unit n+1 transforms raw(n+2): ring of 3 (F1: of 2, buffer n & 1)
+            if (at(2)) tf_pass1w(1);
+            if (at(3)) tf_pass1w(2);
+            if (at(4)) tf_pass2();
+            if (at(5)) { tf_pass2b(); tf_pass2w(vb ^ 1, 0); }
+            if (at(6)) tf_pass2w(vb ^ 1, 1);
+            if (at(7)) tf_pass2w(vb ^ 1, 2);
         };
         // F1: the production of raw(n+2) (prod_step) in the slots the transform leaves free, one small MFMA per slot; the second
         // block of waves 0, 1 (granules 512..611) as one piece in front of them
