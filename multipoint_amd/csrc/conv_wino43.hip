@@ -689,6 +689,8 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
         // block of waves 0, 1 (granules 512..611) as one piece in front of them
         auto prod_at = [&](const int g, const int e, const int vb) __attribute__((always_inline)) {
             const unsigned wbuf = (unsigned)vb * (RB4 * 4u);
+            // (round 6: the second block at group 1 / 3 / 5 instead of 0: +-0 / +1.7 % / +1.6 %; one production step per group or all of them
+            // early: +-0 / +0.9 % -- profiles/r06_transform_schedules.txt)
             constexpr int slot_g[11] = {0, 0, 1, 1, 1, 2, 3, 4, 4, 4, 5};
             constexpr int slot_e[11] = {1, 3, 1, 2, 3, 1, 3, 1, 2, 3, 1};
             if (MPQX & 4194304) return;                            // (timing only: no production at all)
