@@ -104,6 +104,16 @@ class PairPipeline:
         else:
             raise ValueError('unknown matching method')
 
+    def set_tie_guard(self, device=None, eps=6e-5, min_each_side=4, min_pairs=16):
+        """Sensitivity of the tie guards run_converged / check_converged read (include/multipoint_hip.h): `eps` = the score window
+        (default: the default convolution algorithm's measured prob noise), `min_each_side` = survivors within eps of the k-th score
+        needed on EACH side of the top-k cut (0: that guard off; the split of an exact tie is flagged whatever the number),
+        `min_pairs` = NMS decisions between near-tied scores needed (and >= 1 % of the image's survivors; 0: the footprint guard off).
+        Lower thresholds redo more images with the tie-exact algorithm; what stays below them is decided by fp32 rounding.  The
+        setting belongs to the device's shared post-processing handle, i.e. to every pipeline on that device."""
+        U.topk_tie_guard(device, eps, min_each_side)
+        U.nms_tie_guard(device, min_pairs)
+
     @staticmethod
     def interleave(optical, thermal):
         """(P,1,H,W) x 2 -> (2P,1,H,W) with image 2p = optical[p], 2p+1 = thermal[p]."""

@@ -629,6 +629,20 @@ def test_run_converged_reads_the_tie_guards_on_the_converged_pass(oracle, U, top
         assert int(res.kp_count[b]) == len(okp) and np.array_equal(res.kp_yx[b, :len(okp)].cpu().numpy().astype(np.int64), okp)
     pipe.check_converged()
     assert pipe.tie_flagged == 0                               # nothing left over from the passes that were redone
+    # the sensitivity is the caller's (PairPipeline.set_tie_guard): with both thresholds out of reach nothing is flagged -- the noisy
+    # plateau holds near-ties, no exact ones for the cut to split -- and the defaults come back afterwards
+    try:
+        pipe.set_tie_guard(None, min_each_side=100000, min_pairs=10 ** 9)
+        loose = PairPipeline(_MapNet(auto, twin, desc), pred, capacity=64 if topk == 0 else None, nms_rounds=1)
+        loose.run_converged(img)
+        # (top-k 40: among the plateau's ~1800 survivors in a window of 1300 float steps some are EXACTLY equal, and a cut that splits
+        # such a pair is flagged whatever the thresholds)
+        assert loose.tie_redone == 0 or topk > 0
+    finally:
+        pipe.set_tie_guard(None)
+    again = PairPipeline(_MapNet(auto, twin, desc), pred, capacity=64 if topk == 0 else None, nms_rounds=1)
+    again.run_converged(img)
+    assert again.tie_redone == 1
     plain = PairPipeline(_MapNet(auto, None, desc), pred, capacity=64 if topk == 0 else None, nms_rounds=1, tie_robust=False)
     res = plain.run_converged(img)                             # without the guard: the noisy map's own lists
     want = oracle.box_nms(auto.cpu().numpy(), 4, 0.015, keep_top_k=topk)
