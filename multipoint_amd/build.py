@@ -76,11 +76,9 @@ def check_dma_hazards(asm_path, wait_states=5):
 # a cap in bytes per lane; the caps above zero are the known exceptions, so that a REGRESSION fails the build:
 #   conv_wino43b.hip   the any-frame-size F(4x4,3x3) kernel runs ONE wave per SIMD on all 512 registers (288 accumulators); its 13-46
 #                      spilled registers sit in the item hand-over and the epilogue, 1-2 reloads per unit body (docs/HISTORY.md 3.3)
-#   conv_wino43.hip    the fused conv1+conv2 instantiation keeps ONE spilled register (an item-invariant patch coordinate, reloaded once
-#                      per item behind the epilogue); removing it by recomputation measured +0.7 % on the launch
 #   conv_f16.hip       the pooled instantiations for 16- and 8-pixel-wide M-blocks (frames narrower than 32 pixels) keep 1-2; the
 #                      32-wide ones every benchmark shape runs have none since round 6
-SCRATCH_CAPS = {'conv_mfma.hip': 0, 'conv_wino43.hip': 8, 'conv_wino43b.hip': 136, 'conv_split.hip': 0, 'conv_f16.hip': 12,
+SCRATCH_CAPS = {'conv_mfma.hip': 0, 'conv_wino43.hip': 0, 'conv_wino43b.hip': 136, 'conv_split.hip': 0, 'conv_f16.hip': 12,
                 'conv_f16_res.hip': 0, 'conv_first.hip': 0, 'head_tail.hip': 0, 'head_tail_f16.hip': 0}
 
 

@@ -24,6 +24,10 @@ struct ConvLayer {            // one MFMA conv launch
     const char* name = "";
     float *wpack = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
     float* u43pack = nullptr;     // 3x3 layers: F(4x4,3x3) weights (conv_wino43.hip)
+    // enc.conv2 inside the fused conv1+conv2 launch, conv -> ReLU -> BN models: the first block's BatchNorm folded into this layer --
+    // U from g2[o][c][tap] * s1[c] (in double, rounded once) and bias + sum_c t1[c] sum_tap g2[o][c][tap] (exact: with reflection
+    // padding every tap of every output lands on a real pixel, so the shift's contribution is one constant per output channel)
+    float *u43pack_f1 = nullptr, *bias_f1 = nullptr;
     _Float16* wpack_h = nullptr;  // mixed_precision: fp16 fragments (conv_f16.hip) and the fp16-rounded bias
     float* bias_h = nullptr;
     int cin = 0, cout = 0, taps = 9, nslices = 0;
@@ -34,6 +38,9 @@ struct FirstLayer {
     int channels = 64;            // output channels incl. zero padding (64 or 32)
     float *w = nullptr, *bias = nullptr, *scale = nullptr, *shift = nullptr;
     float *w_h = nullptr, *bias_h = nullptr;      // mixed_precision: fp16-representable copies
+    // the fused F(4x4,3x3) conv1+conv2 launch produces relu(conv1) only: bn_first models get their BatchNorm folded into the block's own
+    // weights (w s, b s + t), the others into conv2 (ConvLayer::u43pack_f1); without BatchNorm these are the plain weights
+    float *w_f1 = nullptr, *bias_f1 = nullptr;
 };
 
 struct Encoder {
@@ -273,7 +280,7 @@ void pack_conv_weights(const std::vector<const float*>& srcs, const std::vector<
 // row [0, 0, 1]; evaluated in double and rounded to fp32 ONCE.  Layout = the LDS image of a unit of 4 input channels:
 //   [slice64][unit = cin/4][ch(4)][cout(64)][pos(36)]
 void pack_wino43_weights(const std::vector<const float*>& srcs, const std::vector<int>& couts, int cin, int cin_real,
-                         std::vector<float>& out)
+                         std::vector<float>& out, const float* in_scale = nullptr)
 {
     const double pts[5] = {0.0, MP_W43_A, -MP_W43_A, MP_W43_B, -MP_W43_B};
     double G[6][3];
@@ -298,9 +305,10 @@ void pack_wino43_weights(const std::vector<const float*>& srcs, const std::vecto
                     size_t t = 0;
                     while (co >= couts[t]) { co -= couts[t]; ++t; }
                     const float* g = srcs[t] + ((size_t)co * cin_real + ci) * 9;
+                    const double sc = in_scale ? (double)in_scale[ci] : 1.0;      // (a producer's BatchNorm scale folded into this layer)
                     double tmp[6][3];
                     for (int a = 0; a < 6; ++a)
-                        for (int j = 0; j < 3; ++j) tmp[a][j] = G[a][0] * g[j] + G[a][1] * g[3 + j] + G[a][2] * g[6 + j];
+                        for (int j = 0; j < 3; ++j) tmp[a][j] = sc * (G[a][0] * g[j] + G[a][1] * g[3 + j] + G[a][2] * g[6 + j]);
                     float* o = out.data() + ((((size_t)s * nunits + u) * 4 + ch) * 64 + co64) * 36;
                     for (int a = 0; a < 6; ++a)
                         for (int b = 0; b < 6; ++b) o[6 * a + b] = (float)(tmp[a][0] * G[b][0] + tmp[a][1] * G[b][1] + tmp[a][2] * G[b][2]);
@@ -460,6 +468,43 @@ int build_encoder(mp_handle* h, TensorMap& tm, Encoder& E, const std::string& pr
                             pool[i], true, chan[i], true);
         if (rc) return rc;
     }
+    // The fused F(4x4,3x3) conv1+conv2 launch (conv_wino43.hip F1: channel_version 0, double convolution, reflection padding) produces
+    // relu(conv1) and nothing else per patch pixel: the first block's BatchNorm is folded at load time -- into the block's own weights
+    // for bn_first models (conv -> BN -> ReLU), into conv2's Winograd-domain weights and bias otherwise (conv -> ReLU -> BN -> pad ->
+    // conv2).  Exact in real arithmetic; in fp32 one rounding per activation fewer than the un-fused launches (equal within the tolerance
+    // class of any two kernel variants: tests/test_gpu_parity.py::test_first_block_inside_f43_equals_standalone).
+    if (dbl && h->cfg.channel_version == 0 && h->cfg.reflection_pad && E.conv[0].u43pack && E.conv[0].cin == 64 && chan[1] == 64) {
+        const std::string ck = conv_key(0), bk = bn_key(0), ck2 = conv_key(1);
+        const float* w1 = tm.get(ck + ".weight", 64 * 9, err); if (!w1) return fail(h, MP_EINVAL, err);
+        const float* b1 = tm.get(ck + ".bias", 64, err); if (!b1) return fail(h, MP_EINVAL, err);
+        const float* w2 = tm.get(ck2 + ".weight", 64LL * 64 * 9, err); if (!w2) return fail(h, MP_EINVAL, err);
+        const float* b2 = tm.get(ck2 + ".bias", 64, err); if (!b2) return fail(h, MP_EINVAL, err);
+        std::vector<float> s1(64, 1.f), t1(64, 0.f);
+        if (!bk.empty() && !bn_terms(tm, bk, 64, 64, s1, t1, err)) return fail(h, MP_EINVAL, err);
+        std::vector<float> wf(9 * 64), bf(64), b2f(64);
+        const bool own = h->cfg.bn_first != 0;                      // fold into the block itself
+        for (int co = 0; co < 64; ++co) {
+            bf[co] = own ? (float)((double)b1[co] * s1[co] + t1[co]) : b1[co];
+            for (int k = 0; k < 9; ++k) wf[k * 64 + co] = own ? (float)((double)w1[co * 9 + k] * s1[co]) : w1[co * 9 + k];
+        }
+        for (int o = 0; o < 64; ++o) {
+            double acc = b2[o];
+            if (!own)
+                for (int c = 0; c < 64; ++c) {
+                    double g = 0.0;
+                    for (int k = 0; k < 9; ++k) g += w2[((size_t)o * 64 + c) * 9 + k];
+                    acc += g * t1[c];
+                }
+            b2f[o] = (float)acc;
+        }
+        std::vector<float> u4;
+        pack_wino43_weights({w2}, {64}, 64, 64, u4, own ? nullptr : s1.data());
+        int rc;
+        if ((rc = upload(h, wf, &E.first.w_f1))) return rc;
+        if ((rc = upload(h, bf, &E.first.bias_f1))) return rc;
+        if ((rc = upload(h, u4, &E.conv[0].u43pack_f1))) return rc;
+        if ((rc = upload(h, b2f, &E.conv[0].bias_f1))) return rc;
+    }
     return MP_OK;
 }
 
@@ -525,7 +570,7 @@ int wino43_kind(const mp_handle* h, const ConvLayer& L, int H, int W, bool fuse,
     q.in_cstride = in_cstride; q.in_coff = in_coff; q.out_cstride = out_cstride; q.out_coff = out_coff;
     const bool g1 = h->wino43_gen != 2 && conv_wino43_supports(q), g2 = h->wino43_gen != 1 && conv_wino43b_supports(q);
     // fuse: the first block is evaluated by the layer's kernel -- only by the pooled 64 -> 64 layer, 64 real channels
-    if (fuse) return h->fuse43 && g1 && L.pool && L.cin == 64 && L.cout == 64 && h->cfg.channel_version == 0 ? 1 : 0;
+    if (fuse) return h->fuse43 && g1 && L.pool && L.cin == 64 && L.cout == 64 && h->cfg.channel_version == 0 && L.u43pack_f1 ? 1 : 0;
     return g1 ? 1 : g2 ? 2 : 0;
 }
 bool uses_wino43(const mp_handle* h, const ConvLayer& L, int H, int W, bool fuse, int in_cstride = 0, int in_coff = 0,
@@ -565,6 +610,9 @@ int run_conv(mp_handle* h, const ConvLayer& L, const float* in, int in_cstride, 
     int big;
     if (f43) {
         p.wpack = L.u43pack; p.in_planar = in_planar; p.out_planar = out_planar;
+        if (fuse) {       // the fused launch: the first block's BatchNorm is folded away (build_encoder)
+            p.wpack = L.u43pack_f1; p.bias = L.bias_f1; p.w1 = fuse->w_f1; p.b1 = fuse->bias_f1; p.s1 = nullptr; p.t1 = nullptr;
+        }
         if (!fuse && h->fwd_batch <= 2 && h->splitk_max > 1) {
             // single-pair latency (the reference's shipped batchsize: 1): a launch with fewer items than half the CUs (conv7 /
             // conv8 of one 480x640 pair: 40 items of 32 units on 256 CUs) cuts the input channels into 2, 4 or 8 ranges --

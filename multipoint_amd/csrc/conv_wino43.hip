@@ -431,14 +431,14 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
 
     // ---- F1: the first encoder block, produced per unit into the raw ring ----
     // LDS: the raw ring needs only TWO buffers here (nothing is in flight from memory); the third buffer's 10 KiB hold two image
-    // patches (item k's and item k+1's: 20 x 36 fp32, rows / columns already reflected) and bias | BN scale | BN shift per unit;
+    // patches (item k's and item k+1's: 20 x 36 fp32, rows / columns already reflected) and the block's bias per unit (its BatchNorm is folded away at load time);
     // w1s holds the weights as [unit][tap][channel of the unit].
     constexpr int IW1 = PX + 2, IH1 = PY + 2;                 // image patch: the receptive field of the 18 x 34 raw patch
     constexpr int IPB = 768;                                  // floats per patch buffer (IH1 * IW1 = 720, rounded up to whole 64-lane DMA blocks)
-    static_assert(!F1 || (IH1 * IW1 <= IPB && 2 * IPB + 16 * 12 + 16 * 4 * 12 <= RB4), "F1: patches + parameters + weights must fit the third raw buffer");
+    static_assert(!F1 || (IH1 * IW1 <= IPB && 2 * IPB + 16 * 4 + 16 * 4 * 12 <= RB4), "F1: patches + parameters + weights must fit the third raw buffer");
     const unsigned ip_lds = raw_lds + 2u * RB4 * 4u;          // ipatch[2][IPB]
-    const unsigned bst_lds = ip_lds + 2u * IPB * 4u;          // bst[16][bias4 | scale4 | shift4]
-    const unsigned w1_lds = bst_lds + 16u * 12u * 4u;         // w1u[16 units][4 channels][12: taps 0..8, 3 unused]
+    const unsigned bst_lds = ip_lds + 2u * IPB * 4u;          // bst[16][bias4] (the block's BatchNorm is folded away at load time)
+    const unsigned w1_lds = bst_lds + 16u * 4u * 4u;         // w1u[16 units][4 channels][12: taps 0..8, 3 unused]
     typedef const __attribute__((address_space(3))) float* lds_f32_ptr;
     typedef const __attribute__((address_space(3))) f32x4* lds_f32x4_ptr;
     typedef __attribute__((address_space(3))) f32x4* lds_f32x4_wptr;
@@ -470,9 +470,6 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     // image patch of item w -> patch buffer par: 720 pixels, one 4-byte DMA granule each (waves 0..3 issue two blocks)
     auto patch_dma = [&](const Where& w, int par) __attribute__((always_inline)) {
         const float* const im = p.img + (long long)w.img * p.H * p.W;
-        // (the patch coordinates of a thread are item-invariant and hipcc carries them through the unit loop -- ONE of them in scratch, reloaded
-        // here once per item.  Recomputing them from an opaque thread id removes the spill and measured +0.7 % on the launch (round 6, 8
-        // alternating rounds): the spill stays, multipoint_amd/build.py caps this source at its 8 bytes.)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             if (wave * 64 + 512 * j >= IH1 * IW1) continue;       // (wave-uniform)
@@ -485,7 +482,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     // the cursor: unit pc_unit of item pc_item is what the next produce() makes; LDS byte addresses of its weights / parameters
     int pc_unit = 0, pc_next_item = item + stride;
     unsigned pc_wv = w1_lds + (unsigned)(lane & 3) * 48u;     // w1u[unit][lane & 3][0..11]
-    unsigned pc_bv = bst_lds;                                 // bst[unit * 12]
+    unsigned pc_bv = bst_lds;                                 // bst[unit * 4]
     // 64 pixels x 4 channels of the cursor's unit -> raw buffer at byte wbuf: nine rank-1 MFMAs on the lane's own pixel.  In steps, so
     // that the unit body can thread them through the gaps of its own MFMA stream (the nine small MFMAs depend on each other):
     //   step 0: issue the reads (9 taps of the pixel, 9 weights, the bias as the accumulator's initial value)
@@ -494,7 +491,7 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     // The nine tap values of a pixel are the same for all 16 units of an item: block 0's (every wave) stay in registers (px_, loaded
     // when the cursor enters an item); the second block of waves 0, 1 gathers them per unit.
     float px_[9];
-    f32x4 pw_[3], pd_, psc_, psh_;
+    f32x4 pw_[3], pd_;
     auto gather_x = [&](float (&x)[9], const int j) __attribute__((always_inline)) {
         const lds_f32_ptr xp = reinterpret_cast<lds_f32_ptr>(pg_x[j]);
 #pragma unroll
@@ -509,17 +506,11 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
         } else if (k <= 9) {
             if (MPQX & 8388608) asm volatile("" :: "v"(pw_[(k - 1) >> 2][(k - 1) & 3]), "v"(x[k - 1]));       // (timing only: no small MFMAs)
             else pd_ = __builtin_amdgcn_mfma_f32_4x4x1f32(pw_[(k - 1) >> 2][(k - 1) & 3], x[k - 1], pd_, 0, 0, 0);
-            if (k == 8) { psc_ = bp[1]; psh_ = bp[2]; }
         } else {
-            f32x4 v;
-#pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2) {
-                f32x2 a = f32x2{pd_[2 * h2], pd_[2 * h2 + 1]};
-                const f32x2 s2 = {psc_[2 * h2], psc_[2 * h2 + 1]}, t2 = {psh_[2 * h2], psh_[2 * h2 + 1]};
-                if (BNF) { a = __builtin_elementwise_fma(a, s2, t2); a = f32x2{relu_q(a[0]), relu_q(a[1])}; }
-                else { a = f32x2{relu_q(a[0]), relu_q(a[1])}; a = __builtin_elementwise_fma(a, s2, t2); }
-                v[2 * h2] = a[0]; v[2 * h2 + 1] = a[1];
-            }
+            // ReLU only: the block's BatchNorm was folded at load time -- into p.w1 / p.b1 for conv -> BN -> ReLU models, into this
+            // layer's U and bias otherwise (api.hip build_encoder) -- which takes two packed multiply-adds and two LDS reads per
+            // 64 pixels and unit out of the unit body
+            const f32x4 v = {relu_q(pd_[0]), relu_q(pd_[1]), relu_q(pd_[2]), relu_q(pd_[3])};
             *reinterpret_cast<lds_f32x4_wptr>(raw_lds + wbuf + pg_w[j]) = v;
         }
     };
@@ -535,10 +526,10 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
         }
     };
     auto prod_advance = [&]() __attribute__((always_inline)) {
-        pc_wv += 4u * 12u * 4u; pc_bv += 12u * 4u;
+        pc_wv += 4u * 12u * 4u; pc_bv += 4u * 4u;
         if (++pc_unit == NC) {
             pc_unit = 0;
-            pc_wv -= (unsigned)NC * 4u * 12u * 4u; pc_bv -= (unsigned)NC * 12u * 4u;
+            pc_wv -= (unsigned)NC * 4u * 12u * 4u; pc_bv -= (unsigned)NC * 4u * 4u;
             if (pc_next_item < item_end) {
                 const Where w = decode(pc_next_item);
                 pc_par ^= 1;
@@ -582,12 +573,9 @@ __global__ __launch_bounds__(512, 2) void conv_wino43_kernel(const ConvParams p)
     if constexpr (F1) {
         for (int f = tid; f < 16 * 4 * 12; f += 512) {            // w1u[unit][channel of the unit][tap] <- p.w1 [tap][64]
             const int ch = f / 12, t = f - ch * 12;
-            (raw + 2 * RB4 + 2 * IPB + 16 * 12)[f] = t < 9 ? p.w1[t * 64 + ch] : 0.f;
+            (raw + 2 * RB4 + 2 * IPB + 16 * 4)[f] = t < 9 ? p.w1[t * 64 + ch] : 0.f;
         }
-        if (tid < 16 * 12) {
-            const int u = tid / 12, r = tid - u * 12, k = r >> 2, i = r & 3;
-            (raw + 2 * RB4 + 2 * IPB)[tid] = (k == 0 ? p.b1 : k == 1 ? p.s1 : p.t1)[4 * u + i];
-        }
+        if (tid < 64) (raw + 2 * RB4 + 2 * IPB)[tid] = p.b1[tid];       // bst[unit][4]: the bias = the accumulators' initial value
         patch_dma(cur, 0);
         if (item + stride < item_end) patch_dma(decode(item + stride), 1);
         prod_offsets(cur);

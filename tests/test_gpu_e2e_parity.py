@@ -82,10 +82,10 @@ def test_e2e_keypoint_flip_accounting(oracle, monkeypatch, variant, P, root_tol)
         assert summary['keypoints_differing'] <= 0.03 * summary['keypoints_total'], summary
         assert desc_err <= 4e-3
     else:
-        assert summary['max_prob_err'] <= 1e-4
+        assert summary['max_prob_err'] <= 3e-5                    # (observed 1.1e-5; north_star bounds the descriptors only)
         assert summary['max_root_margin'] <= root_tol, summary
         assert summary['keypoints_differing'] <= 0.002 * summary['keypoints_total'], summary
-        assert desc_err <= 1e-4
+        assert desc_err <= 1e-5                                   # north_star: 1e-4; observed 1.2e-6
     print('[e2e %s] desc max abs err on the intersection: %.3e' % (variant, desc_err))
 
 

@@ -2,9 +2,9 @@
 reference interface, against the oracle on the same seeded inputs, against the committed golden
 vectors, and -- at BASELINE.json's full size -- through size-independent properties.
 
-Tolerances (north_star): descriptors within 1e-4 (fp32); prob within 1e-4 abs (softmax of fp32 logits
-whose summation order differs from ATen's: observed <= 2e-5); keypoint indices BIT-EXACT given the same
-probability map, tie-break (score desc, row-major index asc)."""
+Tolerances: north_star asks for descriptors within 1e-4 (fp32); asserted here: descriptors within 1e-5, prob within 3e-5 abs
+(softmax of fp32 logits whose summation order differs from ATen's: observed <= 2e-5 / 4e-6); keypoint indices BIT-EXACT given the
+same probability map, tie-break (score desc, row-major index asc)."""
 import os
 
 import numpy as np
@@ -14,8 +14,12 @@ import torch
 pytestmark = pytest.mark.gpu
 DEV = 'cuda:0'
 
-DESC_TOL = 1e-4
-PROB_TOL = 1e-4
+# north_star's bar: descriptors within 1e-4 of the CPU reference (fp32); it gives no number for the heat map.  Round 6 holds the
+# benign-weights cases of this file to 10x / 3x tighter bars -- desc 1e-5, prob 3e-5 -- after measuring that every forward test passes at
+# 4e-6 / 2e-5 (MP_TEST_DESC_TOL / MP_TEST_PROB_TOL override them for such probes); trained-like statistics have their own test and
+# bound (tests/test_gpu_trained_like.py), the fp16 path its own (tests/test_gpu_f16.py).
+DESC_TOL = float(os.environ.get('MP_TEST_DESC_TOL', 1e-5))
+PROB_TOL = float(os.environ.get('MP_TEST_PROB_TOL', 3e-5))
 
 
 @pytest.fixture(scope='module')
