@@ -12,6 +12,7 @@ import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 DEV = 'cuda:0'
 
 # north_star's bar: descriptors within 1e-4 of the CPU reference (fp32); it gives no number for the heat map.  Round 6 holds the
@@ -389,6 +390,21 @@ def test_superpoint_magicleap_model(oracle, golden_dir):
     assert (out['desc'].cpu() - ref['desc']).abs().max().item() <= DESC_TOL
     with pytest.raises(RuntimeError, match='Missing key'):
         M.SuperPointMagicLeap().load_state_dict({k: v for k, v in sd.items() if k != 'convDb.bias'})
+
+
+def test_retired_switch_names_are_reported(oracle):
+    """Rounds 1-4 selected kernels with ~20 MP_* variables; round 5 folded them into MP_DEBUG=key[=value],...  A script that still
+    sets an old name would silently compare the default against itself: mp_create says so once on stderr (round-5 advisor)."""
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from multipoint_amd import _lib\n_lib.get_handle('cuda:0'); _lib.Handle(0)\nprint('created')\n" % ROOT)
+    env = dict(os.environ); env['MP_NO_WINOGRAD'] = '1'
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'created' in r.stdout, r.stderr[-1500:]
+    assert r.stderr.count('MP_NO_WINOGRAD is no longer read') == 1 and 'MP_DEBUG=key' in r.stderr
+    env.pop('MP_NO_WINOGRAD')
+    r = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and 'no longer read' not in r.stderr
 
 
 def test_forward_errors(oracle, shipped):

@@ -287,6 +287,26 @@ def test_committed_bench_line_follows_the_contract():
     assert d['parity']['desc_max_abs_err'] <= 1e-4
 
 
+def test_committed_round6_line_carries_the_exact_entry_and_the_upload():
+    """profiles/r06_bench_n1.json, the line of this round's collection: the contract fields, and the `secondary` rates the round-5
+    verdict asked to see under the driver's clock -- PairPipeline.run_converged at the headline shape and the PCIe-inclusive rate --
+    next to c5 / direct / batch1; `converged` within 3 % of `value`."""
+    import json
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'r06_bench_n1.json')))
+    base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
+    assert d['metric'].split(' @')[0] == base['metric'].split(' @')[0] and d['config']['workload'].startswith('BASELINE configs[2]')
+    assert d['n_gpus'] == 1 and d['dtype'] == 'f32' and d['input'] == 'resident in HBM' and d['vs_baseline'] is None
+    r = d['roofline']
+    assert r['bound'] == 'mfma' and r['peak'] == 157.3 and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-3 and r['traffic'] > 0
+    sec = d['secondary']
+    assert {'converged', 'host_input', 'c5', 'direct', 'batch1'} <= set(sec)
+    assert sec['converged']['pairs_per_s'] >= 0.97 * d['value'] and sec['host_input']['pairs_per_s'] >= 0.95 * d['value']
+    assert 'run_converged' in sec['converged']['workload'] and 'pinned host memory' in sec['host_input']['workload']
+    assert d['parity']['unexplained_keypoints'] == 0 and d['parity']['keypoints_differing'] <= 0.002 * d['parity']['keypoints_total']
+    assert d['parity']['structured']['auto']['keypoints_differing'] == 0
+    assert d['cpu_baseline']['value'] > 0 and d['cpu_baseline']['kind'] in ('reference', 'port')
+
+
 def test_bench_self_launches_ranks():
     """`python bench.py --gpus 2` outside torchrun starts the two ranks itself (child torchrun job, 127.0.0.1 rendezvous)
     and fails only because this container has no GPU -- in both ranks, not at a launcher check; a WORLD_SIZE that does
