@@ -160,9 +160,7 @@ int mp_nms_tie_guard(mp_handle* h, int min_pairs);
 int mp_topk_ambiguous(mp_handle* h, int* flags, int B, int* total, void* stream);
 
 /* replaces torch.nonzero(map > thr) on an arbitrary dense map; with valid_mask (uint8 [B][H][W] or NULL) it is
- * torch.nonzero((map > thr) * valid_mask) (multipoint/utils/evaluation.py:156-157, predict_keypoints.py:176-178).
- * Deviation: H * W must be a multiple of 4 (MP_EINVAL otherwise; every map the path produces is a multiple of 64 pixels -- the
- * model's frames are multiples of 8 -- while mp_box_nms / mp_detect_keypoints take any H x W). */
+ * torch.nonzero((map > thr) * valid_mask) (multipoint/utils/evaluation.py:156-157, predict_keypoints.py:176-178).  Any H x W. */
 int mp_extract_keypoints(mp_handle* h, const float* map, const unsigned char* valid_mask, int B, int H, int W, float thr,
                          int K, int* kp_yx, float* kp_score, int* kp_count, void* stream);
 

@@ -1361,8 +1361,8 @@ int mp_extract_keypoints(mp_handle* h, const float* map, const unsigned char* va
                          int K, int* kp_yx, float* kp_score, int* kp_count, void* stream)
 {
     if (!h) return MP_EINVAL;
-    if (!map || !kp_yx || !kp_count || K <= 0 || B <= 0 || ((long long)H * W) % 4 != 0)
-        return fail(h, MP_EINVAL, "mp_extract_keypoints: bad argument (H*W must be a multiple of 4)");
+    if (!map || !kp_yx || !kp_count || K <= 0 || B <= 0 || H <= 0 || W <= 0)
+        return fail(h, MP_EINVAL, "mp_extract_keypoints: bad argument");
     MP_HIP(hipSetDevice(h->device));
     int rc;
     if ((rc = ensure(h, h->kp_scratch, keypoint_scratch_ints(B, H, W) * 4))) return rc;

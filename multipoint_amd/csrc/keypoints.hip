@@ -61,7 +61,8 @@ template <int MODE>
 __device__ __forceinline__ bool keep_px(float v, float thr) { return MODE == 0 ? (v < 0.f) : (v > thr); }
 
 // pass 1: survivors per segment (and zeros_like(prob) for the dense NMS output, utils.py:119)
-template <int MODE>
+// VEC: n % 4 == 0 (16-byte loads); otherwise (mp_extract_keypoints on a map whose pixel count is no multiple of 4) four scalar loads with bounds
+template <int MODE, bool VEC = true>
 __global__ __launch_bounds__(BT) void count_segments_kernel(const float* __restrict__ map, int n, float thr, int nseg,
                                                             int* __restrict__ seg_count, float* __restrict__ zero_fill,
                                                             const unsigned char* __restrict__ mask)
@@ -72,8 +73,17 @@ __global__ __launch_bounds__(BT) void count_segments_kernel(const float* __restr
     const int lo = sg * SEG, hi = min(n, lo + SEG);
     int c = 0;
     for (int i = lo + threadIdx.x * 4; i < hi; i += BT * 4) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(img + i);          // n % 4 == 0
-        const uchar4 m = mask ? *reinterpret_cast<const uchar4*>(mask + (long long)b * n + i) : make_uchar4(1, 1, 1, 1);
+        f32x4 v;
+        uchar4 m = make_uchar4(1, 1, 1, 1);
+        if constexpr (VEC) {
+            v = *reinterpret_cast<const f32x4*>(img + i);          // n % 4 == 0
+            if (mask) m = *reinterpret_cast<const uchar4*>(mask + (long long)b * n + i);
+        } else {
+            const unsigned char* mk1 = mask ? mask + (long long)b * n : nullptr;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (i + e < hi) ? img[i + e] : (MODE == 0 ? 0.f : -__builtin_inff());      // beyond the map: never kept
+            if (mk1) m = make_uchar4(i < hi ? mk1[i] : 0, i + 1 < hi ? mk1[i + 1] : 0, i + 2 < hi ? mk1[i + 2] : 0, i + 3 < hi ? mk1[i + 3] : 0);
+        }
         const bool mk[4] = {m.x != 0, m.y != 0, m.z != 0, m.w != 0};      // (prob > thr) * valid_mask, evaluation.py:156-157
 #pragma unroll
         for (int e = 0; e < 4; ++e) c += keep_px<MODE>(v[e], thr) && mk[e];
@@ -85,7 +95,7 @@ __global__ __launch_bounds__(BT) void count_segments_kernel(const float* __restr
 }
 
 // pass 2: ordered write of the segment's survivors at the prefix of the segments before it
-template <int MODE>
+template <int MODE, bool VEC = true>
 __global__ __launch_bounds__(BT) void compact_segments_kernel(const float* __restrict__ map, int n, float thr, int W,
                                                               int nseg, const int* __restrict__ seg_count, int cap,
                                                               long long out_stride, int* __restrict__ o_idx,
@@ -107,8 +117,15 @@ __global__ __launch_bounds__(BT) void compact_segments_kernel(const float* __res
         f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
         uchar4 m = make_uchar4(1, 1, 1, 1);
         if (i < hi) {
-            v = *reinterpret_cast<const f32x4*>(img + i);
-            if (mask) m = *reinterpret_cast<const uchar4*>(mask + (long long)b * n + i);
+            if constexpr (VEC) {
+                v = *reinterpret_cast<const f32x4*>(img + i);
+                if (mask) m = *reinterpret_cast<const uchar4*>(mask + (long long)b * n + i);
+            } else {
+                const unsigned char* mk1 = mask ? mask + (long long)b * n : nullptr;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = (i + e < hi) ? img[i + e] : (MODE == 0 ? 0.f : -__builtin_inff());
+                if (mk1) m = make_uchar4(mk1[i], i + 1 < hi ? mk1[i + 1] : 0, i + 2 < hi ? mk1[i + 2] : 0, i + 3 < hi ? mk1[i + 3] : 0);
+            }
         }
         const bool mk[4] = {m.x != 0, m.y != 0, m.z != 0, m.w != 0};
         bool k[4];
@@ -279,9 +296,15 @@ void launch_extract_threshold(const float* map, const unsigned char* mask, int B
     if (B <= 0) return;
     const int n = H * W, nseg = (n + SEG - 1) / SEG;
     const dim3 g(nseg, B);
-    hipLaunchKernelGGL(count_segments_kernel<1>, g, dim3(BT), 0, s, map, n, thr, nseg, seg_scratch, (float*)nullptr, mask);
-    hipLaunchKernelGGL(compact_segments_kernel<1>, g, dim3(BT), 0, s, map, n, thr, W, nseg, seg_scratch, K, (long long)K,
-                       (int*)nullptr, kp_score, kp_yx, kp_count, mask);
+    if (n % 4 == 0) {
+        hipLaunchKernelGGL(count_segments_kernel<1>, g, dim3(BT), 0, s, map, n, thr, nseg, seg_scratch, (float*)nullptr, mask);
+        hipLaunchKernelGGL(compact_segments_kernel<1>, g, dim3(BT), 0, s, map, n, thr, W, nseg, seg_scratch, K, (long long)K,
+                           (int*)nullptr, kp_score, kp_yx, kp_count, mask);
+    } else {          // any H x W (torch.nonzero takes any map): scalar loads
+        hipLaunchKernelGGL((count_segments_kernel<1, false>), g, dim3(BT), 0, s, map, n, thr, nseg, seg_scratch, (float*)nullptr, mask);
+        hipLaunchKernelGGL((compact_segments_kernel<1, false>), g, dim3(BT), 0, s, map, n, thr, W, nseg, seg_scratch, K, (long long)K,
+                           (int*)nullptr, kp_score, kp_yx, kp_count, mask);
+    }
 }
 
 // ints of scratch the two launchers above need

@@ -480,6 +480,32 @@ def test_box_nms_edge_cases(oracle, U):
     assert np.array_equal(m[0][0, :int(m[2][0])].cpu().numpy(), np.argwhere((ramp > 0.5) & vm))
 
 
+@pytest.mark.parametrize('B,H,W', [(1, 37, 45), (3, 33, 131), (2, 5, 3), (2, 1, 1), (3, 129, 257), (2, 64, 66)])
+def test_extract_keypoints_any_frame(U, B, H, W):
+    """torch.nonzero((prob > thr) * valid_mask) (evaluation.py:156-157) takes any map: pixel counts that are no multiple of 4 (every
+    image of a batch then starts at an unaligned address), with and without a mask, row-major order, counts beyond the capacity."""
+    rng = np.random.default_rng(B * 100000 + H * 1000 + W)
+    p = rng.random((B, 1, H, W), dtype=np.float32)
+    vm = rng.random((B, 1, H, W)) < 0.6
+    for mask in (None, vm):
+        kp, sc, cnt = U.extract_keypoints(torch.from_numpy(p).cuda(), 0.5, capacity=H * W,
+                                          valid_mask=None if mask is None else torch.from_numpy(mask).cuda())
+        for b in range(B):
+            keep = p[b, 0] > 0.5 if mask is None else (p[b, 0] > 0.5) & mask[b, 0]
+            ref = np.argwhere(keep)
+            n = int(cnt[b])
+            assert n == len(ref)
+            assert np.array_equal(kp[b, :n].cpu().numpy().astype(np.int64), ref)
+            assert np.array_equal(sc[b, :n].cpu().numpy(), p[b, 0][keep])
+    K = max(1, (H * W) // 8)                                                   # capacity smaller than the count: first K in order, true count
+    kp, sc, cnt = U.extract_keypoints(torch.from_numpy(p).cuda(), 0.5, capacity=K)
+    for b in range(B):
+        ref = np.argwhere(p[b, 0] > 0.5)
+        assert int(cnt[b]) == len(ref)
+        m = min(K, len(ref))
+        assert np.array_equal(kp[b, :m].cpu().numpy().astype(np.int64), ref[:m])
+
+
 @pytest.mark.parametrize('H,W,size,iou,topk', [(37, 45, 4, 0.1, 0), (33, 131, 4, 0.1, 60), (40, 50, 11, 0.1, 0), (17, 23, 3, 0.05, 9),
                                                 (64, 101, 12, 0.1, 0), (48, 66, 16, 0.2, 5), (5, 3, 4, 0.1, 0), (31, 1, 2, 0.1, 0)])
 def test_box_nms_any_frame_and_large_boxes(oracle, U, H, W, size, iou, topk):
